@@ -1,0 +1,90 @@
+"""ctypes binding of libcurvegs.so (C ABI declared in include/curvegs.h).
+
+The product path has NO fallback: if the HIP library is missing or no GPU is present, calls raise.
+``load()`` only dlopens the library (works on a CPU-only box, used by the "symbols exported" tests).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcurvegs.so")
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+_vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+
+# name -> (restype, argtypes); kept in lock-step with include/curvegs.h (tests/test_abi.py parses the header)
+SIGNATURES = {
+    "cgs_last_error": (C.c_char_p, []),
+    "cgs_version": (_i, []),
+    "cgs_target_arch": (C.c_char_p, []),
+    "cgs_geometry_bytes": (C.c_size_t, [_i]),
+    "cgs_image_bytes": (C.c_size_t, [_i, _i]),
+    "cgs_binning_bytes": (C.c_size_t, [_i64]),
+    "cgs_prof_enable": (None, [_i]),
+    "cgs_prof_reset": (None, []),
+    "cgs_prof_collect": (_i, [C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_i64), _i]),
+    "cgs_rasterize_forward": (_i64, [ALLOC_FN, _vp, ALLOC_FN, _vp, ALLOC_FN, _vp, _i, _i, _i, _vp, _i, _i,
+                                     _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i,
+                                     _vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
+    "cgs_rasterize_backward": (_i, [_i, _i, _i, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp,
+                                    _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "cgs_mark_visible": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class CurveGSError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """dlopen libcurvegs.so and attach signatures.  Raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CurveGSError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C curve_gaussian_amd/csrc`). There is no CPU fallback.")
+    import torch  # noqa: F401  -- make sure torch's bundled libamdhip64.so.7 is the HIP runtime in this process
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().cgs_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what: str):
+    if rc < 0:
+        raise CurveGSError(f"{what} failed (status {rc}): {last_error()}")
+    return rc
+
+
+def require_gpu_tensor(t, name: str):
+    if not t.is_cuda:
+        raise CurveGSError(f"{name} must be a GPU tensor (got device {t.device}); libcurvegs has no CPU path")
+
+
+def ptr(t):
+    """Device pointer of a tensor, or NULL for None / empty tensors (the reference's 'empty tensor' convention)."""
+    if t is None or t.numel() == 0:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def prof_collect():
+    lib = load()
+    cap = 64
+    names = (C.c_char_p * cap)()
+    ms = (C.c_double * cap)()
+    n_l = (_i64 * cap)()
+    n = lib.cgs_prof_collect(names, ms, n_l, cap)
+    return {names[i].decode(): (ms[i], int(n_l[i])) for i in range(min(n, cap))}

@@ -1,0 +1,276 @@
+// C ABI of libcurvegs.so (see include/curvegs.h): host-side sequencing of the HIP kernels on the caller's stream.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace cgs {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---------------------------------------------------------------- per-kernel timing (bench.py roofline leg)
+static bool g_prof_on = false;
+struct ProfRec { hipEvent_t e0, e1; const char* name; };
+static std::vector<ProfRec> g_pending;
+static std::map<std::string, std::pair<double, int64_t>> g_totals;
+static std::vector<std::string> g_names_storage;
+static std::mutex g_prof_mu;
+
+ProfScope::ProfScope(const char* n, hipStream_t s) : name(n), stream(s), on(g_prof_on) {
+    if (on) {
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, stream);
+    }
+}
+ProfScope::~ProfScope() {
+    if (on) {
+        (void)hipEventRecord(e1, stream);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_pending.push_back({e0, e1, name});
+    }
+}
+
+bool check_launch(const char* what, bool debug, hipStream_t s) {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && debug) e = hipStreamSynchronize(s);  // reference CHECK_CUDA semantics, auxiliary.h:178-185
+    if (e != hipSuccess) {
+        set_error("%s failed: %s", what, hipGetErrorString(e));
+        return false;
+    }
+    return true;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace cgs
+
+using namespace cgs;
+
+extern "C" {
+
+const char* cgs_last_error(void) { return g_err; }
+int cgs_version(void) { return 100; }
+const char* cgs_target_arch(void) { return "gfx950"; }
+
+size_t cgs_geometry_bytes(int P) {
+    char* c = nullptr;
+    geom_from_chunk(c, (size_t)(P > 0 ? P : 1));
+    return (size_t)c + 128;
+}
+size_t cgs_image_bytes(int width, int height) {
+    char* c = nullptr;
+    const size_t tiles = (size_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+    image_from_chunk(c, (size_t)width * height, tiles);
+    return (size_t)c + 128;
+}
+size_t cgs_binning_bytes(int64_t R) {
+    char* c = nullptr;
+    bin_from_chunk(c, (size_t)(R > 0 ? R : 1));
+    return (size_t)c + 128;
+}
+
+void cgs_prof_enable(int on) { g_prof_on = on != 0; }
+void cgs_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    g_pending.clear();
+    g_totals.clear();
+}
+int cgs_prof_collect(const char** names, double* total_ms, int64_t* launches, int cap) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_pending) {
+        (void)hipEventSynchronize(r.e1);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            auto& t = g_totals[r.name];
+            t.first += ms;
+            t.second += 1;
+        }
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    g_pending.clear();
+    g_names_storage.clear();
+    for (auto& kv : g_totals) g_names_storage.push_back(kv.first);
+    int n = 0;
+    for (auto& kv : g_totals) {
+        if (n < cap) {
+            names[n] = g_names_storage[n].c_str();
+            total_ms[n] = kv.second.first;
+            launches[n] = kv.second.second;
+        }
+        n++;
+    }
+    return n;
+}
+
+int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, cgs_alloc_fn binning_alloc,
+                              void* binning_user, cgs_alloc_fn image_alloc, void* image_user, int P, int D, int M,
+                              const float* background, int width, int height, const float* means3D, const float* shs,
+                              const float* colors_precomp, const float* opacities, const float* scales,
+                              float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                              const float* all_map, const float* viewmatrix, const float* projmatrix,
+                              const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                              float* out_invdepth, float* out_all_map, int antialiasing, int render_geo, int* radii,
+                              int debug, void* stream_) {
+    (void)prefiltered;
+    hipStream_t s = (hipStream_t)stream_;
+    if (P < 0 || width <= 0 || height <= 0 || !out_color || !out_invdepth || !out_all_map || !background ||
+        !viewmatrix || !projmatrix) {
+        set_error("cgs_rasterize_forward: invalid argument (P=%d W=%d H=%d or NULL output/camera pointer)", P, width, height);
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    const size_t npix = (size_t)width * height;
+    if (P == 0) {  // rasterize_points.cu:91: outputs stay zero-filled, nothing is rendered (not even background)
+        if (hipMemsetAsync(out_color, 0, npix * 4, s) != hipSuccess || hipMemsetAsync(out_invdepth, 0, npix * 4, s) != hipSuccess ||
+            hipMemsetAsync(out_all_map, 0, npix * 16, s) != hipSuccess) {
+            set_error("hipMemsetAsync failed");
+            return CGS_ERR_HIP;
+        }
+        return 0;
+    }
+    if (!means3D || !opacities || !radii || (!shs == !colors_precomp) ||
+        (cov3D_precomp ? (scales || rotations) : (!scales || !rotations)) || (render_geo && !all_map) ||
+        (shs && (!cam_pos || M <= 0))) {
+        set_error("cgs_rasterize_forward: inconsistent inputs (need exactly one of shs/colors_precomp and one of "
+                  "(scales,rotations)/cov3D_precomp; all_map is required with render_geo)");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    if (!aligned16(rotations) || !aligned16(all_map)) {
+        set_error("cgs_rasterize_forward: rotations/all_map must be 16-byte aligned");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE;
+    const int tiles = gx * gy;
+    const float focal_y = height / (2.0f * tan_fovy);  // rasterizer_impl.cu:227-228
+    const float focal_x = width / (2.0f * tan_fovx);
+
+    char* gchunk = (char*)geometry_alloc(geometry_user, cgs_geometry_bytes(P));
+    char* ichunk = (char*)image_alloc(image_user, cgs_image_bytes(width, height));
+    if (!gchunk || !ichunk) {
+        set_error("cgs_rasterize_forward: geometry/image allocation callback returned NULL");
+        return CGS_ERR_ALLOC;
+    }
+    GeomState geom = geom_from_chunk(gchunk, (size_t)P);
+    ImageState img = image_from_chunk(ichunk, npix, (size_t)tiles);
+
+    // tile_count and tile_cursor are adjacent 128B-aligned carve-outs: clear both (+total) with one memset
+    const size_t clear_bytes = (size_t)((char*)(img.total + 4) - (char*)img.tile_count);
+    if (hipMemsetAsync(img.tile_count, 0, clear_bytes, s) != hipSuccess) {
+        set_error("hipMemsetAsync(tile histogram) failed");
+        return CGS_ERR_HIP;
+    }
+    launch_preprocess_fwd(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, geom.clamped,
+                          cov3D_precomp, colors_precomp, render_geo ? all_map : nullptr, viewmatrix, projmatrix,
+                          cam_pos, width, height, tan_fovx, tan_fovy, focal_x, focal_y, radii, geom.rec, geom.rgb, gx,
+                          gy, img.tile_count, antialiasing);
+    if (!check_launch("preprocess_fwd", debug, s)) return CGS_ERR_HIP;
+    launch_scan_tiles(s, tiles, img.tile_count, img.ranges, img.total);
+    if (!check_launch("scan_tiles", debug, s)) return CGS_ERR_HIP;
+
+    uint32_t R32 = 0;
+    hipError_t e = hipMemcpyAsync(&R32, img.total, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        set_error("reading num_rendered failed: %s", hipGetErrorString(e));
+        return CGS_ERR_HIP;
+    }
+    const int64_t R = (int64_t)R32;
+    char* bchunk = (char*)binning_alloc(binning_user, cgs_binning_bytes(R));
+    if (!bchunk) {
+        set_error("cgs_rasterize_forward: binning allocation callback returned NULL");
+        return CGS_ERR_ALLOC;
+    }
+    BinState bin = bin_from_chunk(bchunk, (size_t)(R > 0 ? R : 1));
+    if (R > 0) {
+        launch_scatter(s, P, radii, geom.rec, gx, gy, img.ranges, img.tile_cursor, bin.keys);
+        if (!check_launch("scatter", debug, s)) return CGS_ERR_HIP;
+        launch_tile_sort(s, tiles, img.ranges, bin.keys, bin.point_list);
+        if (!check_launch("tile_sort", debug, s)) return CGS_ERR_HIP;
+    }
+    launch_render_fwd(s, render_geo != 0, tiles, img.ranges, bin.point_list, width, height, gx, geom.rec, img.final_T,
+                      img.n_contrib, background, out_color, out_invdepth, out_all_map);
+    if (!check_launch("render_fwd", debug, s)) return CGS_ERR_HIP;
+    return R;
+}
+
+int cgs_rasterize_backward(int P, int D, int M, int64_t R, const float* background, int width, int height,
+                           const float* means3D, const float* shs, const float* colors_precomp, const float* all_map,
+                           const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                           const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                           const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii,
+                           const void* geometry_buffer, const void* binning_buffer, const void* image_buffer,
+                           const float* dL_dout_color, const float* dL_dout_invdepth, const float* dL_dout_all_map,
+                           float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                           float* dL_dinvdepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                           float* dL_drot, float* dL_dall_map, int antialiasing, int render_geo, int debug,
+                           void* stream_) {
+    (void)colors_precomp;
+    (void)all_map;
+    hipStream_t s = (hipStream_t)stream_;
+    if (P == 0) return CGS_OK;
+    if (P < 0 || width <= 0 || height <= 0 || !geometry_buffer || !binning_buffer || !image_buffer || !radii ||
+        !dL_dout_color || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D ||
+        !dL_dall_map || (!dL_dout_invdepth != !dL_dinvdepth) || (scales && (!dL_dscale || !dL_drot)) ||
+        (shs && !dL_dsh)) {
+        set_error("cgs_rasterize_backward: invalid argument");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    if (!aligned16(rotations) || !aligned16(dL_dconic) || !aligned16(dL_drot)) {
+        set_error("cgs_rasterize_backward: rotations/dL_dconic/dL_drot must be 16-byte aligned");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE;
+    const int tiles = gx * gy;
+    const size_t npix = (size_t)width * height;
+    const float focal_y = height / (2.0f * tan_fovy);
+    const float focal_x = width / (2.0f * tan_fovx);
+    char* gchunk = (char*)geometry_buffer;
+    char* bchunk = (char*)binning_buffer;
+    char* ichunk = (char*)image_buffer;
+    GeomState geom = geom_from_chunk(gchunk, (size_t)P);
+    BinState bin = bin_from_chunk(bchunk, (size_t)(R > 0 ? R : 1));
+    ImageState img = image_from_chunk(ichunk, npix, (size_t)tiles);
+
+    if (R > 0) {
+        launch_render_bwd(s, render_geo && dL_dout_all_map, dL_dout_invdepth != nullptr, tiles, img.ranges,
+                          bin.point_list, width, height, gx, background, geom.rec, img.final_T, img.n_contrib,
+                          dL_dout_color, dL_dout_invdepth, dL_dout_all_map, dL_dmean2D, dL_dconic, dL_dopacity,
+                          dL_dcolor, dL_dinvdepth, dL_dall_map);
+        if (!check_launch("render_bwd", debug, s)) return CGS_ERR_HIP;
+    }
+    launch_preprocess_bwd(s, P, D, M, means3D, radii, shs, geom.clamped, opacities, scales, rotations, scale_modifier,
+                          cov3D_precomp, viewmatrix, projmatrix, cam_pos, focal_x, focal_y, tan_fovx, tan_fovy,
+                          dL_dmean2D, dL_dconic, dL_dinvdepth, dL_dopacity, dL_dmean3D, dL_dcolor, dL_dcov3D, dL_dsh,
+                          dL_dscale, dL_drot, antialiasing);
+    if (!check_launch("preprocess_bwd", debug, s)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
+
+int cgs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                     void* stream_) {
+    (void)projmatrix;
+    if (P == 0) return CGS_OK;
+    if (P < 0 || !means3D || !viewmatrix || !present) {
+        set_error("cgs_mark_visible: invalid argument");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    launch_mark_visible((hipStream_t)stream_, P, means3D, viewmatrix, present);
+    if (!check_launch("mark_visible", false, (hipStream_t)stream_)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
+
+}  // extern "C"

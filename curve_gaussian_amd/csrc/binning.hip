@@ -1,0 +1,146 @@
+// Tile binning: replaces the reference's scan + duplicateWithKeys + 64-bit global radix sort + identifyTileRanges
+// (K2-K5: rasterizer_impl.cu:70-138, :283-324) with a counting sort by tile followed by a per-tile LDS sort.
+//
+//   k_preprocess_fwd   counts instances per tile (atomics on a [tiles] histogram)
+//   k_scan_tiles       exclusive scan of the histogram -> ranges[tile] = [start,end), total R
+//   k_scatter          each splat claims a slot in every tile bucket of its rect and writes the 64-bit key
+//                      (depth_bits << 32) | splat_idx
+//   k_tile_sort        one workgroup per tile sorts its bucket in LDS and emits point_list
+//
+// Ordering contract: the reference's stable radix sort on (tile << 32 | depth_bits) leaves ties in emission
+// order = ascending splat index.  Sorting each tile's bucket by the unique key
+// (depth_bits, splat_idx) reproduces exactly that order, independent of the (non-deterministic) slot order
+// produced by the atomics in k_scatter.
+#include "kernels.h"
+
+namespace cgs {
+
+// Single workgroup, 1024 threads; tiles can be any size (loops with a running carry).
+__global__ void __launch_bounds__(1024) k_scan_tiles(int tiles, const uint32_t* __restrict__ tile_count,
+                                                     uint2* __restrict__ ranges, uint32_t* __restrict__ total) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < tiles; base += 1024) {
+        const int i = base + tid;
+        const uint32_t v = (i < tiles) ? tile_count[i] : 0u;
+        // inclusive scan inside the wave
+        uint32_t s = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t n = __shfl_up(s, off, 64);
+            if (lane >= off) s += n;
+        }
+        if (lane == 63) wave_tot[wid] = s;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wid; w++) woff += wave_tot[w];
+        const uint32_t carry = carry_s;
+        const uint32_t incl = carry + woff + s;
+        if (i < tiles) ranges[i] = make_uint2(incl - v, incl);
+        __syncthreads();
+        if (tid == 1023) carry_s = incl;
+        __syncthreads();
+    }
+    if (tid == 0) total[0] = carry_s;
+}
+
+__global__ void __launch_bounds__(256) k_scatter(int P, const int* __restrict__ radii,
+                                                 const SplatRec* __restrict__ rec, int grid_x, int grid_y,
+                                                 const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_cursor,
+                                                 uint64_t* __restrict__ keys) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    const int radius = radii[idx];
+    if (radius <= 0) return;
+    const float4 a = rec[idx].a;
+    const float depth = rec[idx].d.x;
+    uint2 rmin, rmax;
+    get_rect(a.x, a.y, radius, grid_x, grid_y, rmin, rmax);
+    const uint64_t key = ((uint64_t)__float_as_uint(depth) << 32) | (uint32_t)idx;
+    for (uint32_t y = rmin.y; y < rmax.y; y++)
+        for (uint32_t x = rmin.x; x < rmax.x; x++) {
+            const uint32_t tile = y * grid_x + x;
+            const uint32_t slot = atomicAdd(&tile_cursor[tile], 1u);
+            keys[ranges[tile].x + slot] = key;
+        }
+}
+
+// Ascending bitonic network in its "flip + disperse" form: every compare-exchange puts the smaller key at the
+// lower index, so indices >= n can be treated as +inf and simply skipped -- any n works without padding.
+template <typename Ptr>
+__device__ __forceinline__ void bitonic_any_n(Ptr k, uint32_t n, uint32_t n2, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t size = 2; size <= n2; size <<= 1) {
+        // flip: i <-> (block_end - 1 - i)
+        for (uint32_t t = tid; t < n2 / 2; t += nthreads) {
+            const uint32_t half = size >> 1;
+            const uint32_t blk = t / half, j = t % half;
+            const uint32_t lo = blk * size + j, hi = blk * size + size - 1 - j;
+            if (hi < n) {
+                const uint64_t a = k[lo], b = k[hi];
+                if (a > b) { k[lo] = b; k[hi] = a; }
+            }
+        }
+        __syncthreads();
+        for (uint32_t d = size >> 2; d >= 1; d >>= 1) {
+            for (uint32_t t = tid; t < n2 / 2; t += nthreads) {
+                const uint32_t lo = 2 * d * (t / d) + (t % d), hi = lo + d;
+                if (hi < n) {
+                    const uint64_t a = k[lo], b = k[hi];
+                    if (a > b) { k[lo] = b; k[hi] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+constexpr uint32_t SORT_LDS_KEYS = 4096;  // 32 KiB of LDS per workgroup
+
+__global__ void __launch_bounds__(256) k_tile_sort(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
+                                                   uint32_t* __restrict__ point_list) {
+    __shared__ uint64_t sk[SORT_LDS_KEYS];
+    const uint2 rg = ranges[blockIdx.x];
+    const uint32_t n = rg.y - rg.x;
+    if (n == 0) return;
+    const uint32_t tid = threadIdx.x;
+    uint64_t* gk = keys + rg.x;
+    uint32_t* out = point_list + rg.x;
+    if (n == 1) {
+        if (tid == 0) out[0] = (uint32_t)gk[0];
+        return;
+    }
+    uint32_t n2 = 2;
+    while (n2 < n) n2 <<= 1;
+    if (n <= SORT_LDS_KEYS) {
+        for (uint32_t i = tid; i < n; i += 256) sk[i] = gk[i];
+        __syncthreads();
+        bitonic_any_n(sk, n, n2, tid, 256u);
+        for (uint32_t i = tid; i < n; i += 256) out[i] = (uint32_t)sk[i];
+    } else {
+        // rare oversized bucket: same network directly on global memory (one workgroup => __syncthreads orders it)
+        bitonic_any_n(gk, n, n2, tid, 256u);
+        for (uint32_t i = tid; i < n; i += 256) out[i] = (uint32_t)gk[i];
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------ launchers
+void launch_scan_tiles(hipStream_t s, int tiles, const uint32_t* tile_count, uint2* ranges, uint32_t* total) {
+    ProfScope p("scan_tiles", s);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tiles, tile_count, ranges, total);
+}
+void launch_scatter(hipStream_t s, int P, const int* radii, const SplatRec* rec, int grid_x, int grid_y,
+                    const uint2* ranges, uint32_t* tile_cursor, uint64_t* keys) {
+    ProfScope p("scatter", s);
+    hipLaunchKernelGGL(k_scatter, dim3((P + 255) / 256), dim3(256), 0, s, P, radii, rec, grid_x, grid_y, ranges,
+                       tile_cursor, keys);
+}
+void launch_tile_sort(hipStream_t s, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* point_list) {
+    ProfScope p("tile_sort", s);
+    hipLaunchKernelGGL(k_tile_sort, dim3(tiles), dim3(256), 0, s, ranges, keys, point_list);
+}
+
+}  // namespace cgs

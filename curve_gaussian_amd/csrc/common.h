@@ -1,0 +1,175 @@
+// Shared device/host helpers for libcurvegs (gfx950 / CDNA4 only: wave64, DPP, permlane swaps).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/curvegs.h"
+
+namespace cgs {
+
+constexpr int TILE = 16;            // tile edge in pixels (reference config.h:17-18)
+constexpr int TILE_PIX = TILE * TILE;
+constexpr int NUM_ALL_MAP = 4;      // reference config.h:16
+
+// Per-splat render record written by preprocess and gathered by the render kernels: one 64-byte line.
+//   a = {mean2D.x, mean2D.y, conic.x, conic.y}
+//   b = {conic.z, opacity(*AA scale), colour, 1/depth}
+//   c = all_map[0..3]
+//   d = {depth, -, -, -}
+struct __attribute__((aligned(64))) SplatRec {
+    float4 a, b, c, d;
+};
+
+struct GeomState {            // carved from the geometry buffer
+    SplatRec* rec;            // [P]
+    float* rgb;               // [P]   SH-evaluated colour (SH path only)
+    uint8_t* clamped;         // [P]
+};
+struct ImageState {           // carved from the image buffer
+    float* final_T;           // [H*W]
+    uint32_t* n_contrib;      // [H*W]
+    uint2* ranges;            // [tiles]  [start,end) in the sorted list
+    uint32_t* tile_count;     // [tiles]
+    uint32_t* tile_cursor;    // [tiles]
+    uint32_t* total;          // [4]      [0] = R
+};
+struct BinState {             // carved from the binning buffer
+    uint64_t* keys;           // [R]  (depth_bits << 32) | splat_idx, bucketed by tile, unsorted inside a bucket
+    uint32_t* point_list;     // [R]  splat idx, sorted by (tile, depth_bits, idx)
+};
+
+template <typename T>
+static inline void carve(char*& chunk, T*& ptr, size_t count) {
+    uintptr_t off = (reinterpret_cast<uintptr_t>(chunk) + 127) & ~uintptr_t(127);
+    ptr = reinterpret_cast<T*>(off);
+    chunk = reinterpret_cast<char*>(ptr + count);
+}
+static inline GeomState geom_from_chunk(char*& chunk, size_t P) {
+    GeomState g;
+    carve(chunk, g.rec, P);
+    carve(chunk, g.rgb, P);
+    carve(chunk, g.clamped, P);
+    return g;
+}
+static inline ImageState image_from_chunk(char*& chunk, size_t npix, size_t tiles) {
+    ImageState s;
+    carve(chunk, s.final_T, npix);
+    carve(chunk, s.n_contrib, npix);
+    carve(chunk, s.ranges, tiles);
+    carve(chunk, s.tile_count, tiles);
+    carve(chunk, s.tile_cursor, tiles);
+    carve(chunk, s.total, 4);
+    return s;
+}
+static inline BinState bin_from_chunk(char*& chunk, size_t R) {
+    BinState b;
+    carve(chunk, b.keys, R);
+    carve(chunk, b.point_list, R);
+    return b;
+}
+
+// ---------------------------------------------------------------- device math shared by fwd and bwd
+#ifdef __HIPCC__
+__device__ __forceinline__ float3 xform4x3(const float3 p, const float* __restrict__ m) {
+    return make_float3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+                       m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]);
+}
+__device__ __forceinline__ float4 xform4x4(const float3 p, const float* __restrict__ m) {
+    return make_float4(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+                       m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14], m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15]);
+}
+// reference auxiliary.h:40-43 (double because of the 1.0 / 0.5 literals)
+__device__ __forceinline__ float ndc2pix(float v, int S) { return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5); }
+
+// reference auxiliary.h:45-55
+__device__ __forceinline__ void get_rect(float px, float py, int max_radius, int gx, int gy, uint2& rmin, uint2& rmax) {
+    rmin.x = (uint32_t)min(gx, max(0, (int)((px - (float)max_radius) / (float)TILE)));
+    rmin.y = (uint32_t)min(gy, max(0, (int)((py - (float)max_radius) / (float)TILE)));
+    rmax.x = (uint32_t)min(gx, max(0, (int)((px + (float)max_radius + (float)(TILE - 1)) / (float)TILE)));
+    rmax.y = (uint32_t)min(gy, max(0, (int)((py + (float)max_radius + (float)(TILE - 1)) / (float)TILE)));
+}
+
+// Rotation of the UN-normalised quaternion q = (r,x,y,z), rows R[0..2] (reference forward.cu:127-138: its glm
+// matrix is the transpose of this one).
+__device__ __forceinline__ void quat_rows(const float4 q, float R[3][3]) {
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
+    R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
+    R[2][0] = 2.f * (x * z - r * y); R[2][1] = 2.f * (y * z + r * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+// Sigma = Rq diag(s^2) Rq^T, packed upper triangle (reference forward.cu:118-152)
+__device__ __forceinline__ void cov3d_from_scale_rot(const float3 scale, float mod, const float4 q, float cov[6]) {
+    float R[3][3];
+    quat_rows(q, R);
+    const float s[3] = {mod * scale.x, mod * scale.y, mod * scale.z};
+    float Mm[3][3];  // Mm[k][a] = s_k * R[a][k]
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int a = 0; a < 3; a++) Mm[k][a] = s[k] * R[a][k];
+    auto sg = [&](int a, int b) { return Mm[0][a] * Mm[0][b] + Mm[1][a] * Mm[1][b] + Mm[2][a] * Mm[2][b]; };
+    cov[0] = sg(0, 0); cov[1] = sg(0, 1); cov[2] = sg(0, 2); cov[3] = sg(1, 1); cov[4] = sg(1, 2); cov[5] = sg(2, 2);
+}
+// EWA projection terms shared by preprocess fwd (forward.cu:78-113) and bwd (backward.cu:172-205):
+// t = clamped view-space mean, Mt = Jm * Rwc (2x3), cov = Mt Sigma Mt^T as (a,b,c).
+__device__ __forceinline__ void cov2d_terms(const float3 mean, float fx, float fy, float tan_fovx, float tan_fovy,
+                                            const float cov3D[6], const float* __restrict__ vm, float3& t,
+                                            float Mt[2][3], float3& cov, float& txtz, float& tytz) {
+    t = xform4x3(mean, vm);
+    const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
+    txtz = t.x / t.z;
+    tytz = t.y / t.z;
+    t.x = fminf(limx, fmaxf(-limx, txtz)) * t.z;
+    t.y = fminf(limy, fmaxf(-limy, tytz)) * t.z;
+    const float J00 = fx / t.z, J02 = -(fx * t.x) / (t.z * t.z);
+    const float J11 = fy / t.z, J12 = -(fy * t.y) / (t.z * t.z);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        Mt[0][j] = vm[j * 4 + 0] * J00 + vm[j * 4 + 2] * J02;
+        Mt[1][j] = vm[j * 4 + 1] * J11 + vm[j * 4 + 2] * J12;
+    }
+    const float V[3][3] = {{cov3D[0], cov3D[1], cov3D[2]}, {cov3D[1], cov3D[3], cov3D[4]}, {cov3D[2], cov3D[4], cov3D[5]}};
+    float U[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) U[i][j] = Mt[i][0] * V[0][j] + Mt[i][1] * V[1][j] + Mt[i][2] * V[2][j];
+    cov.x = U[0][0] * Mt[0][0] + U[0][1] * Mt[0][1] + U[0][2] * Mt[0][2];
+    cov.y = U[0][0] * Mt[1][0] + U[0][1] * Mt[1][1] + U[0][2] * Mt[1][2];
+    cov.z = U[1][0] * Mt[1][0] + U[1][1] * Mt[1][1] + U[1][2] * Mt[1][2];
+}
+
+// ---------------------------------------------------------------- wave64 reductions (DPP, no LDS)
+// Sum over the 16 lanes of each DPP row; every lane of the row ends up holding the row sum.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    return v;
+}
+// Full wave64 sum, valid in every lane (4 DPP steps + 2 cross-row steps through readlane).
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+__device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+#endif  // __HIPCC__
+
+// ---------------------------------------------------------------- host-side launch bookkeeping
+void set_error(const char* fmt, ...);
+struct ProfScope {  // brackets one kernel launch with events when profiling is enabled
+    ProfScope(const char* name, hipStream_t s);
+    ~ProfScope();
+    const char* name;
+    hipStream_t stream;
+    hipEvent_t e0, e1;
+    bool on;
+};
+bool check_launch(const char* what, bool debug, hipStream_t s);
+
+}  // namespace cgs

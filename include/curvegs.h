@@ -1,0 +1,136 @@
+/*
+ * curvegs.h -- C ABI of libcurvegs.so, the MI355X (gfx950) native curve-Gaussian hot path.
+ *
+ * Drop-in boundary: these entry points are what the reference's torch extension shims
+ * (/root/reference/submodules/diff-cur-rasterization/rasterize_points.cu, submodules/fused-ssim/ssim.cu,
+ * submodules/simple-knn/spatial.cu) call into, restated with plain pointers, sizes and a HIP stream.
+ * No torch types cross this boundary.  All pointers are DEVICE pointers unless marked "host".
+ * Every function returns 0 (CGS_OK) / a non-negative count on success and a negative cgs_status on
+ * failure; cgs_last_error() returns a thread-local message for the last failure.
+ *
+ * Memory is caller-owned.  The rasterizer's scratch state lives in three byte buffers obtained through
+ * caller-supplied allocation callbacks, exactly like the reference's std::function<char*(size_t)>
+ * resize callbacks (rasterize_points.cu:27-33, cuda_rasterizer/rasterizer.h:24-60); the same three
+ * buffers are handed back to cgs_rasterize_backward.
+ */
+#ifndef CURVEGS_H_INCLUDED
+#define CURVEGS_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum cgs_status {
+    CGS_OK = 0,
+    CGS_ERR_INVALID_ARGUMENT = -1,
+    CGS_ERR_HIP = -2,          /* a HIP runtime call or kernel launch failed; see cgs_last_error() */
+    CGS_ERR_ALLOC = -3,        /* an allocation callback returned NULL */
+    CGS_ERR_NO_DEVICE = -4
+} cgs_status;
+
+/* Caller-supplied allocator: must return a device pointer to at least `bytes` bytes (any alignment >= 16;
+ * the library aligns its carve-outs to 128 B itself), valid until the matching backward has run. */
+typedef void* (*cgs_alloc_fn)(void* user, size_t bytes);
+
+const char* cgs_last_error(void);
+int cgs_version(void);
+/* Name of the GPU ISA this library was compiled for ("gfx950"). */
+const char* cgs_target_arch(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Rasterizer.  Replaces CudaRasterizer::Rasterizer::{forward,backward,markVisible}
+ * (cuda_rasterizer/rasterizer.h:24-98; bodies cuda_rasterizer/rasterizer_impl.cu:198-347, :351-466, :141-153)
+ * as called from RasterizeGaussiansCUDA / RasterizeGaussiansBackwardCUDA / markVisible
+ * (rasterize_points.cu:35-130, :132-239, :241-260).
+ *
+ * Fixed by the reference's config.h: 1 colour channel, 4 "all_map" channels.
+ * NULL for shs / colors_precomp / scales / rotations / cov3D_precomp / all_map plays the role of the
+ * reference's empty tensors.  Exactly one of (shs, colors_precomp) and one of ((scales,rotations),
+ * cov3D_precomp) must be non-NULL.  SH layout is the reference's single-channel [P, M] float layout
+ * (forward.cu:32-33).
+ *
+ * cgs_rasterize_forward:
+ *   out_color [1,H,W], out_invdepth [1,H,W], out_all_map [4,H,W] f32, radii [P] i32 are fully written
+ *   (no pre-zeroing required).  Returns num_rendered (#(splat,tile) instances binned) >= 0, which the
+ *   caller passes back as R.  Performs one stream synchronisation (to size the binning buffer), like
+ *   the reference's blocking 4-byte D2H copy (rasterizer_impl.cu:287).
+ * ------------------------------------------------------------------------------------------------ */
+int64_t cgs_rasterize_forward(
+    cgs_alloc_fn geometry_alloc, void* geometry_user,
+    cgs_alloc_fn binning_alloc, void* binning_user,
+    cgs_alloc_fn image_alloc, void* image_user,
+    int P, int D, int M,
+    const float* background,      /* [3]; only [0] is read (1 channel) */
+    int width, int height,
+    const float* means3D,         /* [P,3] */
+    const float* shs,             /* [P,M] or NULL */
+    const float* colors_precomp,  /* [P,1] or NULL */
+    const float* opacities,       /* [P,1] */
+    const float* scales,          /* [P,3] or NULL */
+    float scale_modifier,
+    const float* rotations,       /* [P,4] (w,x,y,z), used UN-normalised, or NULL */
+    const float* cov3D_precomp,   /* [P,6] or NULL */
+    const float* all_map,         /* [P,4] or NULL (required when render_geo) */
+    const float* viewmatrix,      /* [16], column-major math matrix = row-major transposed torch tensor */
+    const float* projmatrix,      /* [16] */
+    const float* cam_pos,         /* [3] */
+    float tan_fovx, float tan_fovy,
+    int prefiltered,
+    float* out_color, float* out_invdepth, float* out_all_map,
+    int antialiasing, int render_geo,
+    int* radii,
+    int debug,
+    void* stream /* hipStream_t */);
+
+/* cgs_rasterize_backward:
+ *   ACCUMULATED outputs (must be zero on entry, as the reference's shim zero-fills them,
+ *   rasterize_points.cu:173-193): dL_dmean2D [P,3] (only .x,.y written, NDC-scaled, quirk 9),
+ *   dL_dconic [P,4] (.x,.y,.w), dL_dopacity [P], dL_dcolor [P,1], dL_dinvdepth [P] (may be NULL together with
+ *   dL_dout_invdepth), dL_dall_map [P,4].
+ *   WRITTEN outputs (no pre-zeroing required): dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dscale [P,3], dL_drot [P,4];
+ *   dL_dsh [P,M] is written for visible splats when shs != NULL (zero it on entry).
+ *   dL_dout_all_map may be NULL (treated as zeros) -- lets the autograd wrapper skip materialising unused grads.
+ */
+int cgs_rasterize_backward(
+    int P, int D, int M, int64_t R,
+    const float* background,
+    int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* all_map,
+    const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+    const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+    float tan_fovx, float tan_fovy,
+    const int* radii,
+    const void* geometry_buffer, const void* binning_buffer, const void* image_buffer,
+    const float* dL_dout_color,     /* [1,H,W] */
+    const float* dL_dout_invdepth,  /* [1,H,W] or NULL */
+    const float* dL_dout_all_map,   /* [4,H,W] or NULL */
+    float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dinvdepth,
+    float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dall_map,
+    int antialiasing, int render_geo, int debug,
+    void* stream);
+
+/* present[i] = (view-space z of means3D[i] > 0.2); rasterizer_impl.cu:54-66 */
+int cgs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, void* stream);
+
+/* Byte sizes the allocation callbacks will be asked for (exposed for callers that pre-allocate). */
+size_t cgs_geometry_bytes(int P);
+size_t cgs_image_bytes(int width, int height);
+size_t cgs_binning_bytes(int64_t R);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-kernel timing hook used by bench.py: when enabled, every kernel launched by the library is
+ * bracketed by hipEvents on the caller's stream; cgs_prof_collect synchronises and accumulates.
+ * ------------------------------------------------------------------------------------------------ */
+void cgs_prof_enable(int on);
+void cgs_prof_reset(void);
+/* Fills up to `cap` entries; returns the number of distinct kernels seen.  names[i] points to static storage. */
+int cgs_prof_collect(const char** names, double* total_ms, int64_t* launches, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CURVEGS_H_INCLUDED */

@@ -1,0 +1,66 @@
+"""Shared helpers for the parity tests: run the CPU oracle and the HIP path on identical inputs and compare."""
+import math
+
+import numpy as np
+import torch
+
+from curve_gaussian_amd import synthetic as S
+from oracle import raster as ORA
+
+REL_TOL = 1e-4          # north-star tolerance (BASELINE.json: "within 1e-4 rel")
+OUTLIER_FRAC = 1e-4     # budget for alpha<1/255 / T<1e-4 threshold flips under different expf rounding
+
+
+def tanfov(cam):
+    return math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+
+
+def oracle_forward(sp, cam, bg, render_geo=True, antialiasing=False, scale_modifier=1.0, cov3D=None, sh=None, degree=0):
+    tfx, tfy = tanfov(cam)
+    n = lambda t: None if t is None else t.detach().cpu().numpy()
+    use_cov = cov3D is not None
+    return ORA.forward(n(bg), n(sp["means3D"]), None if sh is not None else n(sp["colors"]), n(sp["opacities"]),
+                       None if use_cov else n(sp["scales"]), None if use_cov else n(sp["rotations"]), scale_modifier,
+                       n(cov3D), n(sp["all_map"]), n(cam.world_view_transform), n(cam.full_proj_transform), tfx, tfy,
+                       cam.image_height, cam.image_width, n(sh), degree, n(cam.camera_center),
+                       antialiasing=antialiasing, render_geo=render_geo)
+
+
+def hip_settings(cam, bg, dev, render_geo=True, antialiasing=False, scale_modifier=1.0, degree=0, debug=False):
+    from curve_gaussian_amd.diff_cur_rasterization import GaussianRasterizationSettings
+    tfx, tfy = tanfov(cam)
+    c = cam.to(dev)
+    return GaussianRasterizationSettings(
+        image_height=cam.image_height, image_width=cam.image_width, tanfovx=tfx, tanfovy=tfy, bg=bg.to(dev),
+        scale_modifier=scale_modifier, viewmatrix=c.world_view_transform, projmatrix=c.full_proj_transform,
+        sh_degree=degree, campos=c.camera_center, prefiltered=False, debug=debug, antialiasing=antialiasing,
+        render_geo=render_geo)
+
+
+def close_frac(a, b, rel=REL_TOL, abs_floor=None):
+    """fraction of elements with |a-b| > rel * max|b| (+ floor), and the worst normalised error."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    if a.size == 0:
+        return 0.0, 0.0
+    scale = np.abs(b).max()
+    tol = rel * scale + (abs_floor if abs_floor is not None else 1e-7)
+    err = np.abs(a - b)
+    return float((err > tol).mean()), float(err.max() / (scale + 1e-30))
+
+
+def assert_close(name, a, b, rel=REL_TOL, outlier_frac=OUTLIER_FRAC, abs_floor=None):
+    frac, worst = close_frac(a, b, rel, abs_floor)
+    assert frac <= outlier_frac, f"{name}: {frac:.2e} of elements exceed rel tol {rel} (worst normalised err {worst:.3e})"
+    return worst
+
+
+def carve_offsets(base_ptr_mod, counts_and_sizes):
+    """Replicates csrc/common.h::carve (128-byte aligned carve-outs) for tests that decode the scratch buffers."""
+    offs = []
+    cur = base_ptr_mod
+    for count, size in counts_and_sizes:
+        cur = (cur + 127) & ~127
+        offs.append(cur - base_ptr_mod)
+        cur += count * size
+    return offs
