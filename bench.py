@@ -1,0 +1,230 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the curve-Gaussian hot path on MI355X.
+
+Metric (BASELINE.json): Msplats rasterized/s, forward+backward, plus train-step ms and the HBM-roofline fraction.
+A "step" is one pass of the per-view hot path over one view of the synthetic workload:
+    rasterizer forward  (preprocess -> tile binning + per-tile depth sort -> alpha-composite)
+  + rasterizer backward (dL/d{mean2D,conic,opacity,colour,all_map} -> dL/d{mean3D,scale,rotation})
+with inputs already resident in HBM (SURVEY.md section 8d "raster-only benchmark": dL_dcolor ~ N(0,1)*1e-3,
+dL_dinvdepth = dL_dall_map = 0 as in training).  Default workload = BASELINE cfg3 (the configuration the north-star
+target is quoted on): 16 667 curves x 12 = 200 004 splats, 1600x1600, Fibonacci-sphere cameras.
+
+    python bench.py --gpus 1 --steps 64 --warmup 8
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: views shard across ranks (rank r renders views r, r+N, ...), weak scaling (K views per rank); the
+per-step exchange is ONE RCCL all-reduce of the flat curve-level gradient buffer.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+
+
+def algorithmic_bytes(P, R, H, W, passes=6):
+    """compulsory traffic of the REFERENCE algorithm per view, fwd+bwd."""
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    return 480 * P + (228 + 24 * passes) * R + 64 * H * W + 32 * tiles
+
+
+KERNEL_ALG_BYTES = {
+    # per-launch algorithmic bytes of each kernel (same table, split per reference kernel)
+    "render_bwd": lambda P, R, HW, T: 148 * R + 32 * HW + 8 * T,        # K8: 52 r + 96 rmw per instance, 32 B/px, 8 B/tile
+    "render_fwd": lambda P, R, HW, T: 52 * R + 32 * HW + 8 * T,         # K6
+    "preprocess_fwd": lambda P, R, HW, T: 104 * P,                      # K1 44 r + 60 w
+    "preprocess_bwd": lambda P, R, HW, T: 228 * P,                      # K9 (60+36) + K10 (92+40)
+    "tile_sort": lambda P, R, HW, T: (8 + 24 * 6) * R,                  # K4 histogram + 6 radix passes
+    "scatter": lambda P, R, HW, T: 20 * P + 12 * R,                     # K3
+    "scan_tiles": lambda P, R, HW, T: 8 * P + 16 * T,                   # K2 (+K5 range writes)
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-times", action="store_true")
+    ap.add_argument("--cpu-views", type=int, default=2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist = None
+
+    from curve_gaussian_amd import _lib as L
+    from curve_gaussian_amd import synthetic as S
+    from curve_gaussian_amd.diff_cur_rasterization import _C
+    from curve_gaussian_amd.ops import curve_sampling
+    lib = L.load()
+
+    # ---------------------------------------------------------------- workload (resident in HBM before timing)
+    K, Wm = args.steps, args.warmup
+    curves, cams = S.make_config(args.config)
+    B = curves["curve_points"].shape[0]
+    m = S.N_GAUSSIANS
+    xyz, rot, scl = curve_sampling.sample_curves(curves["curve_points"].to(dev), curves["width"].to(dev),
+                                                 curves["is_bezier"].to(dev), m)
+    P = xyz.shape[0]
+    rotn = torch.nn.functional.normalize(rot).contiguous()
+    opac = torch.sigmoid(curves["opacity"].to(dev)).unsqueeze(1).expand(-1, m, -1).reshape(-1, 1).contiguous()
+    colors = torch.ones(P, 1, device=dev)
+    H, W = cams[0].image_height, cams[0].image_width
+    bg = torch.zeros(3, device=dev)
+    n_my = K + Wm
+    my_cams = [cams[(rank + i * world) % len(cams)].to(dev) for i in range(n_my)]
+    tanx, tany = math.tan(cams[0].FoVx * 0.5), math.tan(cams[0].FoVy * 0.5)
+    # per-view direction map (gaussian_renderer/__init__.py:98-104) precomputed: raster-only benchmark
+    Rm = curve_sampling.quaternion_to_matrix(rotn)[..., 0]
+    amaps = {}
+    for c in {id(c): c for c in my_cams}.values():
+        neg = (Rm * (c.camera_center - xyz)).sum(-1) < 0
+        d = torch.where(neg[:, None], -Rm, Rm) @ c.world_view_transform[:3, :3]
+        amaps[id(c)] = torch.cat([d, torch.ones(P, 1, device=dev)], 1).contiguous()
+    g = torch.Generator(device="cpu").manual_seed(103)
+    dL_dcolor = (torch.randn(1, H, W, generator=g) * 1e-3).to(dev)
+    empty = torch.empty(0, device=dev)
+    # flat curve-level gradient buffer exchanged per step (38 floats / curve)
+    flat_grads = torch.zeros(B * 38, device=dev)
+
+    stats = {"R": 0, "visible": 0}
+
+    def step(cam, collect=False):
+        (R, color, radii, gB, bB, iB, invd, om) = _C.rasterize_gaussians(
+            bg, xyz, colors, opac, scl, rotn, 1.0, empty, amaps[id(cam)], cam.world_view_transform,
+            cam.full_proj_transform, tanx, tany, H, W, empty, 0, cam.camera_center, False, False, True, False)
+        grads = _C.rasterize_gaussians_backward(
+            bg, empty, xyz, radii, colors, amaps[id(cam)], opac, scl, rotn, 1.0, empty, cam.world_view_transform,
+            cam.full_proj_transform, tanx, tany, dL_dcolor, empty, empty, empty, 0, cam.camera_center, gB, R, bB, iB,
+            False, True, False)
+        if world > 1:
+            dist.all_reduce(flat_grads)
+        if collect:
+            stats["R"] += R
+            stats["visible"] += int((radii > 0).sum())
+        return grads
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(Wm):
+        step(my_cams[i])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(my_cams[Wm + i])
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---------------------------------------------------------------- per-kernel times (HIP events on the launch stream)
+    kernel_ms = {}
+    if not args.no_kernel_times and rank == 0:
+        lib.cgs_prof_reset()
+        lib.cgs_prof_enable(1)
+        n_prof = min(K, 16)
+        for i in range(n_prof):
+            step(my_cams[Wm + i], collect=True)
+        torch.cuda.synchronize()
+        lib.cgs_prof_enable(0)
+        for name, (ms, n) in L.prof_collect().items():
+            kernel_ms[name] = ms / max(n, 1)
+        R_mean = stats["R"] / n_prof
+        vis_mean = stats["visible"] / n_prof
+    else:
+        R_mean = vis_mean = 0.0
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    ms_per_step = elapsed / K * 1e3
+    value = P * world * K / elapsed / 1e6
+    out = {
+        "metric": "Msplats rasterized/s (fwd+bwd)", "value": round(value, 3), "unit": "Msplats/s",
+        "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config}: synthetic curve-Gaussians, {B} curves x {m} = {P} splats, "
+                               f"{W}x{H}, Fibonacci-sphere views, raster fwd+bwd per view",
+                   "splats": P, "curves": B, "width": W, "height": H, "tiles": tiles,
+                   "instances_per_view_R": round(R_mean, 1), "visible_per_view": round(vis_mean, 1),
+                   "views_per_rank": K, "parallelism": f"view-parallel x{world}"},
+    }
+    if kernel_ms:
+        alg_view = algorithmic_bytes(P, R_mean, H, W)
+        dom = max(kernel_ms, key=kernel_ms.get)
+        alg_dom = KERNEL_ALG_BYTES.get(dom, lambda *a: 0)(P, R_mean, H * W, tiles)
+        ach = alg_dom / (kernel_ms[dom] * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                           "kernel_ms": round(kernel_ms[dom], 5), "algorithmic_bytes_per_launch": int(alg_dom)}
+        out["kernel_ms_per_view"] = {k: round(v, 5) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])}
+        out["whole_path"] = {"algorithmic_bytes_per_view": int(alg_view),
+                             "achieved_GBps": round(alg_view / (ms_per_step * 1e-3) / 1e9, 2),
+                             "hbm_roofline_frac": round(alg_view / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                             "sum_kernel_ms": round(sum(kernel_ms.values()), 5)}
+
+    # ---------------------------------------------------------------- CPU baseline (oracle port, bounded sample)
+    if world == 1 and not args.no_cpu_baseline:
+        import numpy as np
+        import oracle
+        oracle.build()
+        from oracle import raster as ORA
+        cores = os.cpu_count() or 1
+        threads = min(cores, 64)
+        ORA.set_num_threads(threads)
+        n = lambda t: t.detach().cpu().numpy()
+        a_xyz, a_col, a_op, a_sc, a_rot = n(xyz), n(colors), n(opac), n(scl), n(rotn)
+        dcol = n(dL_dcolor)
+        nv = max(1, args.cpu_views)
+        tc0 = time.perf_counter()
+        for i in range(nv):
+            cam = my_cams[Wm + i]
+            fw = ORA.forward(n(bg), a_xyz, a_col, a_op, a_sc, a_rot, 1.0, None, n(amaps[id(cam)]),
+                             n(cam.world_view_transform), n(cam.full_proj_transform), tanx, tany, H, W, None, 0,
+                             n(cam.camera_center))
+            ORA.backward(fw, dcol, None, None)
+            fw.free()
+        tc = time.perf_counter() - tc0
+        out["cpu_baseline"] = {"value": round(P * nv / tc / 1e6, 4), "unit": "Msplats/s", "cores": threads,
+                               "kind": "port",
+                               "sample": f"{nv} views of the same workload, fwd+bwd, oracle/raster_ref.c with OpenMP "
+                                         f"({threads} threads of {cores} host cores), {tc:.1f} s"}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

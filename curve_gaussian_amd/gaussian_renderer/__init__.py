@@ -1,0 +1,61 @@
+"""Drop-in for the reference's ``gaussian_renderer.render`` (/root/reference/gaussian_renderer/__init__.py:18-157)."""
+import math
+
+import torch
+
+from ..diff_cur_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+
+
+class PipelineParams:
+    """Defaults of arguments/__init__.py:68-75."""
+    convert_SHs_python = False
+    compute_cov3D_python = False
+    debug = False
+    antialiasing = False
+    render_geo = True
+
+
+def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_sh=False, override_color=None,
+           use_trained_exp=False, use_mask=False, mask_thr=0.01):
+    """Render the scene.  Background tensor (bg_color) must be on the GPU.  Returns the reference's dict
+    {render, viewspace_points, visibility_filter, radii, depth, rend_dir, rend_alpha} (:147-155)."""
+    dev = pc.get_xyz.device
+    screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True, device=dev) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
+    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,
+        viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
+        sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug,
+        antialiasing=pipe.antialiasing, render_geo=pipe.render_geo)
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+    means3D = pc.get_xyz
+    means2D = screenspace_points
+    opacity = pc.get_opacity
+    scales = pc.get_scaling
+    rotations = pc.get_rotation
+    if use_mask:  # straight-through binarisation, :72-76
+        sig = torch.sigmoid(pc._mask)
+        mask = ((sig > mask_thr).float() - sig).detach() + sig
+        scales = pc.get_scaling * mask.view(-1, 1)
+        opacity = pc.get_opacity * mask.view(-1, 1)
+    # :96-104 -- SH path is dead: single-channel unit colour + direction map
+    colors_precomp = torch.ones(means3D.shape[0], 1, device=dev)
+    global_normal = pc.get_main_axis(viewpoint_camera)
+    local_normal = global_normal @ viewpoint_camera.world_view_transform[:3, :3]
+    input_all_map = torch.cat([local_normal, torch.ones_like(local_normal[:, :1])], dim=1)
+    rendered_image, radii, depth_image, out_all_map = rasterizer(
+        means3D=means3D, means2D=means2D, shs=None, colors_precomp=colors_precomp, opacities=opacity, scales=scales,
+        rotations=rotations, all_map=input_all_map, cov3D_precomp=None)
+    rendered_image = rendered_image.clamp(0, 1)
+    rendered_alpha = out_all_map[3:4, ]
+    rendered_dir = out_all_map[0:3]
+    rendered_dir = (rendered_dir.permute(1, 2, 0) @ (viewpoint_camera.world_view_transform[:3, :3].T)).permute(2, 0, 1)
+    return {"render": rendered_image, "viewspace_points": screenspace_points,
+            "visibility_filter": (radii > 0).nonzero(), "radii": radii, "depth": depth_image,
+            "rend_dir": rendered_dir, "rend_alpha": rendered_alpha}

@@ -1,0 +1,134 @@
+"""Hot-path part of the reference's ``scene.gaussian_curve_model.GaussianCurveModel``
+(/root/reference/scene/gaussian_curve_model.py:54-198): the learnable curve tensors, their layout, and the
+per-step derivation of per-splat tensors (``prepare_scaling_rot``).  Topology edits (densify / split / merge,
+:246-727) are out of scope.
+
+Tensor layout (kept exactly): ``_curve_points [B,4,3]``, ``_width [B,1]`` (log), ``_opacity [B,1]`` (logit),
+``_mask [B,m,1]``, ``_features_dc [B,m,1,1]``, ``_features_rest [B,m,(D+1)^2-1,1]``, ``is_bezier [B]``; derived
+(non-leaf, carry autograd): ``_xyz [P,3]``, ``_rotation [P,4]`` (w,x,y,z un-normalised), ``_scaling [P,3]`` with
+splat index = b*m + i.
+"""
+import torch
+from torch import nn
+
+from ..ops import curve_sampling
+
+
+class GaussianCurveModel:
+    def __init__(self, sh_degree: int = 0, n_gaussians: int = 12, optimizer_type: str = "default", device="cuda"):
+        self.active_sh_degree = 0
+        self.max_sh_degree = sh_degree
+        self.optimizer_type = optimizer_type
+        self.n_gaussians = n_gaussians
+        self.device = torch.device(device)
+        self._curve_points = torch.empty(0)
+        self._width = torch.empty(0)
+        self._opacity = torch.empty(0)
+        self._mask = torch.empty(0)
+        self._features_dc = torch.empty(0)
+        self._features_rest = torch.empty(0)
+        self.is_bezier = torch.empty(0)
+        self._xyz = torch.empty(0)
+        self._rotation = torch.empty(0)
+        self._scaling = torch.empty(0)
+        self.optimizer = None
+        # activations, scene/gaussian_model.py:38-53
+        self.scaling_activation = torch.exp
+        self.scaling_inverse_activation = torch.log
+        self.opacity_activation = torch.sigmoid
+        self.rotation_activation = torch.nn.functional.normalize
+
+    # ------------------------------------------------------------------ construction
+    def create_from_curves(self, curve_points, width, opacity, mask=None, is_bezier=None):
+        """Install curve parameters (the reference builds them in create_from_pcd :142-178 from a point cloud)."""
+        dev = self.device
+        B = curve_points.shape[0]
+        m = self.n_gaussians
+        self._curve_points = nn.Parameter(curve_points.to(dev).float().contiguous().requires_grad_(True))
+        self._width = nn.Parameter(width.to(dev).float().contiguous().requires_grad_(True))
+        self._opacity = nn.Parameter(opacity.to(dev).float().contiguous().requires_grad_(True))
+        if mask is None:
+            mask = torch.ones(B, m, 1)
+        self._mask = nn.Parameter(mask.to(dev).float().contiguous().requires_grad_(True))
+        self._features_dc = nn.Parameter(torch.zeros(B, m, 1, 1, device=dev).requires_grad_(True))
+        self._features_rest = nn.Parameter(
+            torch.zeros(B, m, (self.max_sh_degree + 1) ** 2 - 1, 1, device=dev).requires_grad_(True))
+        if is_bezier is None:
+            is_bezier = torch.ones(B, dtype=torch.bool)
+        self.is_bezier = is_bezier.to(dev)
+        self.max_radii2D = torch.zeros(B * m, device=dev)
+        self.prepare_scaling_rot()
+        return self
+
+    def training_setup(self, feature_lr=0.0025, opacity_lr=0.025, scaling_lr=0.005, lr_curve_points_init=0.0005,
+                       mask_lr=0.01):
+        """Adam groups of the reference (:200-213; lrs from arguments/__init__.py:83-89)."""
+        l = [
+            {'params': [self._features_dc], 'lr': feature_lr, "name": "f_dc"},
+            {'params': [self._features_rest], 'lr': feature_lr / 20.0, "name": "f_rest"},
+            {'params': [self._opacity], 'lr': opacity_lr, "name": "opacity"},
+            {'params': [self._width], 'lr': scaling_lr, "name": "width"},
+            {'params': [self._curve_points], 'lr': lr_curve_points_init, "name": "curve_points"},
+            {'params': [self._mask], 'lr': mask_lr, "name": "mask"},
+        ]
+        self.optimizer = torch.optim.Adam(l, lr=0.0, eps=1e-15)
+        return self.optimizer
+
+    # ------------------------------------------------------------------ per-step derivation
+    def prepare_scaling_rot(self, eps=1e-8):
+        """:180-198 -- fused HIP sampling kernel (forward + hand-written backward)."""
+        self._xyz, self._rotation, self._scaling = curve_sampling.sample_curves(
+            self._curve_points, self._width, self.is_bezier, self.n_gaussians, eps)
+
+    # ------------------------------------------------------------------ accessors (:66-140)
+    @property
+    def get_curve_points(self):
+        return self._curve_points
+
+    @property
+    def get_scaling(self):
+        return self._scaling
+
+    @property
+    def get_rotation(self):
+        return self.rotation_activation(self._rotation)
+
+    @property
+    def get_xyz(self):
+        return self._xyz
+
+    @property
+    def get_opacity(self):
+        return self.opacity_activation(self._opacity.unsqueeze(1).expand(-1, self.n_gaussians, -1).reshape(-1, 1))
+
+    @property
+    def get_curve_opacity(self):
+        return self.opacity_activation(self._opacity)
+
+    @property
+    def get_curve_width(self):
+        return self.scaling_activation(self._width)
+
+    @property
+    def get_features(self):
+        return torch.cat((self._features_dc.flatten(0, 1), self._features_rest.flatten(0, 1)), dim=1)
+
+    @property
+    def get_rotation_matrix(self):
+        return curve_sampling.quaternion_to_matrix(self.get_rotation)
+
+    def get_main_axis(self, view_cam):
+        """:99-105 (the in-place masked negation is written as a where; same values)."""
+        d = self.get_rotation_matrix[..., 0]
+        to_cam = view_cam.camera_center - self._xyz
+        neg = (d * to_cam).sum(-1) < 0.0
+        return torch.where(neg[:, None], -d, d)
+
+    def add_densification_stats(self, viewspace_point_tensor, update_filter):
+        """scene/gaussian_model.py:618-620 -- consumer of means2D.grad[:, :2] (NDC-scaled, quirk 9)."""
+        if not hasattr(self, "xyz_gradient_accum") or self.xyz_gradient_accum.shape[0] != self._xyz.shape[0]:
+            self.xyz_gradient_accum = torch.zeros((self._xyz.shape[0], 1), device=self._xyz.device)
+            self.denom = torch.zeros((self._xyz.shape[0], 1), device=self._xyz.device)
+        self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1,
+                                                             keepdim=True)
+        self.denom[update_filter] += 1
