@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcurvegs.so")
+LIB_PATH = os.environ.get("CGS_LIB", os.path.join(_HERE, "libcurvegs.so"))  # CGS_LIB: A/B experiment builds
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64

@@ -212,7 +212,7 @@ int cgs_rasterize_backward(int P, int D, int M, int64_t R, const float* backgrou
                            const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                            const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                            const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii,
-                           const void* geometry_buffer, const void* binning_buffer, const void* image_buffer,
+                           void* geometry_buffer, const void* binning_buffer, const void* image_buffer,
                            const float* dL_dout_color, const float* dL_dout_invdepth, const float* dL_dout_all_map,
                            float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                            float* dL_dinvdepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
@@ -223,13 +223,17 @@ int cgs_rasterize_backward(int P, int D, int M, int64_t R, const float* backgrou
     hipStream_t s = (hipStream_t)stream_;
     if (P == 0) return CGS_OK;
     if (P < 0 || width <= 0 || height <= 0 || !geometry_buffer || !binning_buffer || !image_buffer || !radii ||
-        !dL_dout_color || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D ||
+        !dL_dout_color || !dL_dmean2D || !dL_dopacity || (shs && !dL_dcolor) || !dL_dmean3D || !dL_dcov3D ||
         !dL_dall_map || (!dL_dout_invdepth != !dL_dinvdepth) || (scales && (!dL_dscale || !dL_drot)) ||
         (shs && !dL_dsh)) {
         set_error("cgs_rasterize_backward: invalid argument");
         return CGS_ERR_INVALID_ARGUMENT;
     }
-    if (!aligned16(rotations) || !aligned16(dL_dconic) || !aligned16(dL_drot)) {
+    if (!dL_dcolor && ((render_geo && dL_dout_all_map) || dL_dout_invdepth)) {
+        set_error("cgs_rasterize_backward: dL_dcolor may only be NULL when no depth / all_map gradients flow in");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    if (!aligned16(rotations) || !aligned16(dL_dconic) || !aligned16(dL_drot) || !aligned16(dL_dall_map)) {
         set_error("cgs_rasterize_backward: rotations/dL_dconic/dL_drot must be 16-byte aligned");
         return CGS_ERR_INVALID_ARGUMENT;
     }
@@ -245,17 +249,21 @@ int cgs_rasterize_backward(int P, int D, int M, int64_t R, const float* backgrou
     BinState bin = bin_from_chunk(bchunk, (size_t)(R > 0 ? R : 1));
     ImageState img = image_from_chunk(ichunk, npix, (size_t)tiles);
 
+    if (hipMemsetAsync(geom.grad_acc, 0, (size_t)P * ACC_STRIDE * sizeof(float), s) != hipSuccess) {
+        set_error("hipMemsetAsync(gradient accumulators) failed");
+        return CGS_ERR_HIP;
+    }
     if (R > 0) {
-        launch_render_bwd(s, render_geo && dL_dout_all_map, dL_dout_invdepth != nullptr, tiles, img.ranges,
-                          bin.point_list, width, height, gx, background, geom.rec, img.final_T, img.n_contrib,
-                          dL_dout_color, dL_dout_invdepth, dL_dout_all_map, dL_dmean2D, dL_dconic, dL_dopacity,
-                          dL_dcolor, dL_dinvdepth, dL_dall_map);
+        const bool geo = render_geo && dL_dout_all_map;
+        launch_render_bwd(s, geo, dL_dout_invdepth != nullptr, dL_dcolor != nullptr, tiles, img.ranges, bin.point_list,
+                          width, height, gx, background, geom.rec, img.final_T, img.n_contrib, dL_dout_color,
+                          dL_dout_invdepth, dL_dout_all_map, geom.grad_acc);
         if (!check_launch("render_bwd", debug, s)) return CGS_ERR_HIP;
     }
     launch_preprocess_bwd(s, P, D, M, means3D, radii, shs, geom.clamped, opacities, scales, rotations, scale_modifier,
-                          cov3D_precomp, viewmatrix, projmatrix, cam_pos, focal_x, focal_y, tan_fovx, tan_fovy,
-                          dL_dmean2D, dL_dconic, dL_dinvdepth, dL_dopacity, dL_dmean3D, dL_dcolor, dL_dcov3D, dL_dsh,
-                          dL_dscale, dL_drot, antialiasing);
+                          cov3D_precomp, viewmatrix, projmatrix, cam_pos, focal_x, focal_y, tan_fovx, tan_fovy, width,
+                          height, geom.rec, geom.grad_acc, dL_dmean2D, dL_dconic, dL_dinvdepth, dL_dopacity, dL_dmean3D,
+                          dL_dcolor, dL_dall_map, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, antialiasing);
     if (!check_launch("preprocess_bwd", debug, s)) return CGS_ERR_HIP;
     return CGS_OK;
 }

@@ -15,13 +15,21 @@ constexpr int NUM_ALL_MAP = 4;      // reference config.h:16
 //   a = {mean2D.x, mean2D.y, conic.x, conic.y}
 //   b = {conic.z, opacity(*AA scale), colour, 1/depth}
 //   c = all_map[0..3]
-//   d = {depth, -, -, -}
+//   d = {depth, radius, 2 ln(255 opacity), -}
 struct __attribute__((aligned(64))) SplatRec {
     float4 a, b, c, d;
 };
 
+// Packed per-splat gradient accumulators filled by the backward compositor (raw sums; the per-splat linear maps to
+// dL/dmean2D, dL/dconic are applied once per splat in k_preprocess_bwd).  One 64-byte line per splat:
+//   [0] Sg = sum G dL/dalpha (= dL/dopacity)   [1] Sx = sum g dx   [2] Sy = sum g dy
+//   [3] Sxx  [4] Sxy  [5] Syy   [6] colour   [7] inv-depth   [8..11] all_map   [12..15] unused
+constexpr int ACC_STRIDE = 16;
+constexpr int ACC_COL = 6, ACC_INVD = 7, ACC_MAP = 8;
+
 struct GeomState {            // carved from the geometry buffer
     SplatRec* rec;            // [P]
+    float* grad_acc;          // [P][ACC_STRIDE]  zeroed and filled by the backward
     float* rgb;               // [P]   SH-evaluated colour (SH path only)
     uint8_t* clamped;         // [P]
 };
@@ -47,6 +55,7 @@ static inline void carve(char*& chunk, T*& ptr, size_t count) {
 static inline GeomState geom_from_chunk(char*& chunk, size_t P) {
     GeomState g;
     carve(chunk, g.rec, P);
+    carve(chunk, g.grad_acc, P * ACC_STRIDE);
     carve(chunk, g.rgb, P);
     carve(chunk, g.clamped, P);
     return g;

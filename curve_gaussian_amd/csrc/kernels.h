@@ -18,10 +18,10 @@ void launch_preprocess_bwd(hipStream_t s, int P, int D, int M, const float* mean
                            const float* shs, const uint8_t* clamped, const float* opacities, const float* scales,
                            const float* rotations, float scale_modifier, const float* cov3D_precomp,
                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, float focal_x,
-                           float focal_y, float tan_fovx, float tan_fovy, const float* dL_dmean2D,
-                           const float* dL_dconic, const float* dL_dinvdepth, float* dL_dopacity, float* dL_dmean3D,
-                           const float* dL_dcolor, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                           int antialiasing);
+                           float focal_y, float tan_fovx, float tan_fovy, int W, int H, const SplatRec* rec,
+                           const float* grad_acc, float* dL_dmean2D, float* dL_dconic, float* dL_dinvdepth,
+                           float* dL_dopacity, float* dL_dmean3D, float* dL_dcolor, float* dL_dall_map,
+                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int antialiasing);
 
 // binning.hip
 void launch_scan_tiles(hipStream_t s, int tiles, const uint32_t* tile_count, uint2* ranges, uint32_t* total);
@@ -33,11 +33,9 @@ void launch_tile_sort(hipStream_t s, int tiles, const uint2* ranges, uint64_t* k
 void launch_render_fwd(hipStream_t s, bool geo, int tiles, const uint2* ranges, const uint32_t* point_list, int W,
                        int H, int grid_x, const SplatRec* rec, float* final_T, uint32_t* n_contrib,
                        const float* bg_color, float* out_color, float* out_invdepth, float* out_all_map);
-void launch_render_bwd(hipStream_t s, bool geo, bool invd, int tiles, const uint2* ranges,
+void launch_render_bwd(hipStream_t s, bool geo, bool invd, bool colg, int tiles, const uint2* ranges,
                        const uint32_t* point_list, int W, int H, int grid_x, const float* bg_color,
                        const SplatRec* rec, const float* final_Ts, const uint32_t* n_contrib, const float* dL_dpixels,
-                       const float* dL_dout_invdepth, const float* dL_dout_all_map, float* dL_dmean2D,
-                       float* dL_dconic2D, float* dL_dopacity, float* dL_dcolors, float* dL_dinvdepths,
-                       float* dL_dall_map);
+                       const float* dL_dout_invdepth, const float* dL_dout_all_map, float* grad_acc);
 
 }  // namespace cgs

@@ -158,7 +158,9 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(
         r.a = make_float4(px, py, conic.x, conic.y);
         r.b = make_float4(conic.z, opacities[idx] * h_convolution_scaling, color, 1.f / p_view.z);
         r.c = all_map ? reinterpret_cast<const float4*>(all_map)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-        r.d = make_float4(p_view.z, my_radius, 0.f, 0.f);
+        const float op_eff = opacities[idx] * h_convolution_scaling;
+        // tau2 = 2 ln(255 * opacity): alpha >= 1/255  <=>  conic quadratic form <= tau2 (used by the quadrant culling)
+        r.d = make_float4(p_view.z, my_radius, 2.f * logf(255.f * op_eff), 0.f);
         rec[idx] = r;
         out_radius = (int)my_radius;
         // per-tile instance counts (replaces the reference's per-splat scan K2 + duplicateWithKeys offsets)
@@ -187,17 +189,38 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(
     const float* __restrict__ scales, const float* __restrict__ rotations, float scale_modifier,
     const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
     const float* __restrict__ projmatrix, const float* __restrict__ cam_pos, float focal_x, float focal_y,
-    float tan_fovx, float tan_fovy, const float* __restrict__ dL_dmean2D, const float* __restrict__ dL_dconic,
-    const float* __restrict__ dL_dinvdepth, float* __restrict__ dL_dopacity, float* __restrict__ dL_dmean3D,
-    const float* __restrict__ dL_dcolor, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
-    float* __restrict__ dL_dscale, float* __restrict__ dL_drot, int antialiasing) {
+    float tan_fovx, float tan_fovy, int W, int H, const SplatRec* __restrict__ rec,
+    const float* __restrict__ grad_acc, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
+    float* __restrict__ dL_dinvdepth, float* __restrict__ dL_dopacity, float* __restrict__ dL_dmean3D,
+    float* __restrict__ dL_dcolor, float* __restrict__ dL_dall_map, float* __restrict__ dL_dcov3D,
+    float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot, int antialiasing) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= P) return;
+    // ---- finish the compositor's per-splat sums: raw moments -> dL/dmean2D (NDC-scaled), dL/dconic, dL/dopacity
+    const float4* accp = reinterpret_cast<const float4*>(grad_acc + (size_t)idx * ACC_STRIDE);
+    const float4 acc0 = accp[0], acc1 = accp[1];  // {Sg,Sx,Sy,Sxx} {Sxy,Syy,col,invd}
+    const bool vis = radii[idx] > 0;
+    float g2x = 0.f, g2y = 0.f, dcx = 0.f, dcy = 0.f, dcz = 0.f;
+    float dopac = acc0.x;
+    if (vis) {
+        const float4 ra = rec[idx].a, rb = rec[idx].b;
+        const float cA = ra.z, cB = ra.w, cC = rb.x, op = rb.y;
+        g2x = -op * (cA * acc0.y + cB * acc0.z) * (float)(0.5 * W);  // backward.cu:542-543, 659-664
+        g2y = -op * (cC * acc0.z + cB * acc0.y) * (float)(0.5 * H);
+        dcx = -0.5f * op * acc0.w;                                   // backward.cu:667-669
+        dcy = -0.5f * op * acc1.x;
+        dcz = -0.5f * op * acc1.y;
+    }
+    dL_dmean2D[3 * idx] = g2x; dL_dmean2D[3 * idx + 1] = g2y; dL_dmean2D[3 * idx + 2] = 0.f;
+    if (dL_dconic) reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(dcx, dcy, 0.f, dcz);
+    if (dL_dcolor) dL_dcolor[idx] = acc1.z;
+    if (dL_dinvdepth) dL_dinvdepth[idx] = acc1.w;
+    if (dL_dall_map) reinterpret_cast<float4*>(dL_dall_map)[idx] = accp[2];
     float3 dmean = make_float3(0.f, 0.f, 0.f);
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float3 dscale = make_float3(0.f, 0.f, 0.f);
     float4 drot = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (radii[idx] > 0) {
+    if (vis) {
         const float3 mean = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
         float cov3D[6];
         float3 sc = make_float3(0.f, 0.f, 0.f);
@@ -210,8 +233,6 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(
             q = reinterpret_cast<const float4*>(rotations)[idx];
             cov3d_from_scale_rot(sc, scale_modifier, q, cov3D);
         }
-        const float4 dcn = reinterpret_cast<const float4*>(dL_dconic)[idx];
-        const float dcx = dcn.x, dcy = dcn.y, dcz = dcn.w;  // float4 .x .y .w (backward.cu:171)
         float3 t, cov;
         float T_[2][3], txtz, tytz;
         cov2d_terms(mean, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, viewmatrix, t, T_, cov, txtz, tytz);
@@ -227,9 +248,9 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(
             c_yy += h_var;
             const float det_cov_plus_h_cov = c_xx * c_yy - c_xy * c_xy;
             const float h_convolution_scaling = sqrtf(fmaxf(0.000025f, det_cov / det_cov_plus_h_cov));
-            const float dL_dopacity_v = dL_dopacity[idx];
+            const float dL_dopacity_v = dopac;
             const float d_h_convolution_scaling = dL_dopacity_v * opacities[idx];
-            dL_dopacity[idx] = dL_dopacity_v * h_convolution_scaling;
+            dopac = dL_dopacity_v * h_convolution_scaling;
             d_inside_root = (det_cov / det_cov_plus_h_cov) <= 0.000025f ? 0.f : d_h_convolution_scaling / (2 * h_convolution_scaling);
         } else {
             c_xx += h_var;
@@ -276,7 +297,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(
         const float dL_dty = y_grad_mul * -focal_y * tz2 * dL_dJ12;
         float dL_dtz = -focal_x * tz2 * dL_dJ00 - focal_y * tz2 * dL_dJ11 + (2 * focal_x * t.x) * tz3 * dL_dJ02 +
                        (2 * focal_y * t.y) * tz3 * dL_dJ12;
-        if (dL_dinvdepth) dL_dtz -= dL_dinvdepth[idx] / (t.z * t.z);  // backward.cu:313-314
+        if (dL_dinvdepth) dL_dtz -= acc1.w / (t.z * t.z);  // backward.cu:313-314
         // K9 assigns (backward.cu:324) ...
         dmean.x = vm[0] * dL_dtx + vm[1] * dL_dty + vm[2] * dL_dtz;
         dmean.y = vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz;
@@ -287,13 +308,12 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(
         const float m_w = 1.0f / (m_hom.w + 0.0000001f);
         const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
         const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
-        const float g2x = dL_dmean2D[3 * idx], g2y = dL_dmean2D[3 * idx + 1];
         dmean.x += (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
         dmean.y += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
         dmean.z += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
         if (shs) {
             const float3 dm = sh_to_color_bwd(idx, D, M, mean, make_float3(cam_pos[0], cam_pos[1], cam_pos[2]), shs,
-                                              clamped, dL_dcolor[idx], dL_dsh);
+                                              clamped, acc1.z, dL_dsh);
             dmean.x += dm.x; dmean.y += dm.y; dmean.z += dm.z;
         }
         if (scales) {
@@ -329,6 +349,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(
             drot.w = 2 * r * (G[0][1] - G[1][0]) + 2 * x * (G[2][0] + G[0][2]) + 2 * y * (G[1][2] + G[2][1]) - 4 * z * (G[1][1] + G[0][0]);
         }
     }
+    dL_dopacity[idx] = dopac;
     dL_dmean3D[3 * idx] = dmean.x; dL_dmean3D[3 * idx + 1] = dmean.y; dL_dmean3D[3 * idx + 2] = dmean.z;
 #pragma unroll
     for (int i = 0; i < 6; i++) dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
@@ -359,15 +380,16 @@ void launch_preprocess_bwd(hipStream_t s, int P, int D, int M, const float* mean
                            const float* shs, const uint8_t* clamped, const float* opacities, const float* scales,
                            const float* rotations, float scale_modifier, const float* cov3D_precomp,
                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, float focal_x,
-                           float focal_y, float tan_fovx, float tan_fovy, const float* dL_dmean2D,
-                           const float* dL_dconic, const float* dL_dinvdepth, float* dL_dopacity, float* dL_dmean3D,
-                           const float* dL_dcolor, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                           int antialiasing) {
+                           float focal_y, float tan_fovx, float tan_fovy, int W, int H, const SplatRec* rec,
+                           const float* grad_acc, float* dL_dmean2D, float* dL_dconic, float* dL_dinvdepth,
+                           float* dL_dopacity, float* dL_dmean3D, float* dL_dcolor, float* dL_dall_map,
+                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int antialiasing) {
     ProfScope p("preprocess_bwd", s);
     hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, radii, shs, clamped,
                        opacities, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, cam_pos,
-                       focal_x, focal_y, tan_fovx, tan_fovy, dL_dmean2D, dL_dconic, dL_dinvdepth, dL_dopacity,
-                       dL_dmean3D, dL_dcolor, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, antialiasing);
+                       focal_x, focal_y, tan_fovx, tan_fovy, W, H, rec, grad_acc, dL_dmean2D, dL_dconic, dL_dinvdepth,
+                       dL_dopacity, dL_dmean3D, dL_dcolor, dL_dall_map, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
+                       antialiasing);
 }
 
 }  // namespace cgs

@@ -82,7 +82,8 @@ class _Ext:
     def rasterize_gaussians_backward(background, all_map_pixels, means3D, radii, colors, all_maps, opacities, scales,
                                      rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx,
                                      tan_fovy, dL_dout_color, dL_dout_invdepth, dL_dout_all_map, sh, degree, campos,
-                                     geomBuffer, R, binningBuffer, imageBuffer, antialiasing, render_geo, debug):
+                                     geomBuffer, R, binningBuffer, imageBuffer, antialiasing, render_geo, debug,
+                                     need_color_grad=True):
         lib = L.load()
         L.require_gpu_tensor(means3D, "means3D")
         dev = means3D.device
@@ -98,9 +99,9 @@ class _Ext:
             M = sh.size(1) if (sh is not None and sh.numel() != 0) else 0
             has_invd = dL_dout_invdepth is not None and dL_dout_invdepth.numel() != 0
             fopt = dict(dtype=torch.float32, device=dev)
-            # accumulated gradients: ONE zero-filled allocation (the reference zero-fills 11 tensors,
-            # rasterize_points.cu:173-183); views of it are returned.
-            acc = torch.zeros((P, 14), **fopt) if P > 0 else torch.zeros((0, 14), **fopt)
+            # The reference zero-fills 11 gradient tensors (rasterize_points.cu:173-183); libcurvegs writes every
+            # output for all P splats, so one uninitialised allocation is carved into views.
+            acc = torch.empty((P, 14), **fopt)
             flat = acc.view(-1)
             o = 0
             def take(n, shape):
@@ -114,7 +115,6 @@ class _Ext:
             dL_dcolors = take(P, (P, NUM_CHANNELS))
             dL_dopacity = take(P, (P, 1))
             dL_dinvdepths = take(P, (P, 1))
-            # written gradients: no zero-fill needed (every splat is written by the fused preprocess backward)
             wr = torch.empty((P, 16), **fopt)
             wflat = wr.view(-1)
             dL_drotations = wflat[0:4 * P].view(P, 4)
@@ -122,9 +122,14 @@ class _Ext:
             dL_dcov3D = wflat[7 * P:13 * P].view(P, 6)
             dL_dscales = wflat[13 * P:16 * P].view(P, 3)
             has_scales = scales is not None and scales.numel() != 0
+            has_amap_g = dL_dout_all_map is not None and dL_dout_all_map.numel() != 0
+            # extension over the reference: skip the colour-gradient accumulation when nobody consumes it
+            want_col = bool(need_color_grad) or M > 0 or has_invd or (bool(render_geo) and has_amap_g)
             if not has_scales:
                 dL_dscales.zero_()
                 dL_drotations.zero_()
+            if not want_col:
+                dL_dcolors.zero_()
             dL_dsh = torch.zeros((P, M, 3), **fopt)  # reference shape; only the first P*M floats are written (quirk 16)
             stream = torch.cuda.current_stream(dev).cuda_stream
             if P != 0:
@@ -134,7 +139,7 @@ class _Ext:
                     L.ptr(cov3D_precomp), L.ptr(viewmatrix), L.ptr(projmatrix), L.ptr(campos), float(tan_fovx),
                     float(tan_fovy), L.ptr(radii), L.ptr(geomBuffer), L.ptr(binningBuffer), L.ptr(imageBuffer),
                     L.ptr(dL_dout_color), L.ptr(dL_dout_invdepth) if has_invd else None, L.ptr(dL_dout_all_map),
-                    L.ptr(dL_dmeans2D), L.ptr(dL_dconic), L.ptr(dL_dopacity), L.ptr(dL_dcolors),
+                    L.ptr(dL_dmeans2D), L.ptr(dL_dconic), L.ptr(dL_dopacity), L.ptr(dL_dcolors) if want_col else None,
                     L.ptr(dL_dinvdepths) if has_invd else None, L.ptr(dL_dmeans3D), L.ptr(dL_dcov3D),
                     L.ptr(dL_dsh) if M > 0 else None, L.ptr(dL_dscales) if has_scales else None,
                     L.ptr(dL_drotations) if has_scales else None, L.ptr(dL_dall_map), int(bool(antialiasing)),
@@ -205,7 +210,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 grad_out_all_map if grad_out_all_map is not None else empty, sh, rs.sh_degree, rs.campos, geomBuffer,
                 ctx.num_rendered, binningBuffer, imgBuffer, rs.antialiasing, rs.render_geo, rs.debug)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
-         grad_rotations, grad_all_map) = _C.rasterize_gaussians_backward(*args)
+         grad_rotations, grad_all_map) = _C.rasterize_gaussians_backward(*args, need_color_grad=ctx.needs_input_grad[3])
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
                 grad_cov3Ds_precomp, grad_all_map, None)
 

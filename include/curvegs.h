@@ -86,13 +86,16 @@ int64_t cgs_rasterize_forward(
     void* stream /* hipStream_t */);
 
 /* cgs_rasterize_backward:
- *   ACCUMULATED outputs (must be zero on entry, as the reference's shim zero-fills them,
- *   rasterize_points.cu:173-193): dL_dmean2D [P,3] (only .x,.y written, NDC-scaled, quirk 9),
- *   dL_dconic [P,4] (.x,.y,.w), dL_dopacity [P], dL_dcolor [P,1], dL_dinvdepth [P] (may be NULL together with
- *   dL_dout_invdepth), dL_dall_map [P,4].
- *   WRITTEN outputs (no pre-zeroing required): dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dscale [P,3], dL_drot [P,4];
- *   dL_dsh [P,M] is written for visible splats when shs != NULL (zero it on entry).
+ *   Every gradient output is fully WRITTEN for all P splats (zeros for culled ones); unlike the reference's shim
+ *   (rasterize_points.cu:173-193) the caller does not have to zero-fill anything, except dL_dsh [P,M], which is
+ *   written for visible splats only when shs != NULL (zero it on entry).  The per-splat accumulation scratch lives
+ *   in the geometry buffer, which is therefore written by the backward.
+ *   dL_dmean2D [P,3] (.z = 0, NDC-scaled, quirk 9), dL_dconic [P,4] (.x,.y,.w; scratch in the reference, may be
+ *   NULL), dL_dopacity [P], dL_dcolor [P,1], dL_dinvdepth [P] (NULL together with dL_dout_invdepth),
+ *   dL_dall_map [P,4], dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dscale [P,3], dL_drot [P,4].
  *   dL_dout_all_map may be NULL (treated as zeros) -- lets the autograd wrapper skip materialising unused grads.
+ *   dL_dcolor may be NULL when the caller does not need the colour gradient (legal only with shs == NULL and no
+ *   depth / all_map gradients flowing in: the training configuration, where colours are a constant ones tensor).
  */
 int cgs_rasterize_backward(
     int P, int D, int M, int64_t R,
@@ -103,7 +106,7 @@ int cgs_rasterize_backward(
     const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
     float tan_fovx, float tan_fovy,
     const int* radii,
-    const void* geometry_buffer, const void* binning_buffer, const void* image_buffer,
+    void* geometry_buffer, const void* binning_buffer, const void* image_buffer,
     const float* dL_dout_color,     /* [1,H,W] */
     const float* dL_dout_invdepth,  /* [1,H,W] or NULL */
     const float* dL_dout_all_map,   /* [4,H,W] or NULL */
