@@ -52,20 +52,20 @@ __global__ void __launch_bounds__(256) k_scatter(int P, const int* __restrict__ 
                                                  const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_cursor,
                                                  uint64_t* __restrict__ keys) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P) return;
-    const int radius = radii[idx];
-    if (radius <= 0) return;
-    const float4 a = rec[idx].a;
-    const float depth = rec[idx].d.x;
-    uint2 rmin, rmax;
-    get_rect(a.x, a.y, radius, grid_x, grid_y, rmin, rmax);
-    const uint64_t key = ((uint64_t)__float_as_uint(depth) << 32) | (uint32_t)idx;
-    for (uint32_t y = rmin.y; y < rmax.y; y++)
-        for (uint32_t x = rmin.x; x < rmax.x; x++) {
-            const uint32_t tile = y * grid_x + x;
-            const uint32_t slot = atomicAdd(&tile_cursor[tile], 1u);
-            keys[ranges[tile].x + slot] = key;
-        }
+    const int radius = idx < P ? radii[idx] : 0;
+    uint2 rmin = make_uint2(0, 0), rmax = make_uint2(0, 0);
+    uint32_t key_lo = 0, key_hi = 0;
+    if (radius > 0) {
+        const float4 a = rec[idx].a;
+        get_rect(a.x, a.y, radius, grid_x, grid_y, rmin, rmax);
+        key_hi = __float_as_uint(rec[idx].d.x);  // depth bits (positive floats order like unsigned ints)
+        key_lo = (uint32_t)idx;
+    }
+    for_each_rect_tile_coop(radius > 0, rmin, rmax, grid_x, [&](int src, uint32_t tile) {
+        const uint64_t key = ((uint64_t)__builtin_amdgcn_readlane(key_hi, src) << 32) | __builtin_amdgcn_readlane(key_lo, src);
+        const uint32_t slot = atomicAdd(&tile_cursor[tile], 1u);
+        keys[ranges[tile].x + slot] = key;
+    });
 }
 
 // Ascending bitonic network in its "flip + disperse" form: every compare-exchange puts the smaller key at the

@@ -166,6 +166,29 @@ __device__ __forceinline__ float wave_sum(float v) {
     const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
     return (r0 + r1) + (r2 + r3);
 }
+// Cooperative rect walk: the 64 lanes of a wave visit the tiles of ONE splat's rect at a time (lane = tile), so the
+// atomics of a rect row hit consecutive addresses and coalesce into one L2 request per row (measured ~7x the rate
+// of one-splat-per-lane loops, whose 64 lanes scatter over 64 unrelated cache lines).  `has` = this lane's splat
+// is visible; rect = its tile rect.  fn(splat_lane, tile_index) is called with a wave-uniform splat_lane.
+template <typename F>
+__device__ __forceinline__ void for_each_rect_tile_coop(bool has, uint2 rmin, uint2 rmax, int grid_x, F fn) {
+    uint64_t todo = __ballot(has);
+    const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const uint32_t x0 = __builtin_amdgcn_readlane(rmin.x, src), y0 = __builtin_amdgcn_readlane(rmin.y, src);
+        const uint32_t w = __builtin_amdgcn_readlane(rmax.x, src) - x0, h = __builtin_amdgcn_readlane(rmax.y, src) - y0;
+        const uint32_t n = w * h;
+        for (uint32_t base = 0; base < n; base += 64) {
+            const uint32_t t = base + (uint32_t)lane;
+            if (t < n) {
+                const uint32_t ty = t / w, tx = t - ty * w;
+                fn(src, (y0 + ty) * (uint32_t)grid_x + x0 + tx);
+            }
+        }
+    }
+}
 __device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 #endif  // __HIPCC__
 

@@ -106,10 +106,10 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(
     int* __restrict__ radii, SplatRec* __restrict__ rec, float* __restrict__ rgb, int grid_x, int grid_y,
     uint32_t* __restrict__ tile_count, int antialiasing) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P) return;
     // radius 0 == "not processed further" (forward.cu:187-190)
     int out_radius = 0;
-    do {
+    uint2 rmin = make_uint2(0, 0), rmax = make_uint2(0, 0);
+    if (idx < P) do {
         const float3 p_orig = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
         const float3 p_view = xform4x3(p_orig, viewmatrix);
         if (p_view.z <= 0.2f) break;  // near cull only, auxiliary.h:166
@@ -144,9 +144,9 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(
         const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
         const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
         const float px = ndc2pix(p_proj.x, W), py = ndc2pix(p_proj.y, H);
-        uint2 rmin, rmax;
-        get_rect(px, py, (int)my_radius, grid_x, grid_y, rmin, rmax);
-        if ((rmax.x - rmin.x) * (rmax.y - rmin.y) == 0) break;
+        uint2 r0, r1;
+        get_rect(px, py, (int)my_radius, grid_x, grid_y, r0, r1);
+        if ((r1.x - r0.x) * (r1.y - r0.y) == 0) break;
         float color;
         if (colors_precomp) {
             color = colors_precomp[idx];
@@ -156,18 +156,20 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(
         }
         SplatRec r;
         r.a = make_float4(px, py, conic.x, conic.y);
-        r.b = make_float4(conic.z, opacities[idx] * h_convolution_scaling, color, 1.f / p_view.z);
-        r.c = all_map ? reinterpret_cast<const float4*>(all_map)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
         const float op_eff = opacities[idx] * h_convolution_scaling;
+        r.b = make_float4(conic.z, op_eff, color, 1.f / p_view.z);
+        r.c = all_map ? reinterpret_cast<const float4*>(all_map)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
         // tau2 = 2 ln(255 * opacity): alpha >= 1/255  <=>  conic quadratic form <= tau2 (used by the quadrant culling)
         r.d = make_float4(p_view.z, my_radius, 2.f * logf(255.f * op_eff), 0.f);
         rec[idx] = r;
         out_radius = (int)my_radius;
-        // per-tile instance counts (replaces the reference's per-splat scan K2 + duplicateWithKeys offsets)
-        for (uint32_t y = rmin.y; y < rmax.y; y++)
-            for (uint32_t x = rmin.x; x < rmax.x; x++) atomicAdd(&tile_count[y * grid_x + x], 1u);
+        rmin = r0;
+        rmax = r1;
     } while (false);
-    radii[idx] = out_radius;
+    if (idx < P) radii[idx] = out_radius;
+    // per-tile instance counts (replaces the reference's per-splat scan K2 + duplicateWithKeys offsets)
+    for_each_rect_tile_coop(out_radius > 0, rmin, rmax, grid_x,
+                            [&](int, uint32_t tile) { atomicAdd(&tile_count[tile], 1u); });
 }
 
 // reference checkFrustum, rasterizer_impl.cu:54-66
