@@ -30,6 +30,11 @@ SIGNATURES = {
                                     _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "cgs_mark_visible": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
+    "cgs_sample_curves_forward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
+    "cgs_sample_curves_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cgs_splat_attrs_forward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cgs_splat_attrs_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                      _vp, _vp, _vp]),
 }
 
 _lib = None

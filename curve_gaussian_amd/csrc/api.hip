@@ -281,4 +281,82 @@ int cgs_mark_visible(int P, const float* means3D, const float* viewmatrix, const
     return CGS_OK;
 }
 
+
+int cgs_sample_curves_forward(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier,
+                              const float* coef, float eps, double* norms, float* xyz, float* rotation,
+                              float* scaling, void* stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    if (B == 0) return CGS_OK;
+    if (B < 0 || m <= 0 || !curve_points || !width || !coef || !norms || !xyz || !rotation || !scaling ||
+        !aligned16(curve_points) || !aligned16(rotation) || !aligned16(coef)) {
+        set_error("cgs_sample_curves_forward: invalid argument (NULL or misaligned pointer, B=%d m=%d)", B, m);
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    if (hipMemsetAsync(norms, 0, 4 * sizeof(double), s) != hipSuccess) {
+        set_error("hipMemsetAsync(norms) failed");
+        return CGS_ERR_HIP;
+    }
+    launch_sample_forward(s, B, m, curve_points, width, is_bezier, coef, eps, norms, xyz, rotation, scaling);
+    if (!check_launch("sample_curves_forward", false, s)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
+
+int cgs_sample_curves_backward(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier,
+                               const float* coef, float eps, double* norms, const float* dL_dxyz,
+                               const float* dL_drotation, const float* dL_dscaling, float* dL_dcurve_points,
+                               float* dL_dwidth, void* stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    if (B == 0) return CGS_OK;
+    if (B < 0 || m <= 0 || !curve_points || !width || !coef || !norms || !dL_dcurve_points || !dL_dwidth ||
+        !aligned16(curve_points) || !aligned16(dL_drotation) || !aligned16(dL_dcurve_points) || !aligned16(coef)) {
+        set_error("cgs_sample_curves_backward: invalid argument");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    if (hipMemsetAsync(norms + 2, 0, 2 * sizeof(double), s) != hipSuccess) {
+        set_error("hipMemsetAsync(norms) failed");
+        return CGS_ERR_HIP;
+    }
+    launch_sample_backward(s, B, m, curve_points, width, is_bezier, coef, eps, norms, dL_dxyz, dL_drotation, dL_dscaling,
+                           dL_dcurve_points, dL_dwidth);
+    if (!check_launch("sample_curves_backward", false, s)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
+
+int cgs_splat_attrs_forward(int B, int m, const float* rotation_raw, const float* xyz, const float* opacity_logit,
+                            const float* mask_logit, float mask_thr, const float* scaling, const float* campos,
+                            const float* viewmatrix, float* rotation_n, float* opacity, float* scaling_out,
+                            float* all_map, void* stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    if (B == 0) return CGS_OK;
+    if (B < 0 || m <= 0 || !rotation_raw || !xyz || !opacity_logit || !campos || !viewmatrix || !rotation_n || !opacity ||
+        !all_map || (scaling_out && !scaling) || !aligned16(rotation_raw) || !aligned16(rotation_n) || !aligned16(all_map)) {
+        set_error("cgs_splat_attrs_forward: invalid argument");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    launch_attrs_forward(s, B, m, rotation_raw, xyz, opacity_logit, mask_logit, mask_thr, scaling, campos, viewmatrix,
+                         rotation_n, opacity, scaling_out, all_map);
+    if (!check_launch("splat_attrs_forward", false, s)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
+
+int cgs_splat_attrs_backward(int B, int m, const float* rotation_raw, const float* xyz, const float* opacity_logit,
+                             const float* mask_logit, float mask_thr, const float* scaling, const float* campos,
+                             const float* viewmatrix, const float* dL_drotation_n, const float* dL_dopacity,
+                             const float* dL_dscaling_out, const float* dL_dall_map, float* dL_drotation_raw,
+                             float* dL_dopacity_logit, float* dL_dmask_logit, float* dL_dscaling, void* stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    if (B == 0) return CGS_OK;
+    if (B < 0 || m <= 0 || !rotation_raw || !xyz || !opacity_logit || !campos || !viewmatrix || !dL_drotation_raw ||
+        !dL_dopacity_logit || !aligned16(rotation_raw) || !aligned16(dL_drotation_n) || !aligned16(dL_dall_map) ||
+        !aligned16(dL_drotation_raw)) {
+        set_error("cgs_splat_attrs_backward: invalid argument");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    launch_attrs_backward(s, B, m, rotation_raw, xyz, opacity_logit, mask_logit, mask_thr, scaling, campos, viewmatrix,
+                          dL_drotation_n, dL_dopacity, dL_dscaling_out, dL_dall_map, dL_drotation_raw, dL_dopacity_logit,
+                          dL_dmask_logit, dL_dscaling);
+    if (!check_launch("splat_attrs_backward", false, s)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
+
 }  // extern "C"

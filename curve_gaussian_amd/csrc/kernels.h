@@ -38,4 +38,20 @@ void launch_render_bwd(hipStream_t s, bool geo, bool invd, bool colg, int tiles,
                        const SplatRec* rec, const float* final_Ts, const uint32_t* n_contrib, const float* dL_dpixels,
                        const float* dL_dout_invdepth, const float* dL_dout_all_map, float* grad_acc);
 
+
+// sampling.hip
+void launch_sample_forward(hipStream_t s, int B, int m, const float* cp, const float* width, const uint8_t* is_bezier,
+                           const void* coef, float eps, double* norms, float* xyz, float* rot, float* scaling);
+void launch_sample_backward(hipStream_t s, int B, int m, const float* cp, const float* width, const uint8_t* is_bezier,
+                            const void* coef, float eps, double* norms, const float* g_xyz, const float* g_rot,
+                            const float* g_scaling, float* g_cp, float* g_width);
+void launch_attrs_forward(hipStream_t s, int B, int m, const float* rot_raw, const float* xyz, const float* opacity_logit,
+                          const float* mask_logit, float mask_thr, const float* scaling, const float* campos,
+                          const float* vm, float* rot_n, float* opac, float* scl_out, float* all_map);
+void launch_attrs_backward(hipStream_t s, int B, int m, const float* rot_raw, const float* xyz,
+                           const float* opacity_logit, const float* mask_logit, float mask_thr, const float* scaling,
+                           const float* campos, const float* vm, const float* g_rot_n, const float* g_opac,
+                           const float* g_scl_out, const float* g_all_map, float* g_rot_raw, float* g_opacity_logit,
+                           float* g_mask_logit, float* g_scaling);
+
 }  // namespace cgs

@@ -4,6 +4,7 @@ import math
 import torch
 
 from ..diff_cur_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+from ..ops.curve_sampling import splat_attributes
 
 
 class PipelineParams:
@@ -36,19 +37,13 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
     means3D = pc.get_xyz
     means2D = screenspace_points
-    opacity = pc.get_opacity
-    scales = pc.get_scaling
-    rotations = pc.get_rotation
-    if use_mask:  # straight-through binarisation, :72-76
-        sig = torch.sigmoid(pc._mask)
-        mask = ((sig > mask_thr).float() - sig).detach() + sig
-        scales = pc.get_scaling * mask.view(-1, 1)
-        opacity = pc.get_opacity * mask.view(-1, 1)
-    # :96-104 -- SH path is dead: single-channel unit colour + direction map
+    # :57-76, :96-104 fused into one HIP kernel each way (rotation normalisation, opacity sigmoid + expansion,
+    # straight-through mask on scales/opacity, camera-facing main axis -> view-space direction map):
+    rotations, opacity, scales, input_all_map = splat_attributes(
+        pc._rotation, pc._xyz, pc._opacity, pc.get_scaling, viewpoint_camera.camera_center,
+        viewpoint_camera.world_view_transform, pc.n_gaussians, pc._mask if use_mask else None, mask_thr)
+    # SH path is dead in the reference (:96-97): single-channel unit colour
     colors_precomp = torch.ones(means3D.shape[0], 1, device=dev)
-    global_normal = pc.get_main_axis(viewpoint_camera)
-    local_normal = global_normal @ viewpoint_camera.world_view_transform[:3, :3]
-    input_all_map = torch.cat([local_normal, torch.ones_like(local_normal[:, :1])], dim=1)
     rendered_image, radii, depth_image, out_all_map = rasterizer(
         means3D=means3D, means2D=means2D, shs=None, colors_precomp=colors_precomp, opacities=opacity, scales=scales,
         rotations=rotations, all_map=input_all_map, cov3D_precomp=None)

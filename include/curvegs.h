@@ -125,6 +125,43 @@ size_t cgs_image_bytes(int width, int height);
 size_t cgs_binning_bytes(int64_t R);
 
 /* ------------------------------------------------------------------------------------------------
+ * Curve -> Gaussian sampling.  Replaces GaussianCurveModel.prepare_scaling_rot
+ * (/root/reference/scene/gaussian_curve_model.py:180-198 with get_curve_gaussians :70-78, get_curve_tangent :80-89 and
+ * rot_to_quat_batch, utils/general_utils.py:33-86) and its autograd backward.
+ *   curve_points [B,4,3], width [B,1] (log), is_bezier [B] u8 or NULL (= all Bezier).  P = B*m, splat = b*m + i.
+ *   coef [m,16] f32: per-sample weights computed by the host with the reference's float32 expressions
+ *     {c0..c3 at t_i, c0..c3 at t_i-0.5/m, 3(1-t)^2, 6(1-t)t, 3t^2, (1-t), t, (1-t'), t', pad}.
+ *   norms [4] f64 scratch: [0],[1] = global sums of |v1|^2,|v2|^2 written by the forward and needed by the
+ *     backward; [2],[3] are backward scratch.
+ *   outputs xyz [P,3], rotation [P,4] (w,x,y,z, un-normalised), scaling [P,3].
+ * The backward accepts NULL for any upstream gradient (treated as zero).
+ * ------------------------------------------------------------------------------------------------ */
+int cgs_sample_curves_forward(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier,
+                              const float* coef, float eps, double* norms, float* xyz, float* rotation,
+                              float* scaling, void* stream);
+int cgs_sample_curves_backward(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier,
+                               const float* coef, float eps, double* norms, const float* dL_dxyz,
+                               const float* dL_drotation, const float* dL_dscaling, float* dL_dcurve_points,
+                               float* dL_dwidth, void* stream);
+
+/* Per-view splat attributes fed to the rasterizer (one fused kernel each way instead of ~40 PyTorch kernels):
+ *   rotation_n = F.normalize(rotation_raw)                      gaussian_curve_model.py:121-122
+ *   opacity    = sigmoid(opacity_logit[b]) expanded to splats    :108-110   (* mask when mask_logit != NULL)
+ *   scaling_out = scaling * mask (only when mask_logit != NULL; straight-through mask,
+ *                 gaussian_renderer/__init__.py:72-76); pass scaling_out = NULL otherwise
+ *   all_map    = [ R(rotation_n)[:,0] flipped toward the camera @ view[:3,:3], 1 ]   :99-105, renderer :98-104
+ * opacity_logit [B,1], mask_logit [B,m,1] or NULL, campos [3], viewmatrix [16] (world_view_transform, row-major). */
+int cgs_splat_attrs_forward(int B, int m, const float* rotation_raw, const float* xyz, const float* opacity_logit,
+                            const float* mask_logit, float mask_thr, const float* scaling, const float* campos,
+                            const float* viewmatrix, float* rotation_n, float* opacity, float* scaling_out,
+                            float* all_map, void* stream);
+int cgs_splat_attrs_backward(int B, int m, const float* rotation_raw, const float* xyz, const float* opacity_logit,
+                             const float* mask_logit, float mask_thr, const float* scaling, const float* campos,
+                             const float* viewmatrix, const float* dL_drotation_n, const float* dL_dopacity,
+                             const float* dL_dscaling_out, const float* dL_dall_map, float* dL_drotation_raw,
+                             float* dL_dopacity_logit, float* dL_dmask_logit, float* dL_dscaling, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Per-kernel timing hook used by bench.py: when enabled, every kernel launched by the library is
  * bracketed by hipEvents on the caller's stream; cgs_prof_collect synchronises and accumulates.
  * ------------------------------------------------------------------------------------------------ */
