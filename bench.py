@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--mode", default="view", choices=["view", "raster"],
+                    help="view: full per-view hot path (curve sampling -> splat attrs -> raster fwd+bwd -> curve grads "
+                         "[-> RCCL all-reduce]); raster: rasterizer fwd+bwd only on precomputed splats")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=2)
@@ -112,7 +115,7 @@ def main():
 
     stats = {"R": 0, "visible": 0}
 
-    def step(cam, collect=False):
+    def step_raster(cam, collect=False):
         (R, color, radii, gB, bB, iB, invd, om) = _C.rasterize_gaussians(
             bg, xyz, colors, opac, scl, rotn, 1.0, empty, amaps[id(cam)], cam.world_view_transform,
             cam.full_proj_transform, tanx, tany, H, W, empty, 0, cam.camera_center, False, False, True, False)
@@ -126,6 +129,39 @@ def main():
             stats["R"] += R
             stats["visible"] += int((radii > 0).sum())
         return grads
+
+    # ---- "view" mode: the learnable curve tensors with .grad living inside ONE flat buffer (38 floats / curve:
+    # curve_points 12 | width 1 | opacity 1 | mask 12 | features_dc 12), so the per-step exchange is a single
+    # all-reduce with no packing kernels.
+    from curve_gaussian_amd.diff_cur_rasterization import GaussianRasterizationSettings, rasterize_gaussians
+    p_cp = curves["curve_points"].to(dev).requires_grad_(True)
+    p_w = curves["width"].to(dev).requires_grad_(True)
+    p_op = curves["opacity"].to(dev).requires_grad_(True)
+    p_cp.grad = flat_grads[0:12 * B].view(B, 4, 3)
+    p_w.grad = flat_grads[12 * B:13 * B].view(B, 1)
+    p_op.grad = flat_grads[13 * B:14 * B].view(B, 1)
+    isb = curves["is_bezier"].to(dev)
+    settings = {}
+
+    def step_view(cam, collect=False):
+        flat_grads.zero_()
+        s_xyz, s_rot, s_scl = curve_sampling.sample_curves(p_cp, p_w, isb, m)            # prepare_scaling_rot
+        rot_n, opacity, scales, amap = curve_sampling.splat_attributes(
+            s_rot, s_xyz, p_op, s_scl, cam.camera_center, cam.world_view_transform, m)   # render() glue, fused
+        rs = settings.get(id(cam))
+        if rs is None:
+            rs = settings[id(cam)] = GaussianRasterizationSettings(
+                image_height=H, image_width=W, tanfovx=tanx, tanfovy=tany, bg=bg, scale_modifier=1.0,
+                viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=0,
+                campos=cam.camera_center, prefiltered=False, debug=False, antialiasing=False, render_geo=True)
+        color, radii, invd, om = rasterize_gaussians(s_xyz, None, empty, colors, opacity, scales, rot_n, empty, amap, rs)
+        color.backward(dL_dcolor)   # synthetic upstream gradient; grads accumulate into flat_grads views
+        if world > 1:
+            dist.all_reduce(flat_grads)
+        if collect:
+            stats["visible"] += int((radii > 0).sum())
+
+    step = step_view if args.mode == "view" else step_raster
 
     def barrier():
         if world > 1:
@@ -158,6 +194,13 @@ def main():
         lib.cgs_prof_enable(0)
         for name, (ms, n) in L.prof_collect().items():
             kernel_ms[name] = ms / max(n, 1)
+        if args.mode == "view":  # instance counts come from the raster-only call on the same views
+            for i in range(n_prof):
+                (R_i, *_rest) = _C.rasterize_gaussians(
+                    bg, xyz, colors, opac, scl, rotn, 1.0, empty, amaps[id(my_cams[Wm + i])],
+                    my_cams[Wm + i].world_view_transform, my_cams[Wm + i].full_proj_transform, tanx, tany, H, W, empty,
+                    0, my_cams[Wm + i].camera_center, False, False, True, False)
+                stats["R"] += R_i
         R_mean = stats["R"] / n_prof
         vis_mean = stats["visible"] / n_prof
     else:
@@ -176,7 +219,8 @@ def main():
         "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config}: synthetic curve-Gaussians, {B} curves x {m} = {P} splats, "
-                               f"{W}x{H}, Fibonacci-sphere views, raster fwd+bwd per view",
+                               f"{W}x{H}, " + ("curve sampling + splat attrs + raster fwd+bwd + curve-param grads per view" if args.mode == "view" else "raster fwd+bwd per view"),
+                   "mode": args.mode,
                    "splats": P, "curves": B, "width": W, "height": H, "tiles": tiles,
                    "instances_per_view_R": round(R_mean, 1), "visible_per_view": round(vis_mean, 1),
                    "views_per_rank": K, "parallelism": f"view-parallel x{world}"},

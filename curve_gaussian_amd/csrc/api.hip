@@ -287,7 +287,7 @@ int cgs_sample_curves_forward(int B, int m, const float* curve_points, const flo
                               float* scaling, void* stream_) {
     hipStream_t s = (hipStream_t)stream_;
     if (B == 0) return CGS_OK;
-    if (B < 0 || m <= 0 || !curve_points || !width || !coef || !norms || !xyz || !rotation || !scaling ||
+    if (B < 0 || m <= 0 || m > 256 || !curve_points || !width || !coef || !norms || !xyz || !rotation || !scaling ||
         !aligned16(curve_points) || !aligned16(rotation) || !aligned16(coef)) {
         set_error("cgs_sample_curves_forward: invalid argument (NULL or misaligned pointer, B=%d m=%d)", B, m);
         return CGS_ERR_INVALID_ARGUMENT;

@@ -6,15 +6,19 @@
 //   get_rotation (F.normalize) :121-122, get_opacity :108-110, get_main_axis :99-105,
 //   straight-through mask + all_map build  gaussian_renderer/__init__.py:72-76,98-104
 //
-// One thread per CURVE walks its m samples (splat index = b*m + i).  The reference divides v1 and v2 by the GLOBAL
+// One thread per SPLAT (sample i of curve b, splat index = b*m + i).  The reference divides v1 and v2 by the GLOBAL
 // Frobenius norm of the whole [P,3] tensor, so the forward is three passes
 //   F1: S1 = sum |cross(tan, up)|^2      F2: S2 = sum |cross(tan, v1)|^2      F3: outputs
 // and the backward three more (the norms couple every sample to every other one)
 //   B1: D2 = sum <g_v2, c2v>             B2: D1 = sum <g_v1, c1v>             B3: dL/d{control points, width}
 // Grid-wide sums are block-reduced and accumulated with one f64 atomic per block (order effects ~1e-16).
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace cgs {
+
+constexpr int REDUCE_BLOCKS = 256;  // one workgroup per CU for the grid-wide sums
 
 struct SampleCoef {  // per-sample coefficients, computed on the host with the reference's float32 torch expressions
     float c[4];      // Bezier point weights at t_i
@@ -66,31 +70,27 @@ __device__ __forceinline__ void block_accumulate(double v, double* target) {
 __global__ void __launch_bounds__(256) k_sample_f1(int B, int m, const float* __restrict__ cp,
                                                    const uint8_t* __restrict__ is_bezier,
                                                    const SampleCoef* __restrict__ coef, double* __restrict__ norms) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
     double acc = 0;
-    if (b < B) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < B * m; p += gridDim.x * blockDim.x) {
+        const int b = p / m, i = p - b * m;
         const CurveCP c = load_curve(cp, is_bezier, b);
-        for (int i = 0; i < m; i++) {
-            const V3 t = curve_tangent(c, coef[i]);
-            acc += (double)(t.y * t.y) + (double)(t.x * t.x);  // |cross(tan,(0,0,1))|^2 = ty^2 + tx^2
-        }
+        const V3 t = curve_tangent(c, coef[i]);
+        acc += (double)(t.y * t.y) + (double)(t.x * t.x);  // |cross(tan,(0,0,1))|^2 = ty^2 + tx^2
     }
-    block_accumulate(acc, &norms[0]);
+    block_accumulate(acc, &norms[0]);  // <= REDUCE_BLOCKS same-address f64 atomics
 }
 __global__ void __launch_bounds__(256) k_sample_f2(int B, int m, const float* __restrict__ cp,
                                                    const uint8_t* __restrict__ is_bezier,
                                                    const SampleCoef* __restrict__ coef, double* __restrict__ norms) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
     const float N1 = (float)sqrt(norms[0]);
     double acc = 0;
-    if (b < B) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < B * m; p += gridDim.x * blockDim.x) {
+        const int b = p / m, i = p - b * m;
         const CurveCP c = load_curve(cp, is_bezier, b);
-        for (int i = 0; i < m; i++) {
-            const V3 t = curve_tangent(c, coef[i]);
-            const V3 v1 = {t.y / N1, -t.x / N1, 0.f / N1};
-            const V3 c2 = cross(t, v1);
-            acc += (double)(c2.x * c2.x) + (double)(c2.y * c2.y) + (double)(c2.z * c2.z);
-        }
+        const V3 t = curve_tangent(c, coef[i]);
+        const V3 v1 = {t.y / N1, -t.x / N1, 0.f / N1};
+        const V3 c2 = cross(t, v1);
+        acc += (double)(c2.x * c2.x) + (double)(c2.y * c2.y) + (double)(c2.z * c2.z);
     }
     block_accumulate(acc, &norms[1]);
 }
@@ -193,115 +193,152 @@ __global__ void __launch_bounds__(256) k_sample_f3(int B, int m, const float* __
                                                    const SampleCoef* __restrict__ coef, float eps,
                                                    const double* __restrict__ norms, float* __restrict__ xyz,
                                                    float* __restrict__ rot, float* __restrict__ scaling) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= B * m) return;
+    const int b = p / m, i = p - b * m;
     const float N1 = (float)sqrt(norms[0]), N2 = (float)sqrt(norms[1]);
     const CurveCP c = load_curve(cp, is_bezier, b);
     const float w = expf(width[b]);
-    for (int i = 0; i < m; i++) {
-        const SampleFwd s = sample_forward(c, coef[i], N1, N2, eps);
-        float M[3][3], q[4];
-        rot_matrix(s, M);
-        quat_forward(M, q);
-        const size_t p = (size_t)b * m + i;
-        xyz[3 * p] = s.xyz.x; xyz[3 * p + 1] = s.xyz.y; xyz[3 * p + 2] = s.xyz.z;
-        reinterpret_cast<float4*>(rot)[p] = make_float4(q[0], q[1], q[2], q[3]);
-        scaling[3 * p] = s.dist; scaling[3 * p + 1] = w; scaling[3 * p + 2] = w;
-    }
+    const SampleFwd s = sample_forward(c, coef[i], N1, N2, eps);
+    float M[3][3], q[4];
+    rot_matrix(s, M);
+    quat_forward(M, q);
+    xyz[3 * p] = s.xyz.x; xyz[3 * p + 1] = s.xyz.y; xyz[3 * p + 2] = s.xyz.z;
+    reinterpret_cast<float4*>(rot)[p] = make_float4(q[0], q[1], q[2], q[3]);
+    scaling[3 * p] = s.dist; scaling[3 * p + 1] = w; scaling[3 * p + 2] = w;
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-// PASS 1: D2 (norms[2]);  PASS 2: D1 (norms[3]);  PASS 3: write dL/dcurve_points, dL/dwidth
+// PASS 1: D2 (norms[2]);  PASS 2: D1 (norms[3]);  PASS 3: write dL/dcurve_points, dL/dwidth.
+// Blocks hold CURVES_PER_BLOCK whole curves (CURVES_PER_BLOCK * m threads are active); pass 3 reduces the per-sample
+// contributions to the 13 per-curve outputs through LDS.
+constexpr int SAMPLE_BLOCK = 256;
 template <int PASS>
-__global__ void __launch_bounds__(256) k_sample_bwd(int B, int m, const float* __restrict__ cp,
-                                                    const float* __restrict__ width,
-                                                    const uint8_t* __restrict__ is_bezier,
-                                                    const SampleCoef* __restrict__ coef, float eps,
-                                                    double* __restrict__ norms, const float* __restrict__ g_xyz,
-                                                    const float* __restrict__ g_rot, const float* __restrict__ g_scaling,
-                                                    float* __restrict__ g_cp, float* __restrict__ g_width) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(SAMPLE_BLOCK) k_sample_bwd(int B, int m, int curves_per_block,
+                                                             const float* __restrict__ cp,
+                                                             const float* __restrict__ width,
+                                                             const uint8_t* __restrict__ is_bezier,
+                                                             const SampleCoef* __restrict__ coef, float eps,
+                                                             double* __restrict__ norms,
+                                                             const float* __restrict__ g_xyz,
+                                                             const float* __restrict__ g_rot,
+                                                             const float* __restrict__ g_scaling,
+                                                             float* __restrict__ g_cp, float* __restrict__ g_width) {
+    __shared__ float s_part[PASS == 3 ? 13 : 1][SAMPLE_BLOCK + 1];
     const float N1 = (float)sqrt(norms[0]), N2 = (float)sqrt(norms[1]);
     const float D2 = PASS >= 2 ? (float)norms[2] : 0.f, D1 = PASS >= 3 ? (float)norms[3] : 0.f;
     double acc = 0;
     V3 gp0 = {0, 0, 0}, gp1 = {0, 0, 0}, gp2 = {0, 0, 0}, gp3 = {0, 0, 0};
     float gw = 0.f;
-    if (b < B) {
+    // passes 1,2: grid-stride over splats (few blocks => few same-address f64 atomics); pass 3: whole curves per block
+    int b, i;
+    bool valid;
+    int sp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (PASS == 3) {
+        const int lc = threadIdx.x / m;
+        i = threadIdx.x - lc * m;
+        b = blockIdx.x * curves_per_block + lc;
+        valid = lc < curves_per_block && b < B;
+    } else {
+        valid = sp < B * m;
+        b = valid ? sp / m : 0;
+        i = sp - b * m;
+    }
+    while (valid) {
         const CurveCP c = load_curve(cp, is_bezier, b);
         const float w = expf(width[b]);
-        for (int i = 0; i < m; i++) {
-            const SampleCoef k = coef[i];
-            const size_t p = (size_t)b * m + i;
-            const SampleFwd s = sample_forward(c, k, N1, N2, eps);
-            V3 g_v0 = {0, 0, 0}, g_v1 = {0, 0, 0}, g_v2 = {0, 0, 0};
-            if (g_rot) {
-                float M[3][3], q[4], gM[3][3];
-                rot_matrix(s, M);
-                const QuatFwd f = quat_forward(M, q);
-                const float4 gq = reinterpret_cast<const float4*>(g_rot)[p];
-                const float go[4] = {gq.x, gq.y, gq.z, gq.w};
-                quat_backward(f, go, gM);
-                g_v0 = {gM[0][0], gM[1][0], gM[2][0]};
-                g_v1 = {gM[0][1], gM[1][1], gM[2][1]};
-                g_v2 = {gM[0][2], gM[1][2], gM[2][2]};
-            }
-            if (PASS == 1) {
-                acc += (double)dot(g_v2, s.c2v);
-                continue;
-            }
-            const float iN2 = 1.f / N2;
-            const V3 g_c2v = iN2 * g_v2 - (D2 * iN2 * iN2 * iN2) * s.c2v;
-            // c2v = cross(tan, v1)
-            V3 g_tan = cross(s.v1, g_c2v);
-            const V3 g_v1t = g_v1 + cross(g_c2v, s.tan);
-            if (PASS == 2) {
-                acc += (double)dot(g_v1t, s.c1v);
-                continue;
-            }
-            const float iN1 = 1.f / N1;
-            const V3 g_c1v = iN1 * g_v1t - (D1 * iN1 * iN1 * iN1) * s.c1v;
-            g_tan.y += g_c1v.x;  // c1v = (ty, -tx, 0)
-            g_tan.x -= g_c1v.y;
-            if (s.n > 0.f) {     // v0 = tan / (n + eps)
-                const float ne = s.n + eps;
-                const float coefv = dot(g_v0, s.tan) / (s.n * ne * ne);
-                g_tan = g_tan + (1.f / ne) * g_v0 - coefv * s.tan;
-            } else {
-                g_tan = g_tan + (1.f / eps) * g_v0;
-            }
-            // scaling = (dist, exp(w), exp(w))
-            V3 g_x = {0, 0, 0};
-            if (g_xyz) g_x = {g_xyz[3 * p], g_xyz[3 * p + 1], g_xyz[3 * p + 2]};
-            V3 g_front = {0, 0, 0};
-            if (g_scaling) {
-                const float gd = g_scaling[3 * p];
-                gw += (g_scaling[3 * p + 1] + g_scaling[3 * p + 2]) * w;
-                if (s.dist > 0.f) {
-                    const V3 gdv = (gd / s.dist) * s.dvec;
-                    g_x = g_x + gdv;
-                    g_front = {-gdv.x, -gdv.y, -gdv.z};
-                }
-            }
-            if (c.bez) {
-                gp0 = gp0 + k.c[0] * g_x + k.cf[0] * g_front - k.d[0] * g_tan;
-                gp1 = gp1 + k.c[1] * g_x + k.cf[1] * g_front + (k.d[0] - k.d[1]) * g_tan;
-                gp2 = gp2 + k.c[2] * g_x + k.cf[2] * g_front + (k.d[1] - k.d[2]) * g_tan;
-                gp3 = gp3 + k.c[3] * g_x + k.cf[3] * g_front + k.d[2] * g_tan;
-            } else {
-                gp0 = gp0 + k.l[0] * g_x + k.lf[0] * g_front - g_tan;
-                gp3 = gp3 + k.l[1] * g_x + k.lf[1] * g_front + g_tan;
+        const SampleCoef k = coef[i];
+        const size_t p = (size_t)b * m + i;
+        const SampleFwd s = sample_forward(c, k, N1, N2, eps);
+        V3 g_v0 = {0, 0, 0}, g_v1 = {0, 0, 0}, g_v2 = {0, 0, 0};
+        if (g_rot) {
+            float M[3][3], q[4], gM[3][3];
+            rot_matrix(s, M);
+            const QuatFwd f = quat_forward(M, q);
+            const float4 gq = reinterpret_cast<const float4*>(g_rot)[p];
+            const float go[4] = {gq.x, gq.y, gq.z, gq.w};
+            quat_backward(f, go, gM);
+            g_v0 = {gM[0][0], gM[1][0], gM[2][0]};
+            g_v1 = {gM[0][1], gM[1][1], gM[2][1]};
+            g_v2 = {gM[0][2], gM[1][2], gM[2][2]};
+        }
+        if (PASS == 1) {
+            acc += (double)dot(g_v2, s.c2v);
+            sp += gridDim.x * blockDim.x;
+            valid = sp < B * m;
+            b = valid ? sp / m : 0;
+            i = sp - b * m;
+            continue;
+        }
+        const float iN2 = 1.f / N2;
+        const V3 g_c2v = iN2 * g_v2 - (D2 * iN2 * iN2 * iN2) * s.c2v;
+        // c2v = cross(tan, v1)
+        V3 g_tan = cross(s.v1, g_c2v);
+        const V3 g_v1t = g_v1 + cross(g_c2v, s.tan);
+        if (PASS == 2) {
+            acc += (double)dot(g_v1t, s.c1v);
+            sp += gridDim.x * blockDim.x;
+            valid = sp < B * m;
+            b = valid ? sp / m : 0;
+            i = sp - b * m;
+            continue;
+        }
+        const float iN1 = 1.f / N1;
+        const V3 g_c1v = iN1 * g_v1t - (D1 * iN1 * iN1 * iN1) * s.c1v;
+        g_tan.y += g_c1v.x;  // c1v = (ty, -tx, 0)
+        g_tan.x -= g_c1v.y;
+        if (s.n > 0.f) {     // v0 = tan / (n + eps)
+            const float ne = s.n + eps;
+            const float coefv = dot(g_v0, s.tan) / (s.n * ne * ne);
+            g_tan = g_tan + (1.f / ne) * g_v0 - coefv * s.tan;
+        } else {
+            g_tan = g_tan + (1.f / eps) * g_v0;
+        }
+        // scaling = (dist, exp(w), exp(w))
+        V3 g_x = {0, 0, 0};
+        if (g_xyz) g_x = {g_xyz[3 * p], g_xyz[3 * p + 1], g_xyz[3 * p + 2]};
+        V3 g_front = {0, 0, 0};
+        if (g_scaling) {
+            const float gd = g_scaling[3 * p];
+            gw = (g_scaling[3 * p + 1] + g_scaling[3 * p + 2]) * w;
+            if (s.dist > 0.f) {
+                const V3 gdv = (gd / s.dist) * s.dvec;
+                g_x = g_x + gdv;
+                g_front = {-gdv.x, -gdv.y, -gdv.z};
             }
         }
-        if (PASS == 3) {
-            float4* o = reinterpret_cast<float4*>(g_cp + (size_t)b * 12);
-            o[0] = make_float4(gp0.x, gp0.y, gp0.z, gp1.x);
-            o[1] = make_float4(gp1.y, gp1.z, gp2.x, gp2.y);
-            o[2] = make_float4(gp2.z, gp3.x, gp3.y, gp3.z);
-            g_width[b] = gw;
+        if (c.bez) {
+            gp0 = k.c[0] * g_x + k.cf[0] * g_front - k.d[0] * g_tan;
+            gp1 = k.c[1] * g_x + k.cf[1] * g_front + (k.d[0] - k.d[1]) * g_tan;
+            gp2 = k.c[2] * g_x + k.cf[2] * g_front + (k.d[1] - k.d[2]) * g_tan;
+            gp3 = k.c[3] * g_x + k.cf[3] * g_front + k.d[2] * g_tan;
+        } else {
+            gp0 = k.l[0] * g_x + k.lf[0] * g_front - g_tan;
+            gp3 = k.l[1] * g_x + k.lf[1] * g_front + g_tan;
         }
+        break;
     }
     if (PASS == 1) block_accumulate(acc, &norms[2]);
     if (PASS == 2) block_accumulate(acc, &norms[3]);
+    if (PASS == 3) {
+        const int t = threadIdx.x;
+        s_part[0][t] = gp0.x; s_part[1][t] = gp0.y; s_part[2][t] = gp0.z;
+        s_part[3][t] = gp1.x; s_part[4][t] = gp1.y; s_part[5][t] = gp1.z;
+        s_part[6][t] = gp2.x; s_part[7][t] = gp2.y; s_part[8][t] = gp2.z;
+        s_part[9][t] = gp3.x; s_part[10][t] = gp3.y; s_part[11][t] = gp3.z;
+        s_part[12][t] = gw;
+        __syncthreads();
+        // 13 outputs per curve, summed over its m samples in sample order (deterministic)
+        for (int o = threadIdx.x; o < curves_per_block * 13; o += blockDim.x) {
+            const int c2 = o / 13, f = o - c2 * 13;
+            const int bb = blockIdx.x * curves_per_block + c2;
+            if (bb >= B) continue;
+            float sum = 0.f;
+            for (int q = 0; q < m; q++) sum += s_part[f][c2 * m + q];
+            if (f < 12) g_cp[(size_t)bb * 12 + f] = sum;
+            else g_width[bb] = sum;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ splat attributes
@@ -320,53 +357,51 @@ __global__ void __launch_bounds__(256) k_attrs_fwd(int B, int m, const float* __
                                                    const float* __restrict__ campos, const float* __restrict__ vm,
                                                    float* __restrict__ rot_n, float* __restrict__ opac,
                                                    float* __restrict__ scl_out, float* __restrict__ all_map) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= B * m) return;
+    const int b = p / m;
     const float op = sigmoidf_(opacity_logit[b]);
     const V3 cam = {campos[0], campos[1], campos[2]};
-    for (int i = 0; i < m; i++) {
-        const size_t p = (size_t)b * m + i;
-        const float4 q = reinterpret_cast<const float4*>(rot_raw)[p];
-        const float nrm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-        const float den = fmaxf(nrm, 1e-12f);
-        const float r = q.x / den, qi = q.y / den, qj = q.z / den, qk = q.w / den;
-        reinterpret_cast<float4*>(rot_n)[p] = make_float4(r, qi, qj, qk);
-        float mk = 1.f;
-        if (mask_logit) mk = sigmoidf_(mask_logit[p]) > mask_thr ? 1.f : 0.f;
-        opac[p] = op * mk;
-        if (scl_out) {
-            scl_out[3 * p] = scaling[3 * p] * mk; scl_out[3 * p + 1] = scaling[3 * p + 1] * mk;
-            scl_out[3 * p + 2] = scaling[3 * p + 2] * mk;
-        }
-        // pytorch3d quaternion_to_matrix, column 0
-        const float two_s = 2.0f / (r * r + qi * qi + qj * qj + qk * qk);
-        V3 d = {1.f - two_s * (qj * qj + qk * qk), two_s * (qi * qj + qk * r), two_s * (qi * qk - qj * r)};
-        const V3 x = {xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2]};
-        if (dot(d, cam - x) < 0.0f) d = {-d.x, -d.y, -d.z};
-        reinterpret_cast<float4*>(all_map)[p] = make_float4(d.x * vm[0] + d.y * vm[4] + d.z * vm[8],
-                                                            d.x * vm[1] + d.y * vm[5] + d.z * vm[9],
-                                                            d.x * vm[2] + d.y * vm[6] + d.z * vm[10], 1.0f);
+    const float4 q = reinterpret_cast<const float4*>(rot_raw)[p];
+    const float nrm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    const float den = fmaxf(nrm, 1e-12f);
+    const float r = q.x / den, qi = q.y / den, qj = q.z / den, qk = q.w / den;
+    reinterpret_cast<float4*>(rot_n)[p] = make_float4(r, qi, qj, qk);
+    float mk = 1.f;
+    if (mask_logit) mk = sigmoidf_(mask_logit[p]) > mask_thr ? 1.f : 0.f;
+    opac[p] = op * mk;
+    if (scl_out) {
+        scl_out[3 * p] = scaling[3 * p] * mk; scl_out[3 * p + 1] = scaling[3 * p + 1] * mk;
+        scl_out[3 * p + 2] = scaling[3 * p + 2] * mk;
     }
+    // pytorch3d quaternion_to_matrix, column 0
+    const float two_s = 2.0f / (r * r + qi * qi + qj * qj + qk * qk);
+    V3 d = {1.f - two_s * (qj * qj + qk * qk), two_s * (qi * qj + qk * r), two_s * (qi * qk - qj * r)};
+    const V3 x = {xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2]};
+    if (dot(d, cam - x) < 0.0f) d = {-d.x, -d.y, -d.z};
+    reinterpret_cast<float4*>(all_map)[p] = make_float4(d.x * vm[0] + d.y * vm[4] + d.z * vm[8],
+                                                        d.x * vm[1] + d.y * vm[5] + d.z * vm[9],
+                                                        d.x * vm[2] + d.y * vm[6] + d.z * vm[10], 1.0f);
 }
 
-__global__ void __launch_bounds__(256) k_attrs_bwd(int B, int m, const float* __restrict__ rot_raw,
-                                                   const float* __restrict__ xyz,
-                                                   const float* __restrict__ opacity_logit,
-                                                   const float* __restrict__ mask_logit, float mask_thr,
-                                                   const float* __restrict__ scaling,
-                                                   const float* __restrict__ campos, const float* __restrict__ vm,
-                                                   const float* __restrict__ g_rot_n, const float* __restrict__ g_opac,
-                                                   const float* __restrict__ g_scl_out,
-                                                   const float* __restrict__ g_all_map, float* __restrict__ g_rot_raw,
-                                                   float* __restrict__ g_opacity_logit, float* __restrict__ g_mask_logit,
-                                                   float* __restrict__ g_scaling) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const float op = sigmoidf_(opacity_logit[b]);
-    const V3 cam = {campos[0], campos[1], campos[2]};
-    float g_op_sum = 0.f;
-    for (int i = 0; i < m; i++) {
+// Blocks hold whole curves (curves_per_block * m active threads); the per-curve opacity-logit gradient is the
+// sample-ordered sum of its m per-splat terms (LDS).
+__global__ void __launch_bounds__(SAMPLE_BLOCK) k_attrs_bwd(
+    int B, int m, int curves_per_block, const float* __restrict__ rot_raw, const float* __restrict__ xyz,
+    const float* __restrict__ opacity_logit, const float* __restrict__ mask_logit, float mask_thr,
+    const float* __restrict__ scaling, const float* __restrict__ campos, const float* __restrict__ vm,
+    const float* __restrict__ g_rot_n, const float* __restrict__ g_opac, const float* __restrict__ g_scl_out,
+    const float* __restrict__ g_all_map, float* __restrict__ g_rot_raw, float* __restrict__ g_opacity_logit,
+    float* __restrict__ g_mask_logit, float* __restrict__ g_scaling) {
+    __shared__ float s_go[SAMPLE_BLOCK];
+    const int lc = threadIdx.x / m, i = threadIdx.x - lc * m;
+    const int b = blockIdx.x * curves_per_block + lc;
+    const bool valid = lc < curves_per_block && b < B;
+    float g_op_term = 0.f;
+    if (valid) {
         const size_t p = (size_t)b * m + i;
+        const float op = sigmoidf_(opacity_logit[b]);
+        const V3 cam = {campos[0], campos[1], campos[2]};
         const float4 q = reinterpret_cast<const float4*>(rot_raw)[p];
         const float nrm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
         const float den = fmaxf(nrm, 1e-12f);
@@ -410,7 +445,7 @@ __global__ void __launch_bounds__(256) k_attrs_bwd(int B, int m, const float* __
             mk = sg > mask_thr ? 1.f : 0.f;
         }
         const float go = g_opac ? g_opac[p] : 0.f;
-        g_op_sum += go * mk;
+        g_op_term = go * mk * op * (1.f - op);
         float g_mask = go * op;
         if (g_scl_out) {
             const float g0 = g_scl_out[3 * p], g1 = g_scl_out[3 * p + 1], g2 = g_scl_out[3 * p + 2];
@@ -419,32 +454,41 @@ __global__ void __launch_bounds__(256) k_attrs_bwd(int B, int m, const float* __
         }
         if (g_mask_logit) g_mask_logit[p] = mask_logit ? g_mask * sg * (1.f - sg) : 0.f;  // straight-through estimator
     }
-    g_opacity_logit[b] = g_op_sum * op * (1.f - op);
+    s_go[threadIdx.x] = g_op_term;
+    __syncthreads();
+    if (valid && i == 0) {
+        float sum = 0.f;
+        for (int q = 0; q < m; q++) sum += s_go[threadIdx.x + q];
+        g_opacity_logit[b] = sum;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
 void launch_sample_forward(hipStream_t s, int B, int m, const float* cp, const float* width, const uint8_t* is_bezier,
                            const void* coef, float eps, double* norms, float* xyz, float* rot, float* scaling) {
-    const dim3 grid((B + 255) / 256), block(256);
+    const dim3 grid((B * m + 255) / 256), block(256);
+    const dim3 rgrid(std::min((B * m + 255) / 256, REDUCE_BLOCKS));
     const SampleCoef* k = reinterpret_cast<const SampleCoef*>(coef);
-    { ProfScope p("sample_f1", s); hipLaunchKernelGGL(k_sample_f1, grid, block, 0, s, B, m, cp, is_bezier, k, norms); }
-    { ProfScope p("sample_f2", s); hipLaunchKernelGGL(k_sample_f2, grid, block, 0, s, B, m, cp, is_bezier, k, norms); }
+    { ProfScope p("sample_f1", s); hipLaunchKernelGGL(k_sample_f1, rgrid, block, 0, s, B, m, cp, is_bezier, k, norms); }
+    { ProfScope p("sample_f2", s); hipLaunchKernelGGL(k_sample_f2, rgrid, block, 0, s, B, m, cp, is_bezier, k, norms); }
     { ProfScope p("sample_f3", s); hipLaunchKernelGGL(k_sample_f3, grid, block, 0, s, B, m, cp, width, is_bezier, k, eps, norms, xyz, rot, scaling); }
 }
 void launch_sample_backward(hipStream_t s, int B, int m, const float* cp, const float* width, const uint8_t* is_bezier,
                             const void* coef, float eps, double* norms, const float* g_xyz, const float* g_rot,
                             const float* g_scaling, float* g_cp, float* g_width) {
-    const dim3 grid((B + 255) / 256), block(256);
+    const int cpb = SAMPLE_BLOCK / m;  // whole curves per block
+    const dim3 grid((B + cpb - 1) / cpb), block(SAMPLE_BLOCK);
     const SampleCoef* k = reinterpret_cast<const SampleCoef*>(coef);
-    { ProfScope p("sample_b1", s); hipLaunchKernelGGL(k_sample_bwd<1>, grid, block, 0, s, B, m, cp, width, is_bezier, k, eps, norms, g_xyz, g_rot, g_scaling, g_cp, g_width); }
-    { ProfScope p("sample_b2", s); hipLaunchKernelGGL(k_sample_bwd<2>, grid, block, 0, s, B, m, cp, width, is_bezier, k, eps, norms, g_xyz, g_rot, g_scaling, g_cp, g_width); }
-    { ProfScope p("sample_b3", s); hipLaunchKernelGGL(k_sample_bwd<3>, grid, block, 0, s, B, m, cp, width, is_bezier, k, eps, norms, g_xyz, g_rot, g_scaling, g_cp, g_width); }
+    const dim3 rgrid(std::min((B * m + SAMPLE_BLOCK - 1) / SAMPLE_BLOCK, REDUCE_BLOCKS));
+    { ProfScope p("sample_b1", s); hipLaunchKernelGGL(k_sample_bwd<1>, rgrid, block, 0, s, B, m, cpb, cp, width, is_bezier, k, eps, norms, g_xyz, g_rot, g_scaling, g_cp, g_width); }
+    { ProfScope p("sample_b2", s); hipLaunchKernelGGL(k_sample_bwd<2>, rgrid, block, 0, s, B, m, cpb, cp, width, is_bezier, k, eps, norms, g_xyz, g_rot, g_scaling, g_cp, g_width); }
+    { ProfScope p("sample_b3", s); hipLaunchKernelGGL(k_sample_bwd<3>, grid, block, 0, s, B, m, cpb, cp, width, is_bezier, k, eps, norms, g_xyz, g_rot, g_scaling, g_cp, g_width); }
 }
 void launch_attrs_forward(hipStream_t s, int B, int m, const float* rot_raw, const float* xyz, const float* opacity_logit,
                           const float* mask_logit, float mask_thr, const float* scaling, const float* campos,
                           const float* vm, float* rot_n, float* opac, float* scl_out, float* all_map) {
     ProfScope p("attrs_fwd", s);
-    hipLaunchKernelGGL(k_attrs_fwd, dim3((B + 255) / 256), dim3(256), 0, s, B, m, rot_raw, xyz, opacity_logit, mask_logit,
+    hipLaunchKernelGGL(k_attrs_fwd, dim3((B * m + 255) / 256), dim3(256), 0, s, B, m, rot_raw, xyz, opacity_logit, mask_logit,
                        mask_thr, scaling, campos, vm, rot_n, opac, scl_out, all_map);
 }
 void launch_attrs_backward(hipStream_t s, int B, int m, const float* rot_raw, const float* xyz,
@@ -453,7 +497,8 @@ void launch_attrs_backward(hipStream_t s, int B, int m, const float* rot_raw, co
                            const float* g_scl_out, const float* g_all_map, float* g_rot_raw, float* g_opacity_logit,
                            float* g_mask_logit, float* g_scaling) {
     ProfScope p("attrs_bwd", s);
-    hipLaunchKernelGGL(k_attrs_bwd, dim3((B + 255) / 256), dim3(256), 0, s, B, m, rot_raw, xyz, opacity_logit, mask_logit,
+    const int cpb = SAMPLE_BLOCK / m;
+    hipLaunchKernelGGL(k_attrs_bwd, dim3((B + cpb - 1) / cpb), dim3(SAMPLE_BLOCK), 0, s, B, m, cpb, rot_raw, xyz, opacity_logit, mask_logit,
                        mask_thr, scaling, campos, vm, g_rot_n, g_opac, g_scl_out, g_all_map, g_rot_raw, g_opacity_logit,
                        g_mask_logit, g_scaling);
 }

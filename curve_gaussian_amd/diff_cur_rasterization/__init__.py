@@ -211,8 +211,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                 ctx.num_rendered, binningBuffer, imgBuffer, rs.antialiasing, rs.render_geo, rs.debug)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations, grad_all_map) = _C.rasterize_gaussians_backward(*args, need_color_grad=ctx.needs_input_grad[3])
-        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
-                grad_cov3Ds_precomp, grad_all_map, None)
+        grads = (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
+                 grad_cov3Ds_precomp, grad_all_map)
+        # the reference returns all nine unconditionally (:138-149); autograd rejects gradients for non-tensor inputs
+        # (e.g. means2D=None), so inputs that do not require grad get None
+        return tuple(g if need else None for g, need in zip(grads, ctx.needs_input_grad[:9])) + (None,)
 
 
 class GaussianRasterizationSettings(NamedTuple):
