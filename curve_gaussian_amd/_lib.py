@@ -30,6 +30,10 @@ SIGNATURES = {
                                     _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "cgs_mark_visible": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
+    "cgs_ssim_forward": (_i, [_i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cgs_ssim_backward": (_i, [_i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cgs_knn_workspace_bytes": (C.c_size_t, [_i]),
+    "cgs_knn_mean_dist2": (_i, [_i, _vp, _vp, _vp, _vp]),
     "cgs_sample_curves_forward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     "cgs_sample_curves_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cgs_splat_attrs_forward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -359,4 +359,50 @@ int cgs_splat_attrs_backward(int B, int m, const float* rotation_raw, const floa
     return CGS_OK;
 }
 
+
+int cgs_ssim_forward(int batch, int channels, int height, int width, float C1, float C2, const float* img1,
+                     const float* img2, float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12,
+                     void* stream_) {
+    if (batch * channels == 0 || height == 0 || width == 0) return CGS_OK;
+    if (batch < 0 || channels < 0 || height < 0 || width < 0 || !img1 || !img2 || !ssim_map ||
+        (dm_dmu1 && (!dm_dsigma1_sq || !dm_dsigma12)) || (long long)batch * channels > 65535) {
+        set_error("cgs_ssim_forward: invalid argument");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    launch_ssim_fwd((hipStream_t)stream_, batch * channels, height, width, C1, C2, img1, img2, ssim_map, dm_dmu1,
+                    dm_dsigma1_sq, dm_dsigma12);
+    if (!check_launch("ssim_forward", false, (hipStream_t)stream_)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
+
+int cgs_ssim_backward(int batch, int channels, int height, int width, float C1, float C2, const float* img1,
+                      const float* img2, const float* dL_dmap, const float* dm_dmu1, const float* dm_dsigma1_sq,
+                      const float* dm_dsigma12, float* dL_dimg1, void* stream_) {
+    (void)C1;
+    (void)C2;
+    if (batch * channels == 0 || height == 0 || width == 0) return CGS_OK;
+    if (batch < 0 || channels < 0 || height < 0 || width < 0 || !img1 || !img2 || !dL_dmap || !dm_dmu1 ||
+        !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg1 || (long long)batch * channels > 65535) {
+        set_error("cgs_ssim_backward: invalid argument");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    launch_ssim_bwd((hipStream_t)stream_, batch * channels, height, width, img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq,
+                    dm_dsigma12, dL_dimg1);
+    if (!check_launch("ssim_backward", false, (hipStream_t)stream_)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
+
+size_t cgs_knn_workspace_bytes(int P) { return knn_workspace_bytes(P); }
+
+int cgs_knn_mean_dist2(int P, const float* points, float* mean_dist2, void* workspace, void* stream_) {
+    if (P == 0) return CGS_OK;
+    if (P < 0 || !points || !mean_dist2 || !workspace) {
+        set_error("cgs_knn_mean_dist2: invalid argument");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    launch_knn((hipStream_t)stream_, P, points, mean_dist2, workspace);
+    if (!check_launch("knn_mean_dist2", false, (hipStream_t)stream_)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
+
 }  // extern "C"

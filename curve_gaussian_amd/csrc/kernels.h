@@ -54,4 +54,15 @@ void launch_attrs_backward(hipStream_t s, int B, int m, const float* rot_raw, co
                            const float* g_scl_out, const float* g_all_map, float* g_rot_raw, float* g_opacity_logit,
                            float* g_mask_logit, float* g_scaling);
 
+
+// ssim.hip
+void launch_ssim_fwd(hipStream_t s, int planes, int H, int W, float C1, float C2, const float* img1, const float* img2,
+                     float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12);
+void launch_ssim_bwd(hipStream_t s, int planes, int H, int W, const float* img1, const float* img2,
+                     const float* dL_dmap, const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
+                     float* dL_dimg1);
+// knn.hip
+size_t knn_workspace_bytes(int P);
+void launch_knn(hipStream_t s, int P, const float* pts, float* dists, void* workspace);
+
 }  // namespace cgs

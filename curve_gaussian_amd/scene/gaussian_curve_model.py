@@ -8,10 +8,26 @@ Tensor layout (kept exactly): ``_curve_points [B,4,3]``, ``_width [B,1]`` (log),
 (non-leaf, carry autograd): ``_xyz [P,3]``, ``_rotation [P,4]`` (w,x,y,z un-normalised), ``_scaling [P,3]`` with
 splat index = b*m + i.
 """
+import numpy as np
 import torch
 from torch import nn
 
 from ..ops import curve_sampling
+
+
+def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
+    """Log-linear learning-rate decay with optional delayed warm-up (reference utils/general_utils.py:99-132)."""
+    def helper(step):
+        if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+            return 0.0
+        if lr_delay_steps > 0:
+            delay_rate = lr_delay_mult + (1 - lr_delay_mult) * np.sin(0.5 * np.pi * np.clip(step / lr_delay_steps, 0, 1))
+        else:
+            delay_rate = 1.0
+        t = np.clip(step / max_steps, 0, 1)
+        log_lerp = np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t)
+        return delay_rate * log_lerp
+    return helper
 
 
 class GaussianCurveModel:
@@ -61,7 +77,8 @@ class GaussianCurveModel:
         return self
 
     def training_setup(self, feature_lr=0.0025, opacity_lr=0.025, scaling_lr=0.005, lr_curve_points_init=0.0005,
-                       mask_lr=0.01):
+                       mask_lr=0.01, lr_curve_points_final=0.000005, position_lr_delay_mult=0.01,
+                       position_lr_max_steps=30000):
         """Adam groups of the reference (:200-213; lrs from arguments/__init__.py:83-89)."""
         l = [
             {'params': [self._features_dc], 'lr': feature_lr, "name": "f_dc"},
@@ -72,7 +89,18 @@ class GaussianCurveModel:
             {'params': [self._mask], 'lr': mask_lr, "name": "mask"},
         ]
         self.optimizer = torch.optim.Adam(l, lr=0.0, eps=1e-15)
+        self.curve_scheduler_args = get_expon_lr_func(lr_init=lr_curve_points_init, lr_final=lr_curve_points_final,
+                                                      lr_delay_mult=position_lr_delay_mult,
+                                                      max_steps=position_lr_max_steps)
         return self.optimizer
+
+    def update_learning_rate(self, iteration):
+        """:234-244"""
+        for param_group in self.optimizer.param_groups:
+            if param_group["name"] == "curve_points":
+                lr = self.curve_scheduler_args(iteration)
+                param_group['lr'] = lr
+                return lr
 
     # ------------------------------------------------------------------ per-step derivation
     def prepare_scaling_rot(self, eps=1e-8):

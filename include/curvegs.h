@@ -162,6 +162,27 @@ int cgs_splat_attrs_backward(int B, int m, const float* rotation_raw, const floa
                              float* dL_dopacity_logit, float* dL_dmask_logit, float* dL_dscaling, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * fused-ssim.  Replaces fusedssim / fusedssim_backward (/root/reference/submodules/fused-ssim/ssim.cu:368-404,
+ * :406-444; kernels :187-286, :288-366; declared in ssim.h:7-26).  img [batch, channels, H, W] f32 contiguous, zero
+ * padding ("same"); the "valid" crop is done by the Python wrapper like the reference (fused_ssim/__init__.py:13-14).
+ * dm_* may be NULL (train == false).
+ * ------------------------------------------------------------------------------------------------ */
+int cgs_ssim_forward(int batch, int channels, int height, int width, float C1, float C2, const float* img1,
+                     const float* img2, float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12,
+                     void* stream);
+int cgs_ssim_backward(int batch, int channels, int height, int width, float C1, float C2, const float* img1,
+                      const float* img2, const float* dL_dmap, const float* dm_dmu1, const float* dm_dsigma1_sq,
+                      const float* dm_dsigma12, float* dL_dimg1, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * simple-knn.  Replaces distCUDA2 -> SimpleKNN::knn (/root/reference/submodules/simple-knn/spatial.cu:15-26,
+ * simple_knn.cu:186-222): mean_dist2[i] = mean of the 3 smallest SQUARED distances from point i to other points.
+ * workspace: cgs_knn_workspace_bytes(P) bytes of device scratch.
+ * ------------------------------------------------------------------------------------------------ */
+size_t cgs_knn_workspace_bytes(int P);
+int cgs_knn_mean_dist2(int P, const float* points /*[P,3]*/, float* mean_dist2 /*[P]*/, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Per-kernel timing hook used by bench.py: when enabled, every kernel launched by the library is
  * bracketed by hipEvents on the caller's stream; cgs_prof_collect synchronises and accumulates.
  * ------------------------------------------------------------------------------------------------ */
