@@ -392,6 +392,22 @@ int cgs_ssim_backward(int batch, int channels, int height, int width, float C1, 
     return CGS_OK;
 }
 
+int cgs_edge_aware_loss(int channels, int height, int width, const float* image, const float* gt, float threshold,
+                        void* scratch16, float* dL_dimage, void* stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    if (channels <= 0 || height <= 0 || width <= 0 || !image || !gt || !scratch16) {
+        set_error("cgs_edge_aware_loss: invalid argument");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    if (hipMemsetAsync(scratch16, 0, 16, s) != hipSuccess) {
+        set_error("hipMemsetAsync failed");
+        return CGS_ERR_HIP;
+    }
+    launch_edge_aware_loss(s, channels, height, width, image, gt, threshold, scratch16, dL_dimage);
+    if (!check_launch("edge_aware_loss", false, s)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
+
 size_t cgs_knn_workspace_bytes(int P) { return knn_workspace_bytes(P); }
 
 int cgs_knn_mean_dist2(int P, const float* points, float* mean_dist2, void* workspace, void* stream_) {

@@ -61,6 +61,9 @@ void launch_ssim_fwd(hipStream_t s, int planes, int H, int W, float C1, float C2
 void launch_ssim_bwd(hipStream_t s, int planes, int H, int W, const float* img1, const float* img2,
                      const float* dL_dmap, const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
                      float* dL_dimg1);
+// loss.hip  (scratch16: 16 zeroed bytes = {u32 n_pos, pad, f64 loss_sum})
+void launch_edge_aware_loss(hipStream_t s, int C, int H, int W, const float* image, const float* gt, float thr,
+                            void* scratch16, float* grad);
 // knn.hip
 size_t knn_workspace_bytes(int P);
 void launch_knn(hipStream_t s, int P, const float* pts, float* dists, void* workspace);

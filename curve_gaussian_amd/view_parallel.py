@@ -1,0 +1,54 @@
+"""View-parallel data parallelism for the per-view hot path (new capability; the reference is single-GPU).
+
+One process per GPU, identical curve parameters on every rank, rank r renders views r, r+N, ... of the step's view
+batch, and ONE all-reduce (RCCL over xGMI on the GPU box, gloo in the CPU tests) sums the curve-level gradients.
+The gradients of all learnable tensors live in a single flat buffer so the exchange needs no packing kernels:
+
+    [ _curve_points 12 | _width 1 | _opacity 1 | _mask m | _features_dc m | _features_rest m*((D+1)^2-1) ]  floats/curve
+
+Device-agnostic host logic (plain torch tensors + torch.distributed)."""
+from typing import Dict, List, Sequence
+
+import torch
+
+
+def shard_views(n_views: int, rank: int, world: int) -> List[int]:
+    """Indices of the views rank `rank` renders: r, r+N, r+2N, ... (every view exactly once across ranks)."""
+    return list(range(rank, n_views, world))
+
+
+class FlatGrads:
+    """Owns the flat gradient buffer and installs views of it as the ``.grad`` of the given parameters."""
+
+    def __init__(self, params: Dict[str, torch.Tensor]):
+        self.names = list(params)
+        self.params = params
+        total = sum(p.numel() for p in params.values())
+        any_p = next(iter(params.values()))
+        self.flat = torch.zeros(total, dtype=torch.float32, device=any_p.device)
+        self.slices = {}
+        o = 0
+        for n, p in params.items():
+            self.slices[n] = (o, o + p.numel())
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
+            o += p.numel()
+
+    def zero_(self):
+        self.flat.zero_()
+
+    def view(self, name: str) -> torch.Tensor:
+        a, b = self.slices[name]
+        return self.flat[a:b].view_as(self.params[name])
+
+    def all_reduce(self, group=None, average: bool = False):
+        """Sum (or mean) over ranks, in place.  No-op without an initialised process group."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            self.flat.div_(dist.get_world_size(group))
+
+    @staticmethod
+    def floats_per_curve(m: int = 12, sh_degree: int = 0) -> int:
+        return 12 + 1 + 1 + m + m + m * ((sh_degree + 1) ** 2 - 1)

@@ -174,6 +174,13 @@ int cgs_ssim_backward(int batch, int channels, int height, int width, float C1, 
                       const float* img2, const float* dL_dmap, const float* dm_dmu1, const float* dm_dsigma1_sq,
                       const float* dm_dsigma12, float* dL_dimg1, void* stream);
 
+/* Fused class-balanced edge loss: edge_aware_loss(image, gt_image, threshold) of
+ * /root/reference/utils/loss_utils.py:94-115 (train.py:101).  image, gt [C,H,W] f32.  scratch16: 16 bytes of device
+ * scratch; after the call (stream order) the f64 at scratch16+8 holds SUM (image-gt)^2 * mask, so
+ * loss = that / (C*H*W); the u32 at scratch16 holds the edge-pixel count.  dL_dimage (optional) = d loss / d image. */
+int cgs_edge_aware_loss(int channels, int height, int width, const float* image, const float* gt, float threshold,
+                        void* scratch16, float* dL_dimage, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * simple-knn.  Replaces distCUDA2 -> SimpleKNN::knn (/root/reference/submodules/simple-knn/spatial.cu:15-26,
  * simple_knn.cu:186-222): mean_dist2[i] = mean of the 3 smallest SQUARED distances from point i to other points.

@@ -1,0 +1,116 @@
+"""GPU: the drop-in renderer glue and the training step on the HIP hot path.
+render() (gaussian_renderer/__init__.py:18-157) is checked end-to-end against the composition of the oracles:
+torch restatement of the curve model -> C rasterizer oracle."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import raster as ORA
+from oracle import torch_ref as TR
+from util import S, assert_close, tanfov
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _model(B, seed, H=96, W=128):
+    from curve_gaussian_amd.scene import GaussianCurveModel
+    c = S.make_curves(B, seed)
+    g = torch.Generator().manual_seed(seed)
+    c["width"] = c["width"] + 0.8 + 0.3 * torch.randn(B, 1, generator=g)     # fatter splats for a small image
+    c["mask"] = torch.randn(B, 12, 1, generator=g) * 3
+    c["is_bezier"] = torch.rand(B, generator=g) > 0.25
+    gm = GaussianCurveModel(0, 12, device=DEV).create_from_curves(c["curve_points"], c["width"], c["opacity"],
+                                                                  c["mask"], c["is_bezier"])
+    cam = S.make_camera((0.5, -1.7, 0.9), (0.5, 0.5, 0.5), (0, 0, 1), H, W)
+    return gm, c, cam
+
+
+@pytest.mark.parametrize("use_mask", [False, True])
+def test_render_matches_oracle_composition(use_mask):
+    from curve_gaussian_amd.gaussian_renderer import PipelineParams, render
+    gm, c, cam = _model(300, 5)
+    H, W = cam.image_height, cam.image_width
+    bg = torch.zeros(3, device=DEV)
+    thr = 0.3
+    pkg = render(cam.to(DEV), gm, PipelineParams(), bg, use_mask=use_mask, mask_thr=thr)
+    g = torch.Generator().manual_seed(1)
+    dimg = torch.randn(1, H, W, generator=g)
+    (pkg["render"] * dimg.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    # ---- oracle composition
+    xyz, rot, scl = TR.prepare_scaling_rot(c["curve_points"], c["width"], c["is_bezier"])
+    P = xyz.shape[0]
+    rotn = torch.nn.functional.normalize(rot)
+    opac = torch.sigmoid(c["opacity"]).unsqueeze(1).expand(-1, 12, -1).reshape(-1, 1)
+    if use_mask:
+        mk = (torch.sigmoid(c["mask"]) > thr).float().view(-1, 1)
+        scl, opac = scl * mk, opac * mk
+    amap = TR.build_all_map(rot, xyz, cam.camera_center, cam.world_view_transform)
+    tfx, tfy = tanfov(cam)
+    n = lambda t: t.detach().numpy()
+    fw = ORA.forward(np.zeros(3, np.float32), n(xyz), np.ones((P, 1), np.float32), n(opac), n(scl), n(rotn), 1.0, None,
+                     n(amap), n(cam.world_view_transform), n(cam.full_proj_transform), tfx, tfy, H, W, None, 0,
+                     n(cam.camera_center))
+    assert (pkg["radii"].cpu().numpy() == fw.radii).mean() > 0.999     # 1 ulp in scale can move ceil(3 sigma)
+    assert_close("render", pkg["render"].detach().cpu().numpy(), np.clip(fw.color, 0, 1), outlier_frac=2e-3)
+    assert_close("rend_alpha", pkg["rend_alpha"].detach().cpu().numpy(), fw.out_all_map[3:4], outlier_frac=2e-3)
+    rd = torch.tensor(fw.out_all_map[0:3]).permute(1, 2, 0) @ cam.world_view_transform[:3, :3].T
+    assert_close("rend_dir", pkg["rend_dir"].detach().cpu().numpy(), rd.permute(2, 0, 1).numpy(), outlier_frac=2e-3)
+    assert pkg["visibility_filter"].shape[1] == 1 and pkg["viewspace_points"].grad.shape == (P, 3)
+    # gradient reaches the curve parameters; means2D grad is consumable by add_densification_stats (GM:618-620)
+    assert gm._curve_points.grad.abs().max() > 0 and gm._opacity.grad.abs().max() > 0
+    gm.add_densification_stats(pkg["viewspace_points"], pkg["visibility_filter"].squeeze(1))
+    assert gm.denom.sum() == pkg["visibility_filter"].shape[0]
+    gr = ORA.backward(fw, np.where((fw.color > 0) & (fw.color < 1), dimg.numpy(), 0).astype(np.float32), None, None)
+    assert_close("means2D grad", pkg["viewspace_points"].grad.cpu().numpy(), gr["dL_dmeans2D"], outlier_frac=5e-3,
+                 abs_floor=1e-6)
+    fw.free()
+
+
+def test_edge_aware_loss_matches_reference_golden():
+    from curve_gaussian_amd.ops.losses import edge_aware_loss
+    d = np.load(os.path.join(G, "edge_aware_loss.npz"))
+    img = torch.tensor(d["image"], device=DEV).requires_grad_(True)
+    val = edge_aware_loss(img, torch.tensor(d["gt"], device=DEV))
+    (3.0 * val).backward()
+    np.testing.assert_allclose(float(val), d["value"], rtol=1e-5)
+    np.testing.assert_allclose(img.grad.cpu().numpy(), 3.0 * d["grad"], rtol=1e-4, atol=1e-9)
+    # multi-channel + degenerate gt (no edges at all)
+    g = torch.Generator().manual_seed(2)
+    im3, gt3 = torch.rand(3, 33, 47, generator=g), torch.zeros(3, 33, 47)
+    ref_in = im3.clone().requires_grad_(True)
+    ref = TR.edge_aware_loss(ref_in, gt3)
+    ref.backward()
+    x = im3.to(DEV).requires_grad_(True)
+    v = edge_aware_loss(x, gt3.to(DEV))
+    v.backward()
+    np.testing.assert_allclose(float(v), float(ref), rtol=1e-5)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), ref_in.grad.numpy(), rtol=1e-4, atol=1e-9)
+
+
+def test_train_step_reduces_loss_and_keeps_layout():
+    from curve_gaussian_amd.gaussian_renderer import PipelineParams, render
+    from curve_gaussian_amd.train_step import TrainStep
+    gm, c, cam = _model(200, 11, 64, 96)
+    cams = [S.make_camera((0.5 + 1.8 * math.cos(a), 0.5 + 1.8 * math.sin(a), 0.9), (0.5, 0.5, 0.5), (0, 0, 1), 64, 96).to(DEV)
+            for a in (0.3, 1.7, 3.1, 4.4)]
+    # targets: renders of a perturbed copy of the model
+    with torch.no_grad():
+        gts = []
+        tgt, _, _ = _model(200, 11, 64, 96)
+        tgt._curve_points.add_(0.01 * torch.randn_like(tgt._curve_points))
+        tgt.prepare_scaling_rot()
+        for cm in cams:
+            gts.append(render(cm, tgt, PipelineParams(), torch.zeros(3, device=DEV))["render"].detach())
+    ts = TrainStep(gm, cams, gts, densify_until_iter=20)
+    losses = [float(ts.step()[0]) for _ in range(30)]      # crosses the use_mask switch at iteration 20
+    assert all(np.isfinite(losses))
+    assert np.mean(losses[-8:-4]) < np.mean(losses[:4])
+    assert gm._xyz.shape == (2400, 3) and gm._rotation.shape == (2400, 4) and gm._scaling.shape == (2400, 3)
+    assert gm._curve_points.grad.data_ptr() == ts.flat.flat.data_ptr()   # grads still alias the flat buffer
+    assert gm.optimizer.param_groups[4]["name"] == "curve_points" and gm.optimizer.param_groups[4]["lr"] < 5e-4
