@@ -62,6 +62,7 @@ def main():
                          "[-> RCCL all-reduce]); raster: rasterizer fwd+bwd only on precomputed splats")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=2)
     args = ap.parse_args()
 
@@ -238,6 +239,30 @@ def main():
                              "achieved_GBps": round(alg_view / (ms_per_step * 1e-3) / 1e9, 2),
                              "hbm_roofline_frac": round(alg_view / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                              "sum_kernel_ms": round(sum(kernel_ms.values()), 5)}
+
+    # ---------------------------------------------------------------- train-step ms (the other half of the metric)
+    if world == 1 and not args.no_train_step:
+        from curve_gaussian_amd.scene import GaussianCurveModel
+        from curve_gaussian_amd.train_step import TrainStep
+        gm = GaussianCurveModel(0, m, device=dev).create_from_curves(curves["curve_points"], curves["width"],
+                                                                     curves["opacity"], curves["mask"],
+                                                                     curves["is_bezier"])
+        tcams = my_cams[:8]
+        gg = torch.Generator(device="cpu").manual_seed(7)
+        gts = [((torch.rand(1, H, W, generator=gg) > 0.97).float() * torch.rand(1, H, W, generator=gg)).to(dev) for _ in tcams]
+        ts = TrainStep(gm, tcams, gts)
+        for _ in range(3):
+            ts.step()
+        torch.cuda.synchronize()
+        tt0 = time.perf_counter()
+        n_ts = 16
+        for _ in range(n_ts):
+            ts.step()
+        torch.cuda.synchronize()
+        out["train_step_ms"] = round((time.perf_counter() - tt0) / n_ts * 1e3, 4)
+        out["train_step_note"] = ("lr update + view pick + render (fused attrs + raster) + edge_aware_loss + fused_ssim "
+                                  "+ backward + Adam (6 groups) + prepare_scaling_rot; regularisers of train.py:110-146 "
+                                  "excluded (SURVEY 8d)")
 
     # ---------------------------------------------------------------- CPU baseline (oracle port, bounded sample)
     if world == 1 and not args.no_cpu_baseline:

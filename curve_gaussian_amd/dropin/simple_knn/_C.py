@@ -1,0 +1,1 @@
+from curve_gaussian_amd.simple_knn import distCUDA2  # noqa: F401
