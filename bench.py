@@ -231,8 +231,14 @@ def main():
         dom = max(kernel_ms, key=kernel_ms.get)
         alg_dom = KERNEL_ALG_BYTES.get(dom, lambda *a: 0)(P, R_mean, H * W, tiles)
         ach = alg_dom / (kernel_ms[dom] * 1e-3) / 1e9
+        traffic = None  # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            traffic = tj["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            pass
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                           "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                            "kernel_ms": round(kernel_ms[dom], 5), "algorithmic_bytes_per_launch": int(alg_dom)}
         out["kernel_ms_per_view"] = {k: round(v, 5) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])}
         out["whole_path"] = {"algorithmic_bytes_per_view": int(alg_view),
