@@ -21,6 +21,11 @@ namespace cgs {
 
 constexpr int BATCH = 256;
 constexpr float ALPHA_MIN = 1.0f / 255.0f;
+#ifndef CGS_SLOTS
+#define CGS_SLOTS 8
+#endif
+constexpr int SLOTS = CGS_SLOTS;  // accepted splats buffered per wave between two splat-parallel moment passes (8 or 16)
+constexpr int SLOT_STRIDE = 65;   // +1 pad: lane (s,q) reads s_g[s][16q+p] -> bank (s + 16q + p) % 32, conflict-free
 
 struct TileGeom {
     uint32_t tile, tx, ty;
@@ -210,6 +215,9 @@ __global__ void __launch_bounds__(256) k_render_fwd(const uint2* __restrict__ ra
 }
 
 // ------------------------------------------------------------------------------------------------ backward
+__device__ __forceinline__ float dpp_row_ror8(float v) {  // lane i <- lane i^8 (rotate by 8 inside each 16-lane row)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+}
 // column-wise sum over the four 16-lane rows, result replicated in every row
 __device__ __forceinline__ float rows_sum(float v) {
     const unsigned x = __float_as_uint(v);
@@ -238,8 +246,10 @@ __global__ void __launch_bounds__(256) k_render_bwd(
     __shared__ float4 s_a[BATCH];
     __shared__ float4 s_b[BATCH];
     __shared__ float4 s_c[GEO ? BATCH : 1];
-    __shared__ uint32_t s_id[2][BATCH];
-    __shared__ float s_acc[2][NF][ASTR];   // double-buffered per-batch cross-wave accumulators
+    __shared__ uint32_t s_id[BATCH];
+    __shared__ float s_acc[NF][ASTR];      // per-batch cross-wave accumulators (ds_add_f32 from <=16 lanes per flush)
+    __shared__ float s_g[4][SLOTS][SLOT_STRIDE];  // per wave: g = G dL/dalpha of the last <=16 accepted splats x 64 pixels
+    __shared__ uint32_t s_slotj[4][SLOTS];        // staged index of each slot
     __shared__ uint64_t s_qmask[4][4];
     const TileGeom g = tile_geom(W, H, grid_x);
     const int lane = g.lane;
@@ -273,34 +283,31 @@ __global__ void __launch_bounds__(256) k_render_bwd(
         }
     }
     float last_alpha = 0.f, last_color = 0.f, last_invd = 0.f, lm0 = 0.f, lm1 = 0.f, lm2 = 0.f, lm3 = 0.f;
-    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);  // backward.cu:542-543
     const float nTf_bg = -T_final * (bg_color[0] * dL_dpixel);             // backward.cu:649-652
     const int col = lane & 15;
 
     // Transposed flush of a finished batch: one wave instruction covers 64/FG splats x FG consecutive floats, so the
     // per-line f32 atomics of a splat coalesce into one L2 request (measured 7x the rate of one-field-per-instruction).
-    auto flush_batch = [&](int buf, int nb) {
+    auto flush_batch = [&](int nb) {
         const int f = threadIdx.x % FG, sub = threadIdx.x / FG;
 #pragma unroll 1
         for (int p = 0; p < FG; p++) {
             const int slot = sub + (BATCH / FG) * p;
             if (slot < nb && f < NF) {
-                const float v = s_acc[buf][f][slot];
+                const float v = s_acc[f][slot];
 #ifdef CGS_EXP_NOATOMIC
                 if (v == 123.456f)
 #else
                 if (v != 0.f)
 #endif
-                    atomicAdd(grad_acc + (size_t)s_id[buf][slot] * ACC_STRIDE + f, v);
+                    atomicAdd(grad_acc + (size_t)s_id[slot] * ACC_STRIDE + f, v);
             }
         }
     };
     for (int i = 0; i < rounds; i++) {
-        const int cur = i & 1;
-        __syncthreads();  // every wave is done with the previous batch (staged data + its LDS accumulators)
-        if (i > 0) flush_batch(cur ^ 1, BATCH);  // previous batches are always full (only the last can be partial)
+        if (i > 0) __syncthreads();  // the previous batch has been flushed
 #pragma unroll
-        for (int k = 0; k < NF; k++) s_acc[cur][k][threadIdx.x] = 0.f;
+        for (int k = 0; k < NF; k++) s_acc[k][threadIdx.x] = 0.f;
         const int progress = i * BATCH + threadIdx.x;
         uint32_t qm = 0;
         if (progress < total) {
@@ -309,7 +316,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(
             const float4 a = r->a, b = r->b;
             float4 sa, sb;
             stage_splat(a, b, sa, sb);
-            s_id[cur][threadIdx.x] = id;
+            s_id[threadIdx.x] = id;
             s_a[threadIdx.x] = sa;
             s_b[threadIdx.x] = sb;
             if (GEO) s_c[threadIdx.x] = r->c;
@@ -324,116 +331,141 @@ __global__ void __launch_bounds__(256) k_render_bwd(
         // staged index J (0..255) of batch i sits at 0-based list position  pos = total-1-(i*256+J); it can matter to
         // this wave only if pos < wave_last  <=>  J >= total-wave_last-i*256
         const int first_J = total - (int)wave_last - i * BATCH;
+        // Phase 1 (pixel-parallel): walk this quadrant's accepted splats back to front; every lane keeps its pixel's
+        // recurrences and emits ONE scalar g = G dL/dalpha per (pixel, splat) into the wave's slot buffer.
+        // Phase 2 (splat-parallel, every SLOTS accepted splats): lane (s = lane & 15, q = lane >> 4) owns slot s and
+        // the 16 pixels of quadrant rows 2q, 2q+1 and accumulates the six moments of g there with plain FMAs -- no
+        // 64-lane reduction per field; a 4-way cross-row sum (v_permlane swaps) finishes it.
+        int nslot = 0;
+        float t_c = 0.f, t_invd = 0.f, t_m0 = 0.f, t_m1 = 0.f, t_m2 = 0.f, t_m3 = 0.f;  // extras: DPP-reduced, column = slot
+        auto flush_slots = [&](int n) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            constexpr int QG = 64 / SLOTS;        // lane groups per slot (4 or 8)
+            constexpr int RPL = 8 / QG;           // quadrant rows per lane (2 or 1)
+            const int sl = lane & (SLOTS - 1), q = lane / SLOTS;
+            const int j = (int)s_slotj[g.wave][sl < n ? sl : 0];
+            const float4 sa = s_a[j];
+            const float dx0 = sa.x - (float)(g.tx * TILE + ((g.wave & 1) << 3));             // minus column c
+            const float dy0 = sa.y - (float)(g.ty * TILE + ((g.wave >> 1) << 3) + RPL * q);  // minus row r
+            float Sg = 0.f, Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f;
+            float dxc[8], dxc2[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) { dxc[c] = dx0 - (float)c; dxc2[c] = dxc[c] * dxc[c]; }
+            const float* gp = &s_g[g.wave][sl][8 * RPL * q];
+#pragma unroll
+            for (int r = 0; r < RPL; r++) {
+                const float dyr = dy0 - (float)r;
+                float R = 0.f, Rx = 0.f, Rxx = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const float gv = gp[8 * r + c];
+                    R += gv; Rx += gv * dxc[c]; Rxx += gv * dxc2[c];
+                }
+                Sg += R; Sx += Rx; Sxx += Rxx;
+                Sy += dyr * R; Sxy += dyr * Rx; Syy += (dyr * dyr) * R;
+            }
+            if (SLOTS == 8) {  // lanes l and l^8 hold the two half-row groups of the same slot: fold them first
+                Sg += dpp_row_ror8(Sg); Sx += dpp_row_ror8(Sx); Sy += dpp_row_ror8(Sy);
+                Sxx += dpp_row_ror8(Sxx); Sxy += dpp_row_ror8(Sxy); Syy += dpp_row_ror8(Syy);
+            }
+            Sg = rows_sum(Sg); Sx = rows_sum(Sx); Sy = rows_sum(Sy);
+            Sxx = rows_sum(Sxx); Sxy = rows_sum(Sxy); Syy = rows_sum(Syy);
+            if (COLG) t_c = rows_sum(t_c);
+            if (INVD) t_invd = rows_sum(t_invd);
+            if (GEO) { t_m0 = rows_sum(t_m0); t_m1 = rows_sum(t_m1); t_m2 = rows_sum(t_m2); t_m3 = rows_sum(t_m3); }
+            if (lane < n) {
+                atomicAdd(&s_acc[0][j], Sg); atomicAdd(&s_acc[1][j], Sx); atomicAdd(&s_acc[2][j], Sy);
+                atomicAdd(&s_acc[3][j], Sxx); atomicAdd(&s_acc[4][j], Sxy); atomicAdd(&s_acc[5][j], Syy);
+                if (COLG) atomicAdd(&s_acc[ACC_COL][j], t_c);
+                if (INVD) atomicAdd(&s_acc[ACC_INVD][j], t_invd);
+                if (GEO) {
+                    atomicAdd(&s_acc[ACC_MAP + 0][j], t_m0); atomicAdd(&s_acc[ACC_MAP + 1][j], t_m1);
+                    atomicAdd(&s_acc[ACC_MAP + 2][j], t_m2); atomicAdd(&s_acc[ACC_MAP + 3][j], t_m3);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // slot buffer may be overwritten from here on
+        };
 #pragma unroll 1
         for (int c = 0; c < 4; c++) {
             uint64_t m = uniform64(s_qmask[g.wave][c]);
             const int lo = first_J - c * 64;
             if (lo >= 64) m = 0;
             else if (lo > 0) m &= ~((1ull << lo) - 1ull);
-#pragma unroll 1
-            for (int sub = 0; sub < 4; sub++) {
-                uint32_t m16 = (uint32_t)(m >> (16 * sub)) & 0xFFFFu;
-                if (m16 == 0) continue;
-                const uint32_t m16_all = m16;
-                // per-wave register tile: lane (16 r + c) holds row r's partial sums of splat (jbase + c)
-                float t_g = 0.f, t_x = 0.f, t_y = 0.f, t_xx = 0.f, t_xy = 0.f, t_yy = 0.f, t_c = 0.f, t_invd = 0.f;
-                float t_m0 = 0.f, t_m1 = 0.f, t_m2 = 0.f, t_m3 = 0.f;
-                const int jbase = c * 64 + sub * 16;
-                while (m16) {
-                    const int bit = __builtin_ctz(m16);
-                    m16 &= m16 - 1;
-                    const int j = jbase + bit;
-                    const uint32_t pos = (uint32_t)(total - 1 - (i * BATCH + j));  // contributor after the decrement
-                    const float4 a = s_a[j];
-                    const float4 b = s_b[j];
-                    const float dx = a.x - pixfx, dy = a.y - pixfy;
-                    const float p2 = dx * (a.z * dx + a.w * dy) + b.x * dy * dy;
-                    const float G = __builtin_amdgcn_exp2f(p2);
-                    const float alpha = fminf(0.99f, b.y * G);
-                    const bool active = (pos < last_contributor) && !(p2 > 0.0f) && !(alpha < ALPHA_MIN);
-                    if (ballot64(active) == 0ull) continue;
-                    float v_g = 0.f, v_c = 0.f, v_invd = 0.f, v_m0 = 0.f, v_m1 = 0.f, v_m2 = 0.f, v_m3 = 0.f;
-                    if (active) {
-                        const float rcp_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-                        T = T * rcp_1ma;
-                        const float dchannel_dcolor = alpha * T;
-                        float dL_dalpha;
-                        {
-                            const float cval = b.z;
-                            accum_rec = last_alpha * last_color + (1.f - last_alpha) * accum_rec;
-                            last_color = cval;
-                            dL_dalpha = (cval - accum_rec) * dL_dpixel;
-                            if (COLG) v_c = dchannel_dcolor * dL_dpixel;
-                        }
-                        if (INVD) {
-                            const float invd = b.w;
-                            accum_invd = last_alpha * last_invd + (1.f - last_alpha) * accum_invd;
-                            last_invd = invd;
-                            dL_dalpha += (invd - accum_invd) * dL_invd;
-                            v_invd = dchannel_dcolor * dL_invd;
-                        }
-                        if (GEO) {
-                            const float4 cm = s_c[j];
-                            accum_m0 = last_alpha * lm0 + (1.f - last_alpha) * accum_m0; lm0 = cm.x;
-                            accum_m1 = last_alpha * lm1 + (1.f - last_alpha) * accum_m1; lm1 = cm.y;
-                            accum_m2 = last_alpha * lm2 + (1.f - last_alpha) * accum_m2; lm2 = cm.z;
-                            accum_m3 = last_alpha * lm3 + (1.f - last_alpha) * accum_m3; lm3 = cm.w;
-                            dL_dalpha += (cm.x - accum_m0) * dm0;
-                            dL_dalpha += (cm.y - accum_m1) * dm1;
-                            dL_dalpha += (cm.z - accum_m2) * dm2;
-                            dL_dalpha += (cm.w - accum_m3) * dm3;
-                            v_m0 = dchannel_dcolor * dm0; v_m1 = dchannel_dcolor * dm1;
-                            v_m2 = dchannel_dcolor * dm2; v_m3 = dchannel_dcolor * dm3;
-                        }
-                        dL_dalpha = dL_dalpha * T + nTf_bg * rcp_1ma;
-                        last_alpha = alpha;
-                        v_g = G * dL_dalpha;
+            while (m) {
+                const int bit = __builtin_ctzll(m);
+                m &= m - 1;
+                const int j = c * 64 + bit;
+                const uint32_t pos = (uint32_t)(total - 1 - (i * BATCH + j));  // contributor after the decrement
+                const float4 a = s_a[j];
+                const float4 b = s_b[j];
+                const float dx = a.x - pixfx, dy = a.y - pixfy;
+                const float p2 = dx * (a.z * dx + a.w * dy) + b.x * dy * dy;
+                const float G = __builtin_amdgcn_exp2f(p2);
+                const float alpha = fminf(0.99f, b.y * G);
+                const bool active = (pos < last_contributor) && !(p2 > 0.0f) && !(alpha < ALPHA_MIN);
+                if (ballot64(active) == 0ull) continue;
+                float v_g = 0.f, v_c = 0.f, v_invd = 0.f, v_m0 = 0.f, v_m1 = 0.f, v_m2 = 0.f, v_m3 = 0.f;
+                if (active) {
+                    const float rcp_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                    T = T * rcp_1ma;
+                    const float dchannel_dcolor = alpha * T;
+                    float dL_dalpha;
+                    {
+                        const float cval = b.z;
+                        accum_rec = last_alpha * last_color + (1.f - last_alpha) * accum_rec;
+                        last_color = cval;
+                        dL_dalpha = (cval - accum_rec) * dL_dpixel;
+                        if (COLG) v_c = dchannel_dcolor * dL_dpixel;
                     }
-                    const float v_x = v_g * dx, v_y = v_g * dy;
-                    float v_xx = v_x * dx, v_xy = v_x * dy, v_yy = v_y * dy;
-                    // 64 -> 4 row sums (DPP), parked in column `bit` of the register tile
-#ifdef CGS_EXP_NOREDUCE
-                    const float r_x = v_x, r_y = v_y;
-#else
-                    v_g = row16_sum(v_g);
-                    const float r_x = row16_sum(v_x), r_y = row16_sum(v_y);
-                    v_xx = row16_sum(v_xx); v_xy = row16_sum(v_xy); v_yy = row16_sum(v_yy);
-                    if (COLG) v_c = row16_sum(v_c);
-#endif
-                    if (INVD) v_invd = row16_sum(v_invd);
-                    if (GEO) { v_m0 = row16_sum(v_m0); v_m1 = row16_sum(v_m1); v_m2 = row16_sum(v_m2); v_m3 = row16_sum(v_m3); }
-                    const bool mine = col == bit;
-                    t_g = mine ? v_g : t_g; t_x = mine ? r_x : t_x; t_y = mine ? r_y : t_y;
-                    t_xx = mine ? v_xx : t_xx; t_xy = mine ? v_xy : t_xy; t_yy = mine ? v_yy : t_yy;
-                    if (COLG) t_c = mine ? v_c : t_c;
-                    if (INVD) t_invd = mine ? v_invd : t_invd;
+                    if (INVD) {
+                        const float invd = b.w;
+                        accum_invd = last_alpha * last_invd + (1.f - last_alpha) * accum_invd;
+                        last_invd = invd;
+                        dL_dalpha += (invd - accum_invd) * dL_invd;
+                        v_invd = dchannel_dcolor * dL_invd;
+                    }
                     if (GEO) {
+                        const float4 cm = s_c[j];
+                        accum_m0 = last_alpha * lm0 + (1.f - last_alpha) * accum_m0; lm0 = cm.x;
+                        accum_m1 = last_alpha * lm1 + (1.f - last_alpha) * accum_m1; lm1 = cm.y;
+                        accum_m2 = last_alpha * lm2 + (1.f - last_alpha) * accum_m2; lm2 = cm.z;
+                        accum_m3 = last_alpha * lm3 + (1.f - last_alpha) * accum_m3; lm3 = cm.w;
+                        dL_dalpha += (cm.x - accum_m0) * dm0;
+                        dL_dalpha += (cm.y - accum_m1) * dm1;
+                        dL_dalpha += (cm.z - accum_m2) * dm2;
+                        dL_dalpha += (cm.w - accum_m3) * dm3;
+                        v_m0 = dchannel_dcolor * dm0; v_m1 = dchannel_dcolor * dm1;
+                        v_m2 = dchannel_dcolor * dm2; v_m3 = dchannel_dcolor * dm3;
+                    }
+                    dL_dalpha = dL_dalpha * T + nTf_bg * rcp_1ma;
+                    last_alpha = alpha;
+                    v_g = G * dL_dalpha;
+                }
+                s_g[g.wave][nslot][lane] = v_g;
+                if (lane == 0) s_slotj[g.wave][nslot] = (uint32_t)j;
+                if (COLG || INVD || GEO) {
+                    const bool mine = col == nslot;
+                    if (COLG) { v_c = row16_sum(v_c); t_c = mine ? v_c : t_c; }
+                    if (INVD) { v_invd = row16_sum(v_invd); t_invd = mine ? v_invd : t_invd; }
+                    if (GEO) {
+                        v_m0 = row16_sum(v_m0); v_m1 = row16_sum(v_m1); v_m2 = row16_sum(v_m2); v_m3 = row16_sum(v_m3);
                         t_m0 = mine ? v_m0 : t_m0; t_m1 = mine ? v_m1 : t_m1;
                         t_m2 = mine ? v_m2 : t_m2; t_m3 = mine ? v_m3 : t_m3;
                     }
                 }
-                // flush the tile: reduce the 4 rows column-wise, lanes 0..15 own splats jbase..jbase+15
-                t_g = rows_sum(t_g); t_x = rows_sum(t_x); t_y = rows_sum(t_y);
-                t_xx = rows_sum(t_xx); t_xy = rows_sum(t_xy); t_yy = rows_sum(t_yy);
-                if (COLG) t_c = rows_sum(t_c);
-                if (INVD) t_invd = rows_sum(t_invd);
-                if (GEO) { t_m0 = rows_sum(t_m0); t_m1 = rows_sum(t_m1); t_m2 = rows_sum(t_m2); t_m3 = rows_sum(t_m3); }
-                if (lane < 16 && ((m16_all >> lane) & 1u)) {
-                    const int t = jbase + lane;
-                    atomicAdd(&s_acc[cur][0][t], t_g); atomicAdd(&s_acc[cur][1][t], t_x); atomicAdd(&s_acc[cur][2][t], t_y);
-                    atomicAdd(&s_acc[cur][3][t], t_xx); atomicAdd(&s_acc[cur][4][t], t_xy); atomicAdd(&s_acc[cur][5][t], t_yy);
-                    if (COLG) atomicAdd(&s_acc[cur][ACC_COL][t], t_c);
-                    if (INVD) atomicAdd(&s_acc[cur][ACC_INVD][t], t_invd);
-                    if (GEO) {
-                        atomicAdd(&s_acc[cur][ACC_MAP + 0][t], t_m0); atomicAdd(&s_acc[cur][ACC_MAP + 1][t], t_m1);
-                        atomicAdd(&s_acc[cur][ACC_MAP + 2][t], t_m2); atomicAdd(&s_acc[cur][ACC_MAP + 3][t], t_m3);
-                    }
+                if (++nslot == SLOTS) {
+                    flush_slots(SLOTS);
+                    nslot = 0;
                 }
             }
         }
+        if (nslot) flush_slots(nslot);
+        __syncthreads();  // every wave's LDS accumulation for this batch is done
+        flush_batch(min(BATCH, total - i * BATCH));
     }
-    __syncthreads();
-    flush_batch((rounds - 1) & 1, total - (rounds - 1) * BATCH);
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
