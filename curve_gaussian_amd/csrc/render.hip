@@ -130,13 +130,17 @@ __global__ void __launch_bounds__(256) k_render_fwd(const uint2* __restrict__ ra
     const uint2 range = ranges[g.tile];
     const int total = (int)(range.y - range.x);
     const int rounds = (total + BATCH - 1) / BATCH;
-    // `live` = pixel still compositing (reference: !done); kept as a per-lane predicate, updated branch-free
-    bool live = g.inside;
+    // Per-lane state, branch-free: Tw is the WORKING transmittance -- equal to T while the pixel is live and forced to
+    // 0 once it terminates (reference: done = true), so a dead pixel blends nothing and can never pass the T test
+    // again; T keeps the value the reference writes to final_T.  No per-lane boolean survives an iteration, which
+    // keeps the loop free of exec-mask / SGPR-pair bookkeeping (the scalar unit was the bottleneck of the first
+    // version: ~30 SALU per splat vs ~9 now).
     float T = 1.0f;
+    float Tw = g.inside ? 1.0f : 0.0f;
     uint32_t last_contributor = 0;
     float C = 0.f, Dacc = 0.f;
     float A0 = 0.f, A1 = 0.f, A2 = 0.f, A3 = 0.f;
-    bool wave_done = ballot64(live) == 0ull;
+    bool wave_done = ballot64(Tw > 0.f) == 0ull;
     for (int i = 0; i < rounds; i++) {
         // vote: stop when every wave is finished (reference: __syncthreads_count(done) == BLOCK_SIZE); this barrier
         // also guarantees every wave is done with the previous batch's staged data
@@ -163,7 +167,7 @@ __global__ void __launch_bounds__(256) k_render_fwd(const uint2* __restrict__ ra
         if (wave_done) continue;
         const uint32_t base = (uint32_t)(i * BATCH) + 1u;
 #pragma unroll 1
-        for (int c = 0; c < 4 && !wave_done; c++) {
+        for (int c = 0; c < 4; c++) {
             uint64_t m = uniform64(s_qmask[g.wave][c]);
             while (m) {
                 const int bit = __builtin_ctzll(m);
@@ -173,12 +177,12 @@ __global__ void __launch_bounds__(256) k_render_fwd(const uint2* __restrict__ ra
                 const float4 b = s_b[j];
                 const float dx = a.x - pixfx, dy = a.y - pixfy;
                 const float p2 = dx * (a.z * dx + a.w * dy) + b.x * dy * dy;
-                const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(p2));
-                const float test_T = T * (1.f - alpha);
-                const bool hit = live && !(p2 > 0.0f) && !(alpha < ALPHA_MIN);
-                const bool blend = hit && !(test_T < 0.0001f);
-                live = live && !(hit && !blend);  // T would drop below 1e-4: pixel terminates, splat NOT blended
-                const float w = blend ? alpha * T : 0.f;
+                float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(p2));
+                alpha = (p2 > 0.0f) ? 0.f : alpha;              // reference: power > 0 -> skip
+                const float test_T = Tw - Tw * alpha;
+                const bool hit = !(alpha < ALPHA_MIN);
+                const bool blend = hit && !(test_T < 0.0001f);  // a dead pixel has Tw == test_T == 0: never blends
+                const float w = blend ? alpha * Tw : 0.f;
                 C += b.z * w;
                 Dacc += b.w * w;
                 if (GEO) {
@@ -187,10 +191,12 @@ __global__ void __launch_bounds__(256) k_render_fwd(const uint2* __restrict__ ra
                 }
                 T = blend ? test_T : T;
                 last_contributor = blend ? base + (uint32_t)j : last_contributor;  // 1-based list position
-                if (ballot64(live) == 0ull) {
-                    wave_done = true;
-                    break;
-                }
+                // hit but not blended: T would drop below 1e-4 -> the pixel terminates and the splat is NOT blended
+                Tw = blend ? test_T : (hit ? 0.f : Tw);
+            }
+            if (ballot64(Tw > 0.f) == 0ull) {  // checked once per 64-splat chunk
+                wave_done = true;
+                break;
             }
         }
     }
@@ -239,15 +245,12 @@ __global__ void __launch_bounds__(256) k_render_bwd(
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
     const float* __restrict__ dL_dout_invdepth, const float* __restrict__ dL_dout_all_map,
     float* __restrict__ grad_acc) {
-    // accumulator rows are indexed by FIELD POSITION in the packed per-splat record (common.h ACC_*)
-    constexpr int NF = GEO ? 12 : 8;       // rows kept in LDS
-    constexpr int FG = GEO ? 16 : 8;       // lanes per splat in the transposed flush (8 or 16 consecutive floats)
-    constexpr int ASTR = BATCH + 4;        // row stride: bank = 4 f + slot -> conflict-free transposed reads
+    constexpr int NF = GEO ? 12 : 8;       // fields of the packed per-splat accumulator record that can be non-zero
     __shared__ float4 s_a[BATCH];
     __shared__ float4 s_b[BATCH];
     __shared__ float4 s_c[GEO ? BATCH : 1];
     __shared__ uint32_t s_id[BATCH];
-    __shared__ float s_acc[NF][ASTR];      // per-batch cross-wave accumulators (ds_add_f32 from <=16 lanes per flush)
+    __shared__ float s_t[4][SLOTS][16];    // per wave: slot sums laid out [slot][field] for the transposed atomic flush
     __shared__ float s_g[4][SLOTS][SLOT_STRIDE];  // per wave: g = G dL/dalpha of the last <=16 accepted splats x 64 pixels
     __shared__ uint32_t s_slotj[4][SLOTS];        // staged index of each slot
     __shared__ uint64_t s_qmask[4][4];
@@ -286,28 +289,8 @@ __global__ void __launch_bounds__(256) k_render_bwd(
     const float nTf_bg = -T_final * (bg_color[0] * dL_dpixel);             // backward.cu:649-652
     const int col = lane & 15;
 
-    // Transposed flush of a finished batch: one wave instruction covers 64/FG splats x FG consecutive floats, so the
-    // per-line f32 atomics of a splat coalesce into one L2 request (measured 7x the rate of one-field-per-instruction).
-    auto flush_batch = [&](int nb) {
-        const int f = threadIdx.x % FG, sub = threadIdx.x / FG;
-#pragma unroll 1
-        for (int p = 0; p < FG; p++) {
-            const int slot = sub + (BATCH / FG) * p;
-            if (slot < nb && f < NF) {
-                const float v = s_acc[f][slot];
-#ifdef CGS_EXP_NOATOMIC
-                if (v == 123.456f)
-#else
-                if (v != 0.f)
-#endif
-                    atomicAdd(grad_acc + (size_t)s_id[slot] * ACC_STRIDE + f, v);
-            }
-        }
-    };
     for (int i = 0; i < rounds; i++) {
-        if (i > 0) __syncthreads();  // the previous batch has been flushed
-#pragma unroll
-        for (int k = 0; k < NF; k++) s_acc[k][threadIdx.x] = 0.f;
+        if (i > 0) __syncthreads();  // every wave is done with the previous batch's staged data
         const int progress = i * BATCH + threadIdx.x;
         uint32_t qm = 0;
         if (progress < total) {
@@ -375,14 +358,33 @@ __global__ void __launch_bounds__(256) k_render_bwd(
             if (COLG) t_c = rows_sum(t_c);
             if (INVD) t_invd = rows_sum(t_invd);
             if (GEO) { t_m0 = rows_sum(t_m0); t_m1 = rows_sum(t_m1); t_m2 = rows_sum(t_m2); t_m3 = rows_sum(t_m3); }
+            // Transposed flush: lanes 0..n-1 hold the sums of slot `lane`; lay them out [slot][field] in LDS and let
+            // lane (slot = lane >> 3, field = lane & 7) issue the global f32 atomic, so the 6-8 atomics of one splat
+            // hit 8 consecutive floats of its 64-byte accumulator record and coalesce into ONE L2 request
+            // (measured 7x the rate of one-field-per-instruction; scratch/xcc_probe.hip).
             if (lane < n) {
-                atomicAdd(&s_acc[0][j], Sg); atomicAdd(&s_acc[1][j], Sx); atomicAdd(&s_acc[2][j], Sy);
-                atomicAdd(&s_acc[3][j], Sxx); atomicAdd(&s_acc[4][j], Sxy); atomicAdd(&s_acc[5][j], Syy);
-                if (COLG) atomicAdd(&s_acc[ACC_COL][j], t_c);
-                if (INVD) atomicAdd(&s_acc[ACC_INVD][j], t_invd);
-                if (GEO) {
-                    atomicAdd(&s_acc[ACC_MAP + 0][j], t_m0); atomicAdd(&s_acc[ACC_MAP + 1][j], t_m1);
-                    atomicAdd(&s_acc[ACC_MAP + 2][j], t_m2); atomicAdd(&s_acc[ACC_MAP + 3][j], t_m3);
+                float* tp = &s_t[g.wave][lane][0];
+                tp[0] = Sg; tp[1] = Sx; tp[2] = Sy; tp[3] = Sxx; tp[4] = Sxy; tp[5] = Syy;
+                tp[ACC_COL] = COLG ? t_c : 0.f;
+                tp[ACC_INVD] = INVD ? t_invd : 0.f;
+                if (GEO) { tp[ACC_MAP + 0] = t_m0; tp[ACC_MAP + 1] = t_m1; tp[ACC_MAP + 2] = t_m2; tp[ACC_MAP + 3] = t_m3; }
+                tp[15] = __uint_as_float(s_id[j]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int pass = 0; pass < (GEO ? 2 : 1); pass++) {
+                const int slot = lane >> 3, f = (lane & 7) + 8 * pass;
+                if (slot < n && f < NF) {
+                    const float v = s_t[g.wave][slot][f];
+                    const uint32_t id = __float_as_uint(s_t[g.wave][slot][15]);
+#ifdef CGS_EXP_NOATOMIC
+                    if (v == 123.456f)
+#else
+                    if (v != 0.f)
+#endif
+                        atomicAdd(grad_acc + (size_t)id * ACC_STRIDE + f, v);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -463,8 +465,6 @@ __global__ void __launch_bounds__(256) k_render_bwd(
             }
         }
         if (nslot) flush_slots(nslot);
-        __syncthreads();  // every wave's LDS accumulation for this batch is done
-        flush_batch(min(BATCH, total - i * BATCH));
     }
 }
 
