@@ -181,14 +181,14 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
     launch_scan_tiles(s, tiles, img.tile_count, img.ranges, img.total);
     if (!check_launch("scan_tiles", debug, s)) return CGS_ERR_HIP;
 
-    uint32_t R32 = 0;
-    hipError_t e = hipMemcpyAsync(&R32, img.total, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    uint32_t host_tot[2] = {0, 0};  // {R, longest tile list}
+    hipError_t e = hipMemcpyAsync(host_tot, img.total, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) {
         set_error("reading num_rendered failed: %s", hipGetErrorString(e));
         return CGS_ERR_HIP;
     }
-    const int64_t R = (int64_t)R32;
+    const int64_t R = (int64_t)host_tot[0];
     char* bchunk = (char*)binning_alloc(binning_user, cgs_binning_bytes(R));
     if (!bchunk) {
         set_error("cgs_rasterize_forward: binning allocation callback returned NULL");
@@ -198,7 +198,7 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
     if (R > 0) {
         launch_scatter(s, P, radii, geom.rec, gx, gy, img.ranges, img.tile_cursor, bin.keys);
         if (!check_launch("scatter", debug, s)) return CGS_ERR_HIP;
-        launch_tile_sort(s, tiles, img.ranges, bin.keys, bin.point_list);
+        launch_tile_sort(s, tiles, img.ranges, bin.keys, bin.point_list, host_tot[1]);
         if (!check_launch("tile_sort", debug, s)) return CGS_ERR_HIP;
     }
     launch_render_fwd(s, render_geo != 0, tiles, img.ranges, bin.point_list, width, height, gx, geom.rec, img.final_T,

@@ -19,13 +19,16 @@ namespace cgs {
 __global__ void __launch_bounds__(1024) k_scan_tiles(int tiles, const uint32_t* __restrict__ tile_count,
                                                      uint2* __restrict__ ranges, uint32_t* __restrict__ total) {
     __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t wave_max[16];
     __shared__ uint32_t carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
+    uint32_t vmax = 0;
     for (int base = 0; base < tiles; base += 1024) {
         const int i = base + tid;
         const uint32_t v = (i < tiles) ? tile_count[i] : 0u;
+        vmax = max(vmax, v);
         // inclusive scan inside the wave
         uint32_t s = v;
 #pragma unroll
@@ -44,7 +47,16 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(int tiles, const uint32_t* 
         if (tid == 1023) carry_s = incl;
         __syncthreads();
     }
-    if (tid == 0) total[0] = carry_s;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, off, 64));
+    if (lane == 0) wave_max[wid] = vmax;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t mx = 0;
+        for (int w = 0; w < 16; w++) mx = max(mx, wave_max[w]);
+        total[0] = carry_s;  // R
+        total[1] = mx;       // longest tile list (selects the sort path on the host)
+    }
 }
 
 __global__ void __launch_bounds__(256) k_scatter(int P, const int* __restrict__ radii,
@@ -97,14 +109,61 @@ __device__ __forceinline__ void bitonic_any_n(Ptr k, uint32_t n, uint32_t n2, ui
     }
 }
 
+// Small buckets (n <= 1024, i.e. every tile of the BASELINE configs): counting rank sort.  Keys are unique, so
+// rank(key) = #{keys < key} is its final position.  Every thread ranks up to 4 keys against wave-uniform (broadcast)
+// LDS reads of all n keys: no barriers inside the O(n^2/256) loop, 8 KiB of LDS, 8 workgroups per CU (the bitonic
+// network spends its time in 36+ barrier-separated LDS round trips at 5 workgroups per CU).
+// Measured on cfg3 (mean list 225): 81 us vs 90 us for the LDS bitonic network; unrolling the broadcast loop or
+// splitting the compare into 32-bit depth/idx parts was slower (103 / 117 us).
+constexpr uint32_t RANK_MAX = 1024;
+__global__ void __launch_bounds__(256) k_tile_rank_sort(const uint2* __restrict__ ranges,
+                                                        const uint64_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ point_list) {
+    __shared__ uint64_t sk[RANK_MAX];
+    const uint2 rg = ranges[blockIdx.x];
+    const uint32_t n = rg.y - rg.x;
+    if (n == 0 || n > RANK_MAX) return;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t* gk = keys + rg.x;
+    uint32_t* out = point_list + rg.x;
+    uint64_t mine[4];
+    uint32_t rank[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t i = tid + 256u * q;
+        mine[q] = i < n ? gk[i] : ~0ull;
+        if (i < n) sk[i] = mine[q];
+    }
+    __syncthreads();
+    const int nq = (n + 255) / 256;  // keys per thread actually in use (wave-uniform)
+    const uint32_t n2 = n & ~1u;
+    for (uint32_t u = 0; u < n2; u += 2) {
+        const uint64_t k0 = sk[u], k1 = sk[u + 1];  // uniform address: LDS broadcast
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (q < nq) rank[q] += (uint32_t)(k0 < mine[q]) + (uint32_t)(k1 < mine[q]);
+        }
+    }
+    if (n & 1u) {
+        const uint64_t k0 = sk[n - 1];
+#pragma unroll
+        for (int q = 0; q < 4; q++) rank[q] += (uint32_t)(k0 < mine[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t i = tid + 256u * q;
+        if (i < n) out[rank[q]] = (uint32_t)mine[q];
+    }
+}
+
 constexpr uint32_t SORT_LDS_KEYS = 4096;  // 32 KiB of LDS per workgroup
 
 __global__ void __launch_bounds__(256) k_tile_sort(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
-                                                   uint32_t* __restrict__ point_list) {
+                                                   uint32_t* __restrict__ point_list, uint32_t min_n) {
     __shared__ uint64_t sk[SORT_LDS_KEYS];
     const uint2 rg = ranges[blockIdx.x];
     const uint32_t n = rg.y - rg.x;
-    if (n == 0) return;
+    if (n <= min_n) return;  // handled by k_tile_rank_sort
     const uint32_t tid = threadIdx.x;
     uint64_t* gk = keys + rg.x;
     uint32_t* out = point_list + rg.x;
@@ -138,9 +197,16 @@ void launch_scatter(hipStream_t s, int P, const int* radii, const SplatRec* rec,
     hipLaunchKernelGGL(k_scatter, dim3((P + 255) / 256), dim3(256), 0, s, P, radii, rec, grid_x, grid_y, ranges,
                        tile_cursor, keys);
 }
-void launch_tile_sort(hipStream_t s, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* point_list) {
-    ProfScope p("tile_sort", s);
-    hipLaunchKernelGGL(k_tile_sort, dim3(tiles), dim3(256), 0, s, ranges, keys, point_list);
+void launch_tile_sort(hipStream_t s, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* point_list,
+                      uint32_t max_count) {
+    {
+        ProfScope p("tile_sort", s);
+        hipLaunchKernelGGL(k_tile_rank_sort, dim3(tiles), dim3(256), 0, s, ranges, keys, point_list);
+    }
+    if (max_count > RANK_MAX) {  // rare: some tile list is longer than 1024 -> bitonic network (LDS or global memory)
+        ProfScope p("tile_sort_big", s);
+        hipLaunchKernelGGL(k_tile_sort, dim3(tiles), dim3(256), 0, s, ranges, keys, point_list, RANK_MAX);
+    }
 }
 
 }  // namespace cgs

@@ -27,7 +27,8 @@ void launch_preprocess_bwd(hipStream_t s, int P, int D, int M, const float* mean
 void launch_scan_tiles(hipStream_t s, int tiles, const uint32_t* tile_count, uint2* ranges, uint32_t* total);
 void launch_scatter(hipStream_t s, int P, const int* radii, const SplatRec* rec, int grid_x, int grid_y,
                     const uint2* ranges, uint32_t* tile_cursor, uint64_t* keys);
-void launch_tile_sort(hipStream_t s, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* point_list);
+void launch_tile_sort(hipStream_t s, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* point_list,
+                      uint32_t max_count);
 
 // render.hip
 void launch_render_fwd(hipStream_t s, bool geo, int tiles, const uint2* ranges, const uint32_t* point_list, int W,
