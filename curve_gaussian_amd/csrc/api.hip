@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -52,6 +53,8 @@ bool check_launch(const char* what, bool debug, hipStream_t s) {
     }
     return true;
 }
+
+static std::atomic<int64_t> g_R_hint{0};  // num_rendered of the previous forward (speculative binning capacity)
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -181,24 +184,71 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
     launch_scan_tiles(s, tiles, img.tile_count, img.ranges, img.total);
     if (!check_launch("scan_tiles", debug, s)) return CGS_ERR_HIP;
 
-    uint32_t host_tot[2] = {0, 0};  // {R, longest tile list}
-    hipError_t e = hipMemcpyAsync(host_tot, img.total, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    // num_rendered has to reach the host (it sizes the binning buffer and is part of the reference's API).  Instead of
+    // idling the GPU during that round trip (the reference blocks on a 4-byte cudaMemcpy, rasterizer_impl.cu:287), the
+    // binning kernels are launched SPECULATIVELY into a buffer sized from the previous call's R (+25 %) while an event
+    // marks the readback; the host then waits on the event only.  If the guess was too small (scene changed a lot)
+    // the kernels skipped every tile that would not fit and are re-run on an exact-size buffer.
+    static thread_local uint32_t* h_tot = nullptr;  // pinned {R, longest tile list}
+    static thread_local hipEvent_t ev = nullptr;
+    if (!h_tot) {
+        if (hipHostMalloc((void**)&h_tot, 2 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+            set_error("pinned readback buffer / event creation failed");
+            h_tot = nullptr;
+            return CGS_ERR_HIP;
+        }
+    }
+    hipError_t e = hipMemcpyAsync(h_tot, img.total, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipEventRecord(ev, s);
     if (e != hipSuccess) {
         set_error("reading num_rendered failed: %s", hipGetErrorString(e));
         return CGS_ERR_HIP;
     }
-    const int64_t R = (int64_t)host_tot[0];
-    char* bchunk = (char*)binning_alloc(binning_user, cgs_binning_bytes(R));
-    if (!bchunk) {
-        set_error("cgs_rasterize_forward: binning allocation callback returned NULL");
-        return CGS_ERR_ALLOC;
+    const int64_t hint = g_R_hint.load(std::memory_order_relaxed);
+    int64_t cap = 0;
+    char* bchunk = nullptr;
+    BinState bin{};
+    if (hint > 0 && !debug) {
+        cap = hint + hint / 4 + 4096;
+        bchunk = (char*)binning_alloc(binning_user, cgs_binning_bytes(cap));
+        if (!bchunk) {
+            set_error("cgs_rasterize_forward: binning allocation callback returned NULL");
+            return CGS_ERR_ALLOC;
+        }
+        bin = bin_from_chunk(bchunk, (size_t)cap);
+        launch_scatter(s, P, radii, geom.rec, gx, gy, img.ranges, img.tile_cursor, bin.keys, (uint32_t)cap);
+        launch_tile_sort_small(s, tiles, img.ranges, bin.keys, bin.point_list, (uint32_t)cap);
     }
-    BinState bin = bin_from_chunk(bchunk, (size_t)(R > 0 ? R : 1));
+    e = hipEventSynchronize(ev);
+    if (e != hipSuccess) {
+        set_error("reading num_rendered failed: %s", hipGetErrorString(e));
+        return CGS_ERR_HIP;
+    }
+    const int64_t R = (int64_t)h_tot[0];
+    const uint32_t max_count = h_tot[1];
+    g_R_hint.store(R, std::memory_order_relaxed);
+    if (!bchunk || R > cap) {  // first call, debug mode, or the speculative buffer was too small: exact-size (re)run
+        if (cap > 0 && hipMemsetAsync(img.tile_cursor, 0, (size_t)tiles * sizeof(uint32_t), s) != hipSuccess) {
+            set_error("hipMemsetAsync(tile cursors) failed");
+            return CGS_ERR_HIP;
+        }
+        cap = R;
+        bchunk = (char*)binning_alloc(binning_user, cgs_binning_bytes(R));
+        if (!bchunk) {
+            set_error("cgs_rasterize_forward: binning allocation callback returned NULL");
+            return CGS_ERR_ALLOC;
+        }
+        bin = bin_from_chunk(bchunk, (size_t)(R > 0 ? R : 1));
+        if (R > 0) {
+            launch_scatter(s, P, radii, geom.rec, gx, gy, img.ranges, img.tile_cursor, bin.keys, (uint32_t)cap);
+            if (!check_launch("scatter", debug, s)) return CGS_ERR_HIP;
+            launch_tile_sort_small(s, tiles, img.ranges, bin.keys, bin.point_list, (uint32_t)cap);
+            if (!check_launch("tile_sort", debug, s)) return CGS_ERR_HIP;
+        }
+    }
     if (R > 0) {
-        launch_scatter(s, P, radii, geom.rec, gx, gy, img.ranges, img.tile_cursor, bin.keys);
-        if (!check_launch("scatter", debug, s)) return CGS_ERR_HIP;
-        launch_tile_sort(s, tiles, img.ranges, bin.keys, bin.point_list, host_tot[1]);
+        launch_tile_sort_big(s, tiles, img.ranges, bin.keys, bin.point_list, max_count);  // no-op unless a list > 1024
         if (!check_launch("tile_sort", debug, s)) return CGS_ERR_HIP;
     }
     launch_render_fwd(s, render_geo != 0, tiles, img.ranges, bin.point_list, width, height, gx, geom.rec, img.final_T,

@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(int tiles, const uint32_t* 
 __global__ void __launch_bounds__(256) k_scatter(int P, const int* __restrict__ radii,
                                                  const SplatRec* __restrict__ rec, int grid_x, int grid_y,
                                                  const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_cursor,
-                                                 uint64_t* __restrict__ keys) {
+                                                 uint64_t* __restrict__ keys, uint32_t cap) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int radius = idx < P ? radii[idx] : 0;
     uint2 rmin = make_uint2(0, 0), rmax = make_uint2(0, 0);
@@ -75,8 +75,10 @@ __global__ void __launch_bounds__(256) k_scatter(int P, const int* __restrict__ 
     }
     for_each_rect_tile_coop(radius > 0, rmin, rmax, grid_x, [&](int src, uint32_t tile) {
         const uint64_t key = ((uint64_t)__builtin_amdgcn_readlane(key_hi, src) << 32) | __builtin_amdgcn_readlane(key_lo, src);
+        const uint2 rg = ranges[tile];
+        if (rg.y > cap) return;  // speculative buffer too small for this tile: the host re-runs with the exact size
         const uint32_t slot = atomicAdd(&tile_cursor[tile], 1u);
-        keys[ranges[tile].x + slot] = key;
+        keys[rg.x + slot] = key;
     });
 }
 
@@ -118,11 +120,11 @@ __device__ __forceinline__ void bitonic_any_n(Ptr k, uint32_t n, uint32_t n2, ui
 constexpr uint32_t RANK_MAX = 1024;
 __global__ void __launch_bounds__(256) k_tile_rank_sort(const uint2* __restrict__ ranges,
                                                         const uint64_t* __restrict__ keys,
-                                                        uint32_t* __restrict__ point_list) {
+                                                        uint32_t* __restrict__ point_list, uint32_t cap) {
     __shared__ uint64_t sk[RANK_MAX];
     const uint2 rg = ranges[blockIdx.x];
     const uint32_t n = rg.y - rg.x;
-    if (n == 0 || n > RANK_MAX) return;
+    if (n == 0 || n > RANK_MAX || rg.y > cap) return;
     const uint32_t tid = threadIdx.x;
     const uint64_t* gk = keys + rg.x;
     uint32_t* out = point_list + rg.x;
@@ -192,21 +194,21 @@ void launch_scan_tiles(hipStream_t s, int tiles, const uint32_t* tile_count, uin
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tiles, tile_count, ranges, total);
 }
 void launch_scatter(hipStream_t s, int P, const int* radii, const SplatRec* rec, int grid_x, int grid_y,
-                    const uint2* ranges, uint32_t* tile_cursor, uint64_t* keys) {
+                    const uint2* ranges, uint32_t* tile_cursor, uint64_t* keys, uint32_t cap) {
     ProfScope p("scatter", s);
     hipLaunchKernelGGL(k_scatter, dim3((P + 255) / 256), dim3(256), 0, s, P, radii, rec, grid_x, grid_y, ranges,
-                       tile_cursor, keys);
+                       tile_cursor, keys, cap);
 }
-void launch_tile_sort(hipStream_t s, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* point_list,
-                      uint32_t max_count) {
-    {
-        ProfScope p("tile_sort", s);
-        hipLaunchKernelGGL(k_tile_rank_sort, dim3(tiles), dim3(256), 0, s, ranges, keys, point_list);
-    }
-    if (max_count > RANK_MAX) {  // rare: some tile list is longer than 1024 -> bitonic network (LDS or global memory)
-        ProfScope p("tile_sort_big", s);
-        hipLaunchKernelGGL(k_tile_sort, dim3(tiles), dim3(256), 0, s, ranges, keys, point_list, RANK_MAX);
-    }
+void launch_tile_sort_small(hipStream_t s, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* point_list,
+                            uint32_t cap) {
+    ProfScope p("tile_sort", s);
+    hipLaunchKernelGGL(k_tile_rank_sort, dim3(tiles), dim3(256), 0, s, ranges, keys, point_list, cap);
+}
+void launch_tile_sort_big(hipStream_t s, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* point_list,
+                          uint32_t max_count) {
+    if (max_count <= RANK_MAX) return;  // rare: some tile list is longer than 1024 -> bitonic network (LDS or global)
+    ProfScope p("tile_sort_big", s);
+    hipLaunchKernelGGL(k_tile_sort, dim3(tiles), dim3(256), 0, s, ranges, keys, point_list, RANK_MAX);
 }
 
 }  // namespace cgs

@@ -72,8 +72,8 @@ static inline ImageState image_from_chunk(char*& chunk, size_t npix, size_t tile
 }
 static inline BinState bin_from_chunk(char*& chunk, size_t R) {
     BinState b;
-    carve(chunk, b.keys, R);
-    carve(chunk, b.point_list, R);
+    carve(chunk, b.point_list, R);  // first: its address must not depend on the capacity the buffer was sized for
+    carve(chunk, b.keys, R);        // (the backward only knows R, the forward may have allocated R + slack)
     return b;
 }
 

@@ -25,10 +25,13 @@ void launch_preprocess_bwd(hipStream_t s, int P, int D, int M, const float* mean
 
 // binning.hip
 void launch_scan_tiles(hipStream_t s, int tiles, const uint32_t* tile_count, uint2* ranges, uint32_t* total);
+// `cap` = number of instances the binning buffer can hold: tiles whose range does not fit are skipped (speculative launch)
 void launch_scatter(hipStream_t s, int P, const int* radii, const SplatRec* rec, int grid_x, int grid_y,
-                    const uint2* ranges, uint32_t* tile_cursor, uint64_t* keys);
-void launch_tile_sort(hipStream_t s, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* point_list,
-                      uint32_t max_count);
+                    const uint2* ranges, uint32_t* tile_cursor, uint64_t* keys, uint32_t cap);
+void launch_tile_sort_small(hipStream_t s, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* point_list,
+                            uint32_t cap);
+void launch_tile_sort_big(hipStream_t s, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* point_list,
+                          uint32_t max_count);
 
 // render.hip
 void launch_render_fwd(hipStream_t s, bool geo, int tiles, const uint2* ranges, const uint32_t* point_list, int W,

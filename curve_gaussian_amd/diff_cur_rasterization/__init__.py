@@ -128,9 +128,8 @@ class _Ext:
             if not has_scales:
                 dL_dscales.zero_()
                 dL_drotations.zero_()
-            if not want_col:
-                dL_dcolors.zero_()
-            dL_dsh = torch.zeros((P, M, 3), **fopt)  # reference shape; only the first P*M floats are written (quirk 16)
+            # reference shape [P,M,3]; only the first P*M floats are written (quirk 16)
+            dL_dsh = torch.zeros((P, M, 3), **fopt) if M > 0 else torch.empty((P, 0, 3), **fopt)
             stream = torch.cuda.current_stream(dev).cuda_stream
             if P != 0:
                 rc = lib.cgs_rasterize_backward(
@@ -145,8 +144,9 @@ class _Ext:
                     L.ptr(dL_drotations) if has_scales else None, L.ptr(dL_dall_map), int(bool(antialiasing)),
                     int(bool(render_geo)), int(bool(debug)), stream)
                 L.check(rc, "cgs_rasterize_backward")
-        return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations,
-                dL_dall_map)
+        # need_color_grad=False (extension, training configuration): the colour gradient is not computed -> None
+        return (dL_dmeans2D, dL_dcolors if want_col else None, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
+                dL_drotations, dL_dall_map)
 
     @staticmethod
     def mark_visible(means3D, viewmatrix, projmatrix):

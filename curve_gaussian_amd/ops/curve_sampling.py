@@ -15,6 +15,24 @@ from .. import _lib as L
 
 _f = C.c_float
 _COEF_CACHE = {}
+_ALL_BEZIER_CACHE = {}
+
+
+def _bezier_mask(is_bezier, dev):
+    """u8 mask for the kernel, or None when every curve is a Bezier curve (the common case; the reference branches on
+    ``self.is_bezier.all()`` too, :74,84).  The device->host read behind ``.all()`` is cached per tensor version so the
+    per-step path stays free of host syncs."""
+    if is_bezier is None:
+        return None
+    key = (is_bezier.data_ptr(), is_bezier._version, is_bezier.numel(), str(is_bezier.device))
+    hit = _ALL_BEZIER_CACHE.get(key)
+    if hit is None:
+        if len(_ALL_BEZIER_CACHE) > 64:
+            _ALL_BEZIER_CACHE.clear()
+        allb = bool(is_bezier.all())
+        hit = (allb, None if allb else is_bezier.to(device=dev, dtype=torch.uint8).contiguous())
+        _ALL_BEZIER_CACHE[key] = hit
+    return hit[1]
 
 
 def sample_coefficients(m: int, device) -> torch.Tensor:
@@ -50,9 +68,7 @@ class _SampleCurves(torch.autograd.Function):
             w = width.detach().float().contiguous()
             B = cp.shape[0]
             P = B * m
-            isb = None
-            if is_bezier is not None and not bool(is_bezier.all()):
-                isb = is_bezier.to(device=dev, dtype=torch.uint8).contiguous()
+            isb = _bezier_mask(is_bezier, dev)
             coef = sample_coefficients(m, dev)
             norms = torch.empty(4, dtype=torch.float64, device=dev)
             xyz = torch.empty((P, 3), dtype=torch.float32, device=dev)
@@ -77,7 +93,7 @@ class _SampleCurves(torch.autograd.Function):
             g_xyz, g_rot, g_scl = c(g_xyz), c(g_rot), c(g_scl)
             g_cp = torch.empty_like(cp)
             g_w = torch.empty_like(w)
-            norms = norms.clone()  # [2],[3] are backward scratch; keep the saved forward sums intact for re-entry
+            # norms[2],[3] are backward scratch (re-zeroed by every call); [0],[1] (forward sums) are only read
             rc = lib.cgs_sample_curves_backward(B, ctx.m, L.ptr(cp), L.ptr(w), L.ptr(isb), L.ptr(coef), _f(ctx.eps),
                                                 L.ptr(norms), L.ptr(g_xyz), L.ptr(g_rot), L.ptr(g_scl), L.ptr(g_cp),
                                                 L.ptr(g_w), _stream(dev))

@@ -180,8 +180,8 @@ def _decode_state(geomBuffer, binningBuffer, imgBuffer, P, H, W, R):
     n_contrib = ib[o[1]:o[1] + H * W * 4].view(np.uint32)
     final_T = ib[o[0]:o[0] + H * W * 4].view(np.float32)
     bb = binningBuffer.cpu().numpy()
-    ob = carve_offsets(binningBuffer.data_ptr(), [(max(R, 1), 8), (max(R, 1), 4)])
-    point_list = bb[ob[1]:ob[1] + R * 4].view(np.uint32)
+    ob = carve_offsets(binningBuffer.data_ptr(), [(max(R, 1), 4)])  # point_list is carved first (csrc/common.h)
+    point_list = bb[ob[0]:ob[0] + R * 4].view(np.uint32)
     return ranges, point_list, n_contrib, final_T
 
 
