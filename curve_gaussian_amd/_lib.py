@@ -36,7 +36,7 @@ SIGNATURES = {
     "cgs_knn_workspace_bytes": (C.c_size_t, [_i]),
     "cgs_knn_mean_dist2": (_i, [_i, _vp, _vp, _vp, _vp]),
     "cgs_sample_curves_forward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
-    "cgs_sample_curves_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cgs_sample_curves_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cgs_splat_attrs_forward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cgs_splat_attrs_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _vp, _vp]),

@@ -337,7 +337,7 @@ int cgs_sample_curves_forward(int B, int m, const float* curve_points, const flo
                               float* scaling, void* stream_) {
     hipStream_t s = (hipStream_t)stream_;
     if (B == 0) return CGS_OK;
-    if (B < 0 || m <= 0 || m > 256 || !curve_points || !width || !coef || !norms || !xyz || !rotation || !scaling ||
+    if (B < 0 || m <= 0 || m > 32 || !curve_points || !width || !coef || !norms || !xyz || !rotation || !scaling ||
         !aligned16(curve_points) || !aligned16(rotation) || !aligned16(coef)) {
         set_error("cgs_sample_curves_forward: invalid argument (NULL or misaligned pointer, B=%d m=%d)", B, m);
         return CGS_ERR_INVALID_ARGUMENT;
@@ -354,10 +354,11 @@ int cgs_sample_curves_forward(int B, int m, const float* curve_points, const flo
 int cgs_sample_curves_backward(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier,
                                const float* coef, float eps, double* norms, const float* dL_dxyz,
                                const float* dL_drotation, const float* dL_dscaling, float* dL_dcurve_points,
-                               float* dL_dwidth, void* stream_) {
+                               float* dL_dwidth, float* scratch, void* stream_) {
     hipStream_t s = (hipStream_t)stream_;
     if (B == 0) return CGS_OK;
-    if (B < 0 || m <= 0 || !curve_points || !width || !coef || !norms || !dL_dcurve_points || !dL_dwidth ||
+    if (B < 0 || m <= 0 || m > 32 || !curve_points || !width || !coef || !norms || !dL_dcurve_points || !dL_dwidth ||
+        (dL_drotation && !scratch) ||
         !aligned16(curve_points) || !aligned16(dL_drotation) || !aligned16(dL_dcurve_points) || !aligned16(coef)) {
         set_error("cgs_sample_curves_backward: invalid argument");
         return CGS_ERR_INVALID_ARGUMENT;
@@ -367,7 +368,7 @@ int cgs_sample_curves_backward(int B, int m, const float* curve_points, const fl
         return CGS_ERR_HIP;
     }
     launch_sample_backward(s, B, m, curve_points, width, is_bezier, coef, eps, norms, dL_dxyz, dL_drotation, dL_dscaling,
-                           dL_dcurve_points, dL_dwidth);
+                           dL_dcurve_points, dL_dwidth, scratch);
     if (!check_launch("sample_curves_backward", false, s)) return CGS_ERR_HIP;
     return CGS_OK;
 }

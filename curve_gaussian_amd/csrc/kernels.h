@@ -48,7 +48,7 @@ void launch_sample_forward(hipStream_t s, int B, int m, const float* cp, const f
                            const void* coef, float eps, double* norms, float* xyz, float* rot, float* scaling);
 void launch_sample_backward(hipStream_t s, int B, int m, const float* cp, const float* width, const uint8_t* is_bezier,
                             const void* coef, float eps, double* norms, const float* g_xyz, const float* g_rot,
-                            const float* g_scaling, float* g_cp, float* g_width);
+                            const float* g_scaling, float* g_cp, float* g_width, float* gv_cache);
 void launch_attrs_forward(hipStream_t s, int B, int m, const float* rot_raw, const float* xyz, const float* opacity_logit,
                           const float* mask_logit, float mask_thr, const float* scaling, const float* campos,
                           const float* vm, float* rot_n, float* opac, float* scl_out, float* all_map);

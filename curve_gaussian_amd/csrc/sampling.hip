@@ -51,6 +51,26 @@ __device__ __forceinline__ V3 curve_tangent(const CurveCP& c, const SampleCoef& 
     return k.d[0] * (c.p1 - c.p0) + k.d[1] * (c.p2 - c.p1) + k.d[2] * (c.p3 - c.p2);
 }
 
+// Per-block constants staged once in LDS: the m x 16 coefficient table and the global norms as f32 (the f64 sqrt
+// per thread dominated the small kernels).
+struct BlockConst {
+    float N1, N2, D2, D1;
+};
+__device__ __forceinline__ void stage_consts(const SampleCoef* __restrict__ coef, int m, const double* __restrict__ norms,
+                                             SampleCoef* s_coef, BlockConst* s_bc) {
+    const float* src = reinterpret_cast<const float*>(coef);
+    float* dst = reinterpret_cast<float*>(s_coef);
+    for (int t = threadIdx.x; t < m * 16; t += blockDim.x) dst[t] = src[t];
+    if (threadIdx.x == 0) {
+        s_bc->N1 = (float)sqrt(norms[0]);
+        s_bc->N2 = (float)sqrt(norms[1]);
+        s_bc->D2 = (float)norms[2];
+        s_bc->D1 = (float)norms[3];
+    }
+    __syncthreads();
+}
+constexpr int MAX_M = 32;  // samples per curve supported by the LDS table (reference default 12)
+
 // block-wide sum -> one f64 atomic
 __device__ __forceinline__ void block_accumulate(double v, double* target) {
     __shared__ double s_part[4];
@@ -70,11 +90,14 @@ __device__ __forceinline__ void block_accumulate(double v, double* target) {
 __global__ void __launch_bounds__(256) k_sample_f1(int B, int m, const float* __restrict__ cp,
                                                    const uint8_t* __restrict__ is_bezier,
                                                    const SampleCoef* __restrict__ coef, double* __restrict__ norms) {
+    __shared__ SampleCoef s_coef[MAX_M];
+    __shared__ BlockConst s_bc;
+    stage_consts(coef, m, norms, s_coef, &s_bc);
     double acc = 0;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < B * m; p += gridDim.x * blockDim.x) {
         const int b = p / m, i = p - b * m;
         const CurveCP c = load_curve(cp, is_bezier, b);
-        const V3 t = curve_tangent(c, coef[i]);
+        const V3 t = curve_tangent(c, s_coef[i]);
         acc += (double)(t.y * t.y) + (double)(t.x * t.x);  // |cross(tan,(0,0,1))|^2 = ty^2 + tx^2
     }
     block_accumulate(acc, &norms[0]);  // <= REDUCE_BLOCKS same-address f64 atomics
@@ -82,12 +105,15 @@ __global__ void __launch_bounds__(256) k_sample_f1(int B, int m, const float* __
 __global__ void __launch_bounds__(256) k_sample_f2(int B, int m, const float* __restrict__ cp,
                                                    const uint8_t* __restrict__ is_bezier,
                                                    const SampleCoef* __restrict__ coef, double* __restrict__ norms) {
-    const float N1 = (float)sqrt(norms[0]);
+    __shared__ SampleCoef s_coef[MAX_M];
+    __shared__ BlockConst s_bc;
+    stage_consts(coef, m, norms, s_coef, &s_bc);
+    const float N1 = s_bc.N1;
     double acc = 0;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < B * m; p += gridDim.x * blockDim.x) {
         const int b = p / m, i = p - b * m;
         const CurveCP c = load_curve(cp, is_bezier, b);
-        const V3 t = curve_tangent(c, coef[i]);
+        const V3 t = curve_tangent(c, s_coef[i]);
         const V3 v1 = {t.y / N1, -t.x / N1, 0.f / N1};
         const V3 c2 = cross(t, v1);
         acc += (double)(c2.x * c2.x) + (double)(c2.y * c2.y) + (double)(c2.z * c2.z);
@@ -193,13 +219,16 @@ __global__ void __launch_bounds__(256) k_sample_f3(int B, int m, const float* __
                                                    const SampleCoef* __restrict__ coef, float eps,
                                                    const double* __restrict__ norms, float* __restrict__ xyz,
                                                    float* __restrict__ rot, float* __restrict__ scaling) {
+    __shared__ SampleCoef s_coef[MAX_M];
+    __shared__ BlockConst s_bc;
+    stage_consts(coef, m, norms, s_coef, &s_bc);
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= B * m) return;
     const int b = p / m, i = p - b * m;
-    const float N1 = (float)sqrt(norms[0]), N2 = (float)sqrt(norms[1]);
+    const float N1 = s_bc.N1, N2 = s_bc.N2;
     const CurveCP c = load_curve(cp, is_bezier, b);
     const float w = expf(width[b]);
-    const SampleFwd s = sample_forward(c, coef[i], N1, N2, eps);
+    const SampleFwd s = sample_forward(c, s_coef[i], N1, N2, eps);
     float M[3][3], q[4];
     rot_matrix(s, M);
     quat_forward(M, q);
@@ -223,10 +252,14 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_sample_bwd(int B, int m, int c
                                                              const float* __restrict__ g_xyz,
                                                              const float* __restrict__ g_rot,
                                                              const float* __restrict__ g_scaling,
-                                                             float* __restrict__ g_cp, float* __restrict__ g_width) {
+                                                             float* __restrict__ g_cp, float* __restrict__ g_width,
+                                                             float* __restrict__ gv_cache) {
     __shared__ float s_part[PASS == 3 ? 13 : 1][SAMPLE_BLOCK + 1];
-    const float N1 = (float)sqrt(norms[0]), N2 = (float)sqrt(norms[1]);
-    const float D2 = PASS >= 2 ? (float)norms[2] : 0.f, D1 = PASS >= 3 ? (float)norms[3] : 0.f;
+    __shared__ SampleCoef s_coef[MAX_M];
+    __shared__ BlockConst s_bc;
+    stage_consts(coef, m, norms, s_coef, &s_bc);
+    const float N1 = s_bc.N1, N2 = s_bc.N2;
+    const float D2 = PASS >= 2 ? s_bc.D2 : 0.f, D1 = PASS >= 3 ? s_bc.D1 : 0.f;
     double acc = 0;
     V3 gp0 = {0, 0, 0}, gp1 = {0, 0, 0}, gp2 = {0, 0, 0}, gp3 = {0, 0, 0};
     float gw = 0.f;
@@ -247,11 +280,14 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_sample_bwd(int B, int m, int c
     while (valid) {
         const CurveCP c = load_curve(cp, is_bezier, b);
         const float w = expf(width[b]);
-        const SampleCoef k = coef[i];
+        const SampleCoef k = s_coef[i];
         const size_t p = (size_t)b * m + i;
         const SampleFwd s = sample_forward(c, k, N1, N2, eps);
         V3 g_v0 = {0, 0, 0}, g_v1 = {0, 0, 0}, g_v2 = {0, 0, 0};
-        if (g_rot) {
+        if (PASS > 1 && g_rot) {  // pass 1 cached dL/d{v0,v1,v2} (the quaternion backward) for passes 2 and 3
+            const float* gv = gv_cache + 9 * p;
+            g_v0 = {gv[0], gv[1], gv[2]}; g_v1 = {gv[3], gv[4], gv[5]}; g_v2 = {gv[6], gv[7], gv[8]};
+        } else if (g_rot) {
             float M[3][3], q[4], gM[3][3];
             rot_matrix(s, M);
             const QuatFwd f = quat_forward(M, q);
@@ -261,6 +297,9 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_sample_bwd(int B, int m, int c
             g_v0 = {gM[0][0], gM[1][0], gM[2][0]};
             g_v1 = {gM[0][1], gM[1][1], gM[2][1]};
             g_v2 = {gM[0][2], gM[1][2], gM[2][2]};
+            float* gv = gv_cache + 9 * p;
+            gv[0] = g_v0.x; gv[1] = g_v0.y; gv[2] = g_v0.z; gv[3] = g_v1.x; gv[4] = g_v1.y; gv[5] = g_v1.z;
+            gv[6] = g_v2.x; gv[7] = g_v2.y; gv[8] = g_v2.z;
         }
         if (PASS == 1) {
             acc += (double)dot(g_v2, s.c2v);
@@ -475,14 +514,14 @@ void launch_sample_forward(hipStream_t s, int B, int m, const float* cp, const f
 }
 void launch_sample_backward(hipStream_t s, int B, int m, const float* cp, const float* width, const uint8_t* is_bezier,
                             const void* coef, float eps, double* norms, const float* g_xyz, const float* g_rot,
-                            const float* g_scaling, float* g_cp, float* g_width) {
+                            const float* g_scaling, float* g_cp, float* g_width, float* gv_cache) {
     const int cpb = SAMPLE_BLOCK / m;  // whole curves per block
     const dim3 grid((B + cpb - 1) / cpb), block(SAMPLE_BLOCK);
     const SampleCoef* k = reinterpret_cast<const SampleCoef*>(coef);
     const dim3 rgrid(std::min((B * m + SAMPLE_BLOCK - 1) / SAMPLE_BLOCK, REDUCE_BLOCKS));
-    { ProfScope p("sample_b1", s); hipLaunchKernelGGL(k_sample_bwd<1>, rgrid, block, 0, s, B, m, cpb, cp, width, is_bezier, k, eps, norms, g_xyz, g_rot, g_scaling, g_cp, g_width); }
-    { ProfScope p("sample_b2", s); hipLaunchKernelGGL(k_sample_bwd<2>, rgrid, block, 0, s, B, m, cpb, cp, width, is_bezier, k, eps, norms, g_xyz, g_rot, g_scaling, g_cp, g_width); }
-    { ProfScope p("sample_b3", s); hipLaunchKernelGGL(k_sample_bwd<3>, grid, block, 0, s, B, m, cpb, cp, width, is_bezier, k, eps, norms, g_xyz, g_rot, g_scaling, g_cp, g_width); }
+    { ProfScope p("sample_b1", s); hipLaunchKernelGGL(k_sample_bwd<1>, rgrid, block, 0, s, B, m, cpb, cp, width, is_bezier, k, eps, norms, g_xyz, g_rot, g_scaling, g_cp, g_width, gv_cache); }
+    { ProfScope p("sample_b2", s); hipLaunchKernelGGL(k_sample_bwd<2>, rgrid, block, 0, s, B, m, cpb, cp, width, is_bezier, k, eps, norms, g_xyz, g_rot, g_scaling, g_cp, g_width, gv_cache); }
+    { ProfScope p("sample_b3", s); hipLaunchKernelGGL(k_sample_bwd<3>, grid, block, 0, s, B, m, cpb, cp, width, is_bezier, k, eps, norms, g_xyz, g_rot, g_scaling, g_cp, g_width, gv_cache); }
 }
 void launch_attrs_forward(hipStream_t s, int B, int m, const float* rot_raw, const float* xyz, const float* opacity_logit,
                           const float* mask_logit, float mask_thr, const float* scaling, const float* campos,

@@ -94,9 +94,10 @@ class _SampleCurves(torch.autograd.Function):
             g_cp = torch.empty_like(cp)
             g_w = torch.empty_like(w)
             # norms[2],[3] are backward scratch (re-zeroed by every call); [0],[1] (forward sums) are only read
+            scratch = torch.empty((B * ctx.m, 9), dtype=torch.float32, device=dev) if g_rot is not None else None
             rc = lib.cgs_sample_curves_backward(B, ctx.m, L.ptr(cp), L.ptr(w), L.ptr(isb), L.ptr(coef), _f(ctx.eps),
                                                 L.ptr(norms), L.ptr(g_xyz), L.ptr(g_rot), L.ptr(g_scl), L.ptr(g_cp),
-                                                L.ptr(g_w), _stream(dev))
+                                                L.ptr(g_w), L.ptr(scratch), _stream(dev))
             L.check(rc, "cgs_sample_curves_backward")
         return g_cp, g_w, None, None, None
 

@@ -134,7 +134,7 @@ size_t cgs_binning_bytes(int64_t R);
  *   norms [4] f64 scratch: [0],[1] = global sums of |v1|^2,|v2|^2 written by the forward and needed by the
  *     backward; [2],[3] are backward scratch.
  *   outputs xyz [P,3], rotation [P,4] (w,x,y,z, un-normalised), scaling [P,3].
- * The backward accepts NULL for any upstream gradient (treated as zero).
+ * The backward accepts NULL for any upstream gradient (treated as zero).  m <= 32.
  * ------------------------------------------------------------------------------------------------ */
 int cgs_sample_curves_forward(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier,
                               const float* coef, float eps, double* norms, float* xyz, float* rotation,
@@ -142,7 +142,8 @@ int cgs_sample_curves_forward(int B, int m, const float* curve_points, const flo
 int cgs_sample_curves_backward(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier,
                                const float* coef, float eps, double* norms, const float* dL_dxyz,
                                const float* dL_drotation, const float* dL_dscaling, float* dL_dcurve_points,
-                               float* dL_dwidth, void* stream);
+                               float* dL_dwidth, float* scratch /* [P,9] f32, required when dL_drotation != NULL */,
+                               void* stream);
 
 /* Per-view splat attributes fed to the rasterizer (one fused kernel each way instead of ~40 PyTorch kernels):
  *   rotation_n = F.normalize(rotation_raw)                      gaussian_curve_model.py:121-122
