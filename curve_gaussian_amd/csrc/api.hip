@@ -1,4 +1,5 @@
 // C ABI of libcurvegs.so (see include/curvegs.h): host-side sequencing of the HIP kernels on the caller's stream.
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -456,6 +457,22 @@ int cgs_edge_aware_loss(int channels, int height, int width, const float* image,
     }
     launch_edge_aware_loss(s, channels, height, width, image, gt, threshold, scratch16, dL_dimage);
     if (!check_launch("edge_aware_loss", false, s)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
+
+int cgs_adam_step_flat(int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                       const void* segments, int n_segments, float beta1, float beta2, float eps, int step,
+                       void* stream_) {
+    if (n == 0) return CGS_OK;
+    if (n < 0 || !params || !grads || !exp_avg || !exp_avg_sq || !segments || n_segments <= 0 || step <= 0) {
+        set_error("cgs_adam_step_flat: invalid argument");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    launch_adam_flat((hipStream_t)stream_, (long long)n, params, grads, exp_avg, exp_avg_sq, segments, n_segments, beta1,
+                     beta2, eps, (float)bc1, (float)sqrt(bc2));
+    if (!check_launch("adam_step_flat", false, (hipStream_t)stream_)) return CGS_ERR_HIP;
     return CGS_OK;
 }
 

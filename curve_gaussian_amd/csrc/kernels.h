@@ -68,6 +68,8 @@ void launch_ssim_bwd(hipStream_t s, int planes, int H, int W, const float* img1,
 // loss.hip  (scratch16: 16 zeroed bytes = {u32 n_pos, pad, f64 loss_sum})
 void launch_edge_aware_loss(hipStream_t s, int C, int H, int W, const float* image, const float* gt, float thr,
                             void* scratch16, float* grad);
+void launch_adam_flat(hipStream_t s, long long n, float* p, const float* g, float* m, float* v, const void* segs, int nseg,
+                      float b1, float b2, float eps, float bc1, float sqrt_bc2);
 // knn.hip
 size_t knn_workspace_bytes(int P);
 void launch_knn(hipStream_t s, int P, const float* pts, float* dists, void* workspace);

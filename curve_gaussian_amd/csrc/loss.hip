@@ -24,10 +24,16 @@ __global__ void __launch_bounds__(256) k_edge_count(int C, int HW, const float* 
         e = e / (float)C;
         cnt += e > thr ? 1u : 0u;
     }
+    __shared__ unsigned int s_cnt[4];
     unsigned int w = cnt;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) w += __shfl_xor(w, off, 64);
-    if ((threadIdx.x & 63) == 0 && w) atomicAdd(n_pos, w);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int t = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (t) atomicAdd(n_pos, t);
+    }
 }
 
 __global__ void __launch_bounds__(256) k_edge_loss(int C, int HW, const float* __restrict__ image,
@@ -62,9 +68,39 @@ void launch_edge_aware_loss(hipStream_t s, int C, int H, int W, const float* ima
     const int HW = H * W;
     unsigned int* n_pos = reinterpret_cast<unsigned int*>(scratch16);
     double* loss_sum = reinterpret_cast<double*>(reinterpret_cast<char*>(scratch16) + 8);
-    const int blocks = std::min((HW + 255) / 256, 512);
+    const int blocks = std::min((HW + 255) / 256, 256);  // one workgroup per CU: <= 256 same-address atomics
     { ProfScope p("edge_count", s); hipLaunchKernelGGL(k_edge_count, dim3(blocks), dim3(256), 0, s, C, HW, gt, thr, n_pos); }
     { ProfScope p("edge_loss", s); hipLaunchKernelGGL(k_edge_loss, dim3(blocks), dim3(256), 0, s, C, HW, image, gt, thr, n_pos, loss_sum, grad); }
+}
+
+// ------------------------------------------------------------------------------------------------ flat Adam
+// torch.optim.Adam (default, non-amsgrad, no weight decay) over ONE flat parameter buffer with per-segment learning
+// rates -- the reference steps 6 parameter groups with ~8 foreach kernels each (GaussianCurveModel.training_setup,
+// scene/gaussian_curve_model.py:200-213; train.py:235); here it is one launch.
+//   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+struct AdamSeg { long long begin; float lr; float pad; };
+__global__ void __launch_bounds__(256) k_adam_flat(long long n, float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   const AdamSeg* __restrict__ segs, int nseg, float b1, float b2,
+                                                   float eps, float bc1, float sqrt_bc2) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float lr = segs[0].lr;
+        for (int s = 1; s < nseg; s++) lr = i >= segs[s].begin ? segs[s].lr : lr;
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * (1.f - b1);          // torch: exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;          // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+        p[i] = p[i] - (lr / bc1) * (mi / denom);
+    }
+}
+void launch_adam_flat(hipStream_t s, long long n, float* p, const float* g, float* m, float* v, const void* segs, int nseg,
+                      float b1, float b2, float eps, float bc1, float sqrt_bc2) {
+    ProfScope pr("adam_flat", s);
+    const int blocks = (int)std::min<long long>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_adam_flat, dim3(blocks), dim3(256), 0, s, n, p, g, m, v, reinterpret_cast<const AdamSeg*>(segs),
+                       nseg, b1, b2, eps, bc1, sqrt_bc2);
 }
 
 }  // namespace cgs

@@ -17,7 +17,7 @@ class PipelineParams:
 
 
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_sh=False, override_color=None,
-           use_trained_exp=False, use_mask=False, mask_thr=0.01):
+           use_trained_exp=False, use_mask=False, mask_thr=0.01, compute_visibility=True):
     """Render the scene.  Background tensor (bg_color) must be on the GPU.  Returns the reference's dict
     {render, viewspace_points, visibility_filter, radii, depth, rend_dir, rend_alpha} (:147-155)."""
     dev = pc.get_xyz.device
@@ -50,7 +50,14 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_
     rendered_image = rendered_image.clamp(0, 1)
     rendered_alpha = out_all_map[3:4, ]
     rendered_dir = out_all_map[0:3]
-    rendered_dir = (rendered_dir.permute(1, 2, 0) @ (viewpoint_camera.world_view_transform[:3, :3].T)).permute(2, 0, 1)
+    # view space -> world space (:143-145).  The reference does this with a [H*W,3] x [3,3] matmul; the same
+    # contraction as three broadcast FMAs avoids a 150 us GEMM launch on a 1600^2 image.
+    wv = viewpoint_camera.world_view_transform[:3, :3]
+    rendered_dir = (rendered_dir[0:1] * wv[:, 0].view(3, 1, 1) + rendered_dir[1:2] * wv[:, 1].view(3, 1, 1) +
+                    rendered_dir[2:3] * wv[:, 2].view(3, 1, 1))
+    # compute_visibility=False (extension) skips the nonzero(), which is a host sync (train.py only needs it for the
+    # densification statistics and the opacity regulariser)
     return {"render": rendered_image, "viewspace_points": screenspace_points,
-            "visibility_filter": (radii > 0).nonzero(), "radii": radii, "depth": depth_image,
+            "visibility_filter": (radii > 0).nonzero() if compute_visibility else None, "radii": radii,
+            "depth": depth_image,
             "rend_dir": rendered_dir, "rend_alpha": rendered_alpha}

@@ -1,0 +1,60 @@
+"""One-launch Adam over flat parameter / gradient buffers (csrc/loss.hip::k_adam_flat).
+
+The reference builds ``torch.optim.Adam`` over six parameter groups (scene/gaussian_curve_model.py:200-213) and steps
+them with ~8 foreach kernels per group (train.py:235).  ``FlatAdam`` keeps every learnable tensor as a view of ONE flat
+buffer (the same layout as the flat gradient buffer of view_parallel.FlatGrads) and updates all of them, with per-group
+learning rates, in a single kernel.  Semantics = torch.optim.Adam(lr per group, betas=(0.9,0.999), eps) without weight
+decay / amsgrad."""
+import ctypes as C
+import struct
+
+import torch
+
+from .. import _lib as L
+
+
+class FlatAdam:
+    def __init__(self, named_params, lrs, flat_grads, betas=(0.9, 0.999), eps=1e-15):
+        """named_params: dict name -> nn.Parameter (insertion order = flat layout, must match flat_grads.names);
+        lrs: dict name -> lr; flat_grads: view_parallel.FlatGrads built over the same dict."""
+        self.names = list(named_params)
+        assert self.names == flat_grads.names
+        self.params = named_params
+        self.grads = flat_grads
+        any_p = next(iter(named_params.values()))
+        L.require_gpu_tensor(any_p, "parameters")
+        self.device = any_p.device
+        n = flat_grads.flat.numel()
+        self.flat = torch.empty(n, dtype=torch.float32, device=self.device)
+        for name, p in named_params.items():      # adopt: parameters become views of the flat buffer
+            a, b = flat_grads.slices[name]
+            self.flat[a:b].copy_(p.data.reshape(-1))
+            p.data = self.flat[a:b].view_as(p)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.betas, self.eps = betas, eps
+        self.step_count = 0
+        self.param_groups = [{"name": nm, "lr": float(lrs[nm]), "params": [named_params[nm]]} for nm in self.names]
+        self._seg_dev = torch.empty(len(self.names) * 16, dtype=torch.uint8, device=self.device)
+        self._seg_host = None
+        self._sync_segments()
+
+    def _sync_segments(self):
+        blob = b"".join(struct.pack("<qff", self.grads.slices[g["name"]][0], float(g["lr"]), 0.0) for g in self.param_groups)
+        if blob != self._seg_host:
+            self._seg_host = blob
+            self._seg_dev.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8), non_blocking=False)
+
+    def step(self):
+        self._sync_segments()   # learning rates may have been changed through param_groups (update_learning_rate)
+        self.step_count += 1
+        lib = L.load()
+        with torch.cuda.device(self.device):
+            rc = lib.cgs_adam_step_flat(self.flat.numel(), L.ptr(self.flat), L.ptr(self.grads.flat), L.ptr(self.exp_avg),
+                                        L.ptr(self.exp_avg_sq), L.ptr(self._seg_dev), len(self.param_groups),
+                                        C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
+                                        self.step_count, torch.cuda.current_stream(self.device).cuda_stream)
+        L.check(rc, "cgs_adam_step_flat")
+
+    def zero_grad(self, set_to_none=False):
+        self.grads.zero_()

@@ -182,6 +182,14 @@ int cgs_ssim_backward(int batch, int channels, int height, int width, float C1, 
 int cgs_edge_aware_loss(int channels, int height, int width, const float* image, const float* gt, float threshold,
                         void* scratch16, float* dL_dimage, void* stream);
 
+/* One-launch Adam over a flat parameter buffer (torch.optim.Adam semantics: no weight decay, no amsgrad), replacing
+ * the per-group foreach step of the reference (scene/gaussian_curve_model.py:200-213, train.py:235).
+ * segments: device array of n_segments x {int64 begin; float lr; float pad}, sorted by begin, segments[0].begin == 0;
+ * element i uses the lr of the last segment with begin <= i.  step = 1-based step count (bias correction). */
+int cgs_adam_step_flat(int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                       const void* segments, int n_segments, float beta1, float beta2, float eps, int step,
+                       void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * simple-knn.  Replaces distCUDA2 -> SimpleKNN::knn (/root/reference/submodules/simple-knn/spatial.cu:15-26,
  * simple_knn.cu:186-222): mean_dist2[i] = mean of the 3 smallest SQUARED distances from point i to other points.
