@@ -20,6 +20,9 @@ SIGNATURES = {
     "cgs_geometry_bytes": (C.c_size_t, [_i]),
     "cgs_image_bytes": (C.c_size_t, [_i, _i]),
     "cgs_binning_bytes": (C.c_size_t, [_i64]),
+    "cgs_set_tile_culling": (_i, [_i]),
+    "cgs_reset_binning_hints": (None, []),
+    "cgs_last_forward_stats": (None, [C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i)]),
     "cgs_prof_enable": (None, [_i]),
     "cgs_prof_reset": (None, []),
     "cgs_prof_collect": (_i, [C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_i64), _i]),

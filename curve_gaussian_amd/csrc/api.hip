@@ -55,7 +55,16 @@ bool check_launch(const char* what, bool debug, hipStream_t s) {
     return true;
 }
 
+static std::atomic<int> g_tile_cull{1};   // exact tile-level culling of (splat, tile) instances (cgs_set_tile_culling)
 static std::atomic<int64_t> g_R_hint{0};  // num_rendered of the previous forward (speculative binning capacity)
+// Longest tile list seen recently (decaying maximum): sizes the fixed-capacity buckets of the single-pass binning.
+static std::atomic<int64_t> g_max_hint{0};
+static void update_max_hint(uint32_t longest) {
+    const int64_t old = g_max_hint.load(std::memory_order_relaxed);
+    const int64_t decayed = old - old / 16;
+    g_max_hint.store(std::max<int64_t>((int64_t)longest, decayed), std::memory_order_relaxed);
+}
+static thread_local int64_t g_last_stats[3] = {0, 0, 0};  // num_rendered, longest tile list, binning path (0 exact, 1 bucket)
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -86,6 +95,13 @@ size_t cgs_binning_bytes(int64_t R) {
     return (size_t)c + 128;
 }
 
+void cgs_reset_binning_hints(void) {
+    g_R_hint.store(0, std::memory_order_relaxed);
+    g_max_hint.store(0, std::memory_order_relaxed);
+}
+int cgs_set_tile_culling(int on) {
+    return g_tile_cull.exchange(on ? 1 : 0, std::memory_order_relaxed);
+}
 void cgs_prof_enable(int on) { g_prof_on = on != 0; }
 void cgs_prof_reset(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -172,16 +188,93 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
     ImageState img = image_from_chunk(ichunk, npix, (size_t)tiles);
 
     // tile_count and tile_cursor are adjacent 128B-aligned carve-outs: clear both (+total) with one memset
-    const size_t clear_bytes = (size_t)((char*)(img.total + 4) - (char*)img.tile_count);
+    const size_t clear_bytes = (size_t)((char*)(img.total + TOTAL_WORDS) - (char*)img.tile_count);
+    const int cull = g_tile_cull.load(std::memory_order_relaxed);
+    static thread_local uint32_t* h_tot = nullptr;  // pinned copy of img.total
+    static thread_local hipEvent_t ev = nullptr;
+    if (!h_tot) {
+        if (hipHostMalloc((void**)&h_tot, TOTAL_WORDS * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+            set_error("pinned readback buffer / event creation failed");
+            h_tot = nullptr;
+            return CGS_ERR_HIP;
+        }
+    }
+    auto read_totals = [&]() -> bool {  // async copy of img.total + event; the caller waits on the event later
+        hipError_t e = hipMemcpyAsync(h_tot, img.total, TOTAL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipEventRecord(ev, s);
+        if (e != hipSuccess) set_error("reading num_rendered failed: %s", hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    auto wait_totals = [&]() -> bool {
+        const hipError_t e = hipEventSynchronize(ev);
+        if (e != hipSuccess) set_error("reading num_rendered failed: %s", hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    auto preprocess = [&](uint32_t* tile_count) -> bool {
+        launch_preprocess_fwd(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, geom.clamped,
+                              cov3D_precomp, colors_precomp, render_geo ? all_map : nullptr, viewmatrix, projmatrix,
+                              cam_pos, width, height, tan_fovx, tan_fovy, focal_x, focal_y, radii, geom.rec, geom.rgb,
+                              gx, gy, tile_count, antialiasing, cull);
+        return check_launch("preprocess_fwd", debug, s);
+    };
+    auto render = [&](const uint32_t* point_list) -> bool {
+        launch_render_fwd(s, render_geo != 0, tiles, img.ranges, point_list, width, height, gx, geom.rec, img.final_T,
+                          img.n_contrib, background, out_color, out_invdepth, out_all_map);
+        return check_launch("render_fwd", debug, s);
+    };
+
+    // ---- path B: single-pass bucket binning (default once a previous forward has told us how long tile lists get).
+    // Every tile owns a fixed-capacity bucket, so neither the per-tile count pass, nor the scan, nor num_rendered is
+    // needed before the compositor can be queued: the whole forward is enqueued back to back and the host only waits
+    // for the 16-byte readback (num_rendered is part of the reference's API) while the compositor is already running.
+    // A tile that outgrows its bucket raises the overflow flag and the call falls through to the exact path below.
+    bool preprocessed = false;
+    const int64_t max_hint = g_max_hint.load(std::memory_order_relaxed);
+    if (cull && !debug && max_hint > 0) {
+        const uint64_t cap = (((uint64_t)max_hint * 5 / 4 + 64) + 63) & ~63ull;
+        if (cap <= bucket_cap_limit() && cap * (uint64_t)tiles < (1ull << 31)) {
+            if (hipMemsetAsync(img.tile_count, 0, clear_bytes, s) != hipSuccess) {
+                set_error("hipMemsetAsync(tile histogram) failed");
+                return CGS_ERR_HIP;
+            }
+            if (!preprocess(nullptr)) return CGS_ERR_HIP;
+            preprocessed = true;
+            char* bchunk = (char*)binning_alloc(binning_user, cgs_binning_bytes((int64_t)(cap * tiles)));
+            if (!bchunk) {
+                set_error("cgs_rasterize_forward: binning allocation callback returned NULL");
+                return CGS_ERR_ALLOC;
+            }
+            BinState bin = bin_from_chunk(bchunk, (size_t)(cap * tiles));
+            launch_scatter_bucket(s, P, radii, geom.rec, gx, gy, img.tile_count, bin.keys, (uint32_t)cap, cull);
+            launch_tile_sort_bucket(s, tiles, img.tile_count, img.ranges, img.total, bin.keys, bin.point_list, (uint32_t)cap);
+            if (!read_totals()) return CGS_ERR_HIP;
+            if (!render(bin.point_list)) return CGS_ERR_HIP;
+            if (!wait_totals()) return CGS_ERR_HIP;
+            int64_t Rb = 0;
+            uint32_t longest = 0;
+            for (int k = 0; k < TOTAL_PARTS; k++) {
+                Rb += (int64_t)h_tot[4 + 2 * k];
+                longest = std::max(longest, h_tot[5 + 2 * k]);
+            }
+            update_max_hint(longest);
+            if ((uint64_t)longest <= cap) {
+                g_R_hint.store(Rb, std::memory_order_relaxed);
+                g_last_stats[0] = Rb; g_last_stats[1] = (int64_t)longest; g_last_stats[2] = 1;
+                return Rb;
+            }
+            // overflow: the image just rendered is incomplete -- redo the binning with exact sizes
+        }
+    }
+
+    // ---- path A: exact layout (count -> scan -> scatter -> sort); bit-identical to the reference's binning when
+    // tile culling is off.  Used for the first forward, in debug mode, with culling off and after a bucket overflow.
     if (hipMemsetAsync(img.tile_count, 0, clear_bytes, s) != hipSuccess) {
         set_error("hipMemsetAsync(tile histogram) failed");
         return CGS_ERR_HIP;
     }
-    launch_preprocess_fwd(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, geom.clamped,
-                          cov3D_precomp, colors_precomp, render_geo ? all_map : nullptr, viewmatrix, projmatrix,
-                          cam_pos, width, height, tan_fovx, tan_fovy, focal_x, focal_y, radii, geom.rec, geom.rgb, gx,
-                          gy, img.tile_count, antialiasing);
-    if (!check_launch("preprocess_fwd", debug, s)) return CGS_ERR_HIP;
+    if (!preprocess(img.tile_count)) return CGS_ERR_HIP;
+    (void)preprocessed;
     launch_scan_tiles(s, tiles, img.tile_count, img.ranges, img.total);
     if (!check_launch("scan_tiles", debug, s)) return CGS_ERR_HIP;
 
@@ -190,22 +283,7 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
     // binning kernels are launched SPECULATIVELY into a buffer sized from the previous call's R (+25 %) while an event
     // marks the readback; the host then waits on the event only.  If the guess was too small (scene changed a lot)
     // the kernels skipped every tile that would not fit and are re-run on an exact-size buffer.
-    static thread_local uint32_t* h_tot = nullptr;  // pinned {R, longest tile list}
-    static thread_local hipEvent_t ev = nullptr;
-    if (!h_tot) {
-        if (hipHostMalloc((void**)&h_tot, 2 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
-            hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
-            set_error("pinned readback buffer / event creation failed");
-            h_tot = nullptr;
-            return CGS_ERR_HIP;
-        }
-    }
-    hipError_t e = hipMemcpyAsync(h_tot, img.total, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipEventRecord(ev, s);
-    if (e != hipSuccess) {
-        set_error("reading num_rendered failed: %s", hipGetErrorString(e));
-        return CGS_ERR_HIP;
-    }
+    if (!read_totals()) return CGS_ERR_HIP;
     const int64_t hint = g_R_hint.load(std::memory_order_relaxed);
     int64_t cap = 0;
     char* bchunk = nullptr;
@@ -218,17 +296,14 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
             return CGS_ERR_ALLOC;
         }
         bin = bin_from_chunk(bchunk, (size_t)cap);
-        launch_scatter(s, P, radii, geom.rec, gx, gy, img.ranges, img.tile_cursor, bin.keys, (uint32_t)cap);
+        launch_scatter(s, P, radii, geom.rec, gx, gy, img.ranges, img.tile_cursor, bin.keys, (uint32_t)cap, cull);
         launch_tile_sort_small(s, tiles, img.ranges, bin.keys, bin.point_list, (uint32_t)cap);
     }
-    e = hipEventSynchronize(ev);
-    if (e != hipSuccess) {
-        set_error("reading num_rendered failed: %s", hipGetErrorString(e));
-        return CGS_ERR_HIP;
-    }
+    if (!wait_totals()) return CGS_ERR_HIP;
     const int64_t R = (int64_t)h_tot[0];
     const uint32_t max_count = h_tot[1];
     g_R_hint.store(R, std::memory_order_relaxed);
+    update_max_hint(max_count);
     if (!bchunk || R > cap) {  // first call, debug mode, or the speculative buffer was too small: exact-size (re)run
         if (cap > 0 && hipMemsetAsync(img.tile_cursor, 0, (size_t)tiles * sizeof(uint32_t), s) != hipSuccess) {
             set_error("hipMemsetAsync(tile cursors) failed");
@@ -242,7 +317,7 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
         }
         bin = bin_from_chunk(bchunk, (size_t)(R > 0 ? R : 1));
         if (R > 0) {
-            launch_scatter(s, P, radii, geom.rec, gx, gy, img.ranges, img.tile_cursor, bin.keys, (uint32_t)cap);
+            launch_scatter(s, P, radii, geom.rec, gx, gy, img.ranges, img.tile_cursor, bin.keys, (uint32_t)cap, cull);
             if (!check_launch("scatter", debug, s)) return CGS_ERR_HIP;
             launch_tile_sort_small(s, tiles, img.ranges, bin.keys, bin.point_list, (uint32_t)cap);
             if (!check_launch("tile_sort", debug, s)) return CGS_ERR_HIP;
@@ -252,10 +327,15 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
         launch_tile_sort_big(s, tiles, img.ranges, bin.keys, bin.point_list, max_count);  // no-op unless a list > 1024
         if (!check_launch("tile_sort", debug, s)) return CGS_ERR_HIP;
     }
-    launch_render_fwd(s, render_geo != 0, tiles, img.ranges, bin.point_list, width, height, gx, geom.rec, img.final_T,
-                      img.n_contrib, background, out_color, out_invdepth, out_all_map);
-    if (!check_launch("render_fwd", debug, s)) return CGS_ERR_HIP;
+    if (!render(bin.point_list)) return CGS_ERR_HIP;
+    g_last_stats[0] = R; g_last_stats[1] = (int64_t)max_count; g_last_stats[2] = 0;
     return R;
+}
+
+void cgs_last_forward_stats(int64_t* num_rendered, int64_t* longest_tile_list, int* binning_path) {
+    if (num_rendered) *num_rendered = g_last_stats[0];
+    if (longest_tile_list) *longest_tile_list = g_last_stats[1];
+    if (binning_path) *binning_path = (int)g_last_stats[2];
 }
 
 int cgs_rasterize_backward(int P, int D, int M, int64_t R, const float* background, int width, int height,

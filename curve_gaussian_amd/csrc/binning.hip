@@ -59,26 +59,56 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(int tiles, const uint32_t* 
     }
 }
 
+// Every iteration of the cooperative walk is a dependent chain of memory round trips (ranges load -> returning atomic
+// -> key store), so a wave's run time is (splats per wave) x (two L2 latencies): the kernel is latency-bound, not
+// throughput-bound.  Only the first SCATTER_SPW lanes of a wave own a splat, which shortens the serial chain and
+// multiplies the number of waves in flight by 64 / SCATTER_SPW.
+#ifndef CGS_SCATTER_SPW
+#define CGS_SCATTER_SPW 16
+#endif
+constexpr int SCATTER_SPW = CGS_SCATTER_SPW;
+// BUCKET = false: exact layout -- slot inside the tile's range from the scan.  BUCKET = true: single-pass layout --
+// every tile owns a fixed-capacity bucket [tile * cap, (tile + 1) * cap); tile_cursor doubles as the instance count
+// (no count pass, no scan); instances beyond `cap` are counted but not stored (the sort flags the overflow).
+template <bool BUCKET>
 __global__ void __launch_bounds__(256) k_scatter(int P, const int* __restrict__ radii,
                                                  const SplatRec* __restrict__ rec, int grid_x, int grid_y,
                                                  const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_cursor,
-                                                 uint64_t* __restrict__ keys, uint32_t cap) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int radius = idx < P ? radii[idx] : 0;
+                                                 uint64_t* __restrict__ keys, uint32_t cap, int cull) {
+    const int lane = threadIdx.x & 63;
+    const int idx = (blockIdx.x * 4 + (threadIdx.x >> 6)) * SCATTER_SPW + lane;
+    const int radius = (lane < SCATTER_SPW && idx < P) ? radii[idx] : 0;
     uint2 rmin = make_uint2(0, 0), rmax = make_uint2(0, 0);
     uint32_t key_lo = 0, key_hi = 0;
+    float4 ra = make_float4(0.f, 0.f, 1.f, 0.f);
+    float conic_z = 1.f, tau2 = -1.f;
     if (radius > 0) {
-        const float4 a = rec[idx].a;
-        get_rect(a.x, a.y, radius, grid_x, grid_y, rmin, rmax);
-        key_hi = __float_as_uint(rec[idx].d.x);  // depth bits (positive floats order like unsigned ints)
+        ra = rec[idx].a;
+        get_rect(ra.x, ra.y, radius, grid_x, grid_y, rmin, rmax);
+        const float4 d = rec[idx].d;
+        key_hi = __float_as_uint(d.x);  // depth bits (positive floats order like unsigned ints)
         key_lo = (uint32_t)idx;
+        if (cull) {
+            conic_z = rec[idx].b.x;
+            tau2 = d.z;
+        }
     }
-    for_each_rect_tile_coop(radius > 0, rmin, rmax, grid_x, [&](int src, uint32_t tile) {
+    for_each_rect_tile_coop(radius > 0, rmin, rmax, [&](int src, uint32_t tx, uint32_t ty) {
+        if (cull && !tile_reach_det(readlane_f(ra.x, src), readlane_f(ra.y, src), readlane_f(ra.z, src),
+                                    readlane_f(ra.w, src), readlane_f(conic_z, src), readlane_f(tau2, src),
+                                    (float)(tx * TILE), (float)(ty * TILE)))
+            return;
+        const uint32_t tile = ty * (uint32_t)grid_x + tx;
         const uint64_t key = ((uint64_t)__builtin_amdgcn_readlane(key_hi, src) << 32) | __builtin_amdgcn_readlane(key_lo, src);
-        const uint2 rg = ranges[tile];
-        if (rg.y > cap) return;  // speculative buffer too small for this tile: the host re-runs with the exact size
-        const uint32_t slot = atomicAdd(&tile_cursor[tile], 1u);
-        keys[rg.x + slot] = key;
+        if (BUCKET) {
+            const uint32_t slot = atomicAdd(&tile_cursor[tile], 1u);
+            if (slot < cap) keys[(size_t)tile * cap + slot] = key;
+        } else {
+            const uint2 rg = ranges[tile];
+            if (rg.y > cap) return;  // speculative buffer too small for this tile: the host re-runs with the exact size
+            const uint32_t slot = atomicAdd(&tile_cursor[tile], 1u);
+            if (rg.x + slot < rg.y) keys[rg.x + slot] = key;  // (always true; keeps a count/scatter disagreement memory-safe)
+        }
     });
 }
 
@@ -118,13 +148,34 @@ __device__ __forceinline__ void bitonic_any_n(Ptr k, uint32_t n, uint32_t n2, ui
 // Measured on cfg3 (mean list 225): 81 us vs 90 us for the LDS bitonic network; unrolling the broadcast loop or
 // splitting the compare into 32-bit depth/idx parts was slower (103 / 117 us).
 constexpr uint32_t RANK_MAX = 1024;
+// Bucket layout: derive this tile's range from its instance count, publish it for the compositor and fold the
+// count into the partial sums / maxima of `total` (num_rendered, longest list; longest > cap <=> overflow).
+__device__ __forceinline__ uint2 bucket_range(const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges_out,
+                                              uint32_t* __restrict__ total, uint32_t cap, bool publish) {
+    const uint32_t cnt = tile_count[blockIdx.x];
+    const uint32_t n = min(cnt, cap);
+    const uint32_t base = blockIdx.x * cap;
+    if (publish && threadIdx.x == 0) {
+        ranges_out[blockIdx.x] = make_uint2(base, base + n);
+        if (cnt) {  // same-address atomics from every tile serialise (~20 ns each): spread over TOTAL_PARTS partial slots
+            uint32_t* part = total + 4 + 2 * (blockIdx.x % TOTAL_PARTS);
+            atomicAdd(&part[0], n);
+            atomicMax(&part[1], cnt);  // > cap  <=>  this bucket overflowed
+        }
+    }
+    return make_uint2(base, base + n);
+}
+
+template <bool BUCKET>
 __global__ void __launch_bounds__(256) k_tile_rank_sort(const uint2* __restrict__ ranges,
                                                         const uint64_t* __restrict__ keys,
-                                                        uint32_t* __restrict__ point_list, uint32_t cap) {
+                                                        uint32_t* __restrict__ point_list, uint32_t cap,
+                                                        const uint32_t* __restrict__ tile_count,
+                                                        uint2* __restrict__ ranges_out, uint32_t* __restrict__ total) {
     __shared__ uint64_t sk[RANK_MAX];
-    const uint2 rg = ranges[blockIdx.x];
+    const uint2 rg = BUCKET ? bucket_range(tile_count, ranges_out, total, cap, true) : ranges[blockIdx.x];
     const uint32_t n = rg.y - rg.x;
-    if (n == 0 || n > RANK_MAX || rg.y > cap) return;
+    if (n == 0 || n > RANK_MAX || (!BUCKET && rg.y > cap)) return;
     const uint32_t tid = threadIdx.x;
     const uint64_t* gk = keys + rg.x;
     uint32_t* out = point_list + rg.x;
@@ -160,10 +211,12 @@ __global__ void __launch_bounds__(256) k_tile_rank_sort(const uint2* __restrict_
 
 constexpr uint32_t SORT_LDS_KEYS = 4096;  // 32 KiB of LDS per workgroup
 
+template <bool BUCKET>
 __global__ void __launch_bounds__(256) k_tile_sort(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
-                                                   uint32_t* __restrict__ point_list, uint32_t min_n) {
+                                                   uint32_t* __restrict__ point_list, uint32_t min_n, uint32_t cap,
+                                                   const uint32_t* __restrict__ tile_count) {
     __shared__ uint64_t sk[SORT_LDS_KEYS];
-    const uint2 rg = ranges[blockIdx.x];
+    const uint2 rg = BUCKET ? bucket_range(tile_count, nullptr, nullptr, cap, false) : ranges[blockIdx.x];
     const uint32_t n = rg.y - rg.x;
     if (n <= min_n) return;  // handled by k_tile_rank_sort
     const uint32_t tid = threadIdx.x;
@@ -194,21 +247,45 @@ void launch_scan_tiles(hipStream_t s, int tiles, const uint32_t* tile_count, uin
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tiles, tile_count, ranges, total);
 }
 void launch_scatter(hipStream_t s, int P, const int* radii, const SplatRec* rec, int grid_x, int grid_y,
-                    const uint2* ranges, uint32_t* tile_cursor, uint64_t* keys, uint32_t cap) {
+                    const uint2* ranges, uint32_t* tile_cursor, uint64_t* keys, uint32_t cap, int cull) {
     ProfScope p("scatter", s);
-    hipLaunchKernelGGL(k_scatter, dim3((P + 255) / 256), dim3(256), 0, s, P, radii, rec, grid_x, grid_y, ranges,
-                       tile_cursor, keys, cap);
+    hipLaunchKernelGGL(k_scatter<false>, dim3((P + 4 * SCATTER_SPW - 1) / (4 * SCATTER_SPW)), dim3(256), 0, s, P,
+                       radii, rec, grid_x, grid_y, ranges, tile_cursor, keys, cap, cull);
 }
 void launch_tile_sort_small(hipStream_t s, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* point_list,
                             uint32_t cap) {
     ProfScope p("tile_sort", s);
-    hipLaunchKernelGGL(k_tile_rank_sort, dim3(tiles), dim3(256), 0, s, ranges, keys, point_list, cap);
+    hipLaunchKernelGGL(k_tile_rank_sort<false>, dim3(tiles), dim3(256), 0, s, ranges, keys, point_list, cap, nullptr,
+                       nullptr, nullptr);
 }
 void launch_tile_sort_big(hipStream_t s, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* point_list,
                           uint32_t max_count) {
     if (max_count <= RANK_MAX) return;  // rare: some tile list is longer than 1024 -> bitonic network (LDS or global)
     ProfScope p("tile_sort_big", s);
-    hipLaunchKernelGGL(k_tile_sort, dim3(tiles), dim3(256), 0, s, ranges, keys, point_list, RANK_MAX);
+    hipLaunchKernelGGL(k_tile_sort<false>, dim3(tiles), dim3(256), 0, s, ranges, keys, point_list, RANK_MAX, 0u,
+                       nullptr);
 }
+// Single-pass bucket binning: scatter straight into fixed-capacity tile buckets, then sort each bucket and publish
+// ranges / num_rendered / longest list / overflow flag from the sort kernel.
+void launch_scatter_bucket(hipStream_t s, int P, const int* radii, const SplatRec* rec, int grid_x, int grid_y,
+                           uint32_t* tile_count, uint64_t* keys, uint32_t cap, int cull) {
+    ProfScope p("scatter", s);
+    hipLaunchKernelGGL(k_scatter<true>, dim3((P + 4 * SCATTER_SPW - 1) / (4 * SCATTER_SPW)), dim3(256), 0, s, P, radii,
+                       rec, grid_x, grid_y, nullptr, tile_count, keys, cap, cull);
+}
+void launch_tile_sort_bucket(hipStream_t s, int tiles, const uint32_t* tile_count, uint2* ranges, uint32_t* total,
+                             uint64_t* keys, uint32_t* point_list, uint32_t cap) {
+    {
+        ProfScope p("tile_sort", s);
+        hipLaunchKernelGGL(k_tile_rank_sort<true>, dim3(tiles), dim3(256), 0, s, nullptr, keys, point_list, cap,
+                           tile_count, ranges, total);
+    }
+    if (cap > RANK_MAX) {
+        ProfScope p("tile_sort_big", s);
+        hipLaunchKernelGGL(k_tile_sort<true>, dim3(tiles), dim3(256), 0, s, nullptr, keys, point_list, RANK_MAX, cap,
+                           tile_count);
+    }
+}
+uint32_t bucket_cap_limit() { return SORT_LDS_KEYS; }
 
 }  // namespace cgs

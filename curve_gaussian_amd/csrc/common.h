@@ -33,13 +33,16 @@ struct GeomState {            // carved from the geometry buffer
     float* rgb;               // [P]   SH-evaluated colour (SH path only)
     uint8_t* clamped;         // [P]
 };
+constexpr int TOTAL_PARTS = 256;
+constexpr int TOTAL_WORDS = 4 + 2 * TOTAL_PARTS;
 struct ImageState {           // carved from the image buffer
     float* final_T;           // [H*W]
     uint32_t* n_contrib;      // [H*W]
     uint2* ranges;            // [tiles]  [start,end) in the sorted list
     uint32_t* tile_count;     // [tiles]
     uint32_t* tile_cursor;    // [tiles]
-    uint32_t* total;          // [4]      [0] = R
+    uint32_t* total;          // [TOTAL_WORDS]  [0] = R, [1] = longest list (exact path); [4 + 2k], [5 + 2k] = partial
+                              //                sum / max of the tile lists with tile % TOTAL_PARTS == k (bucket path)
 };
 struct BinState {             // carved from the binning buffer
     uint64_t* keys;           // [R]  (depth_bits << 32) | splat_idx, bucketed by tile, unsorted inside a bucket
@@ -67,7 +70,7 @@ static inline ImageState image_from_chunk(char*& chunk, size_t npix, size_t tile
     carve(chunk, s.ranges, tiles);
     carve(chunk, s.tile_count, tiles);
     carve(chunk, s.tile_cursor, tiles);
-    carve(chunk, s.total, 4);
+    carve(chunk, s.total, TOTAL_WORDS);
     return s;
 }
 static inline BinState bin_from_chunk(char*& chunk, size_t R) {
@@ -169,9 +172,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Cooperative rect walk: the 64 lanes of a wave visit the tiles of ONE splat's rect at a time (lane = tile), so the
 // atomics of a rect row hit consecutive addresses and coalesce into one L2 request per row (measured ~7x the rate
 // of one-splat-per-lane loops, whose 64 lanes scatter over 64 unrelated cache lines).  `has` = this lane's splat
-// is visible; rect = its tile rect.  fn(splat_lane, tile_index) is called with a wave-uniform splat_lane.
+// is visible; rect = its tile rect.  fn(splat_lane, tile_x, tile_y) is called with a wave-uniform splat_lane.
 template <typename F>
-__device__ __forceinline__ void for_each_rect_tile_coop(bool has, uint2 rmin, uint2 rmax, int grid_x, F fn) {
+__device__ __forceinline__ void for_each_rect_tile_coop(bool has, uint2 rmin, uint2 rmax, F fn) {
     uint64_t todo = __ballot(has);
     const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     while (todo) {
@@ -184,10 +187,42 @@ __device__ __forceinline__ void for_each_rect_tile_coop(bool has, uint2 rmin, ui
             const uint32_t t = base + (uint32_t)lane;
             if (t < n) {
                 const uint32_t ty = t / w, tx = t - ty * w;
-                fn(src, (y0 + ty) * (uint32_t)grid_x + x0 + tx);
+                fn(src, x0 + tx, y0 + ty);
             }
         }
     }
+}
+
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+// ---------------------------------------------------------------- exact tile-level culling
+// One edge of the box minimisation below, written with explicit fmaf / separate roundings only (contraction off) so
+// the count pass (k_preprocess_fwd) and the scatter pass (k_scatter) take bit-identical decisions.
+__device__ __forceinline__ float edge_min_det(float P, float B, float Q, float rQ, float e, float lo, float hi) {
+#pragma clang fp contract(off)
+    // min over d in [lo,hi] of P e^2 + 2 B e d + Q d^2
+    const float Be = B * e;
+    const float d = fminf(fmaxf(-Be * rQ, lo), hi);
+    return __builtin_fmaf(P * e, e, __builtin_fmaf(2.f * Be, d, (Q * d) * d));
+}
+// true iff the splat (centre c, conic A,B,C, tau2 = 2 ln(255 opacity)) may reach alpha >= 1/255 at some pixel of the
+// TILE x TILE tile whose first pixel is (X0, Y0).  Conservative: same slack as the compositor's quadrant masks.
+__device__ __forceinline__ bool tile_reach_det(float cx, float cy, float A, float B, float C, float tau2, float X0,
+                                               float Y0) {
+#pragma clang fp contract(off)
+    if (!(tau2 >= 0.f)) return false;  // opacity < 1/255 (or NaN): never blended anywhere
+    const float l = X0 - cx, r = l + (float)(TILE - 1), b = Y0 - cy, t = b + (float)(TILE - 1);
+    if (l <= 0.f && r >= 0.f && b <= 0.f && t >= 0.f) return true;
+    const float rA = __builtin_amdgcn_rcpf(A), rC = __builtin_amdgcn_rcpf(C);
+    float m = edge_min_det(A, B, C, rC, l, b, t);
+    m = fminf(m, edge_min_det(A, B, C, rC, r, b, t));
+    m = fminf(m, edge_min_det(C, B, A, rA, b, l, r));
+    m = fminf(m, edge_min_det(C, B, A, rA, t, l, r));
+    const float X = fmaxf(fabsf(l), fabsf(r)), Y = fmaxf(fabsf(b), fabsf(t));
+    const float mag = __builtin_fmaf(A * X, X, __builtin_fmaf(2.f * fabsf(B) * X, Y, (C * Y) * Y));
+    const float lim = __builtin_fmaf(tau2, 1.001f, 1e-3f);
+    return m <= __builtin_fmaf(8e-6f, mag, lim);
 }
 __device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 #endif  // __HIPCC__

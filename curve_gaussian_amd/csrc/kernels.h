@@ -12,7 +12,7 @@ void launch_preprocess_fwd(hipStream_t s, int P, int D, int M, const float* mean
                            const float* all_map, const float* viewmatrix, const float* projmatrix,
                            const float* cam_pos, int W, int H, float tan_fovx, float tan_fovy, float focal_x,
                            float focal_y, int* radii, SplatRec* rec, float* rgb, int grid_x, int grid_y,
-                           uint32_t* tile_count, int antialiasing);
+                           uint32_t* tile_count, int antialiasing, int cull);
 void launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* viewmatrix, uint8_t* present);
 void launch_preprocess_bwd(hipStream_t s, int P, int D, int M, const float* means3D, const int* radii,
                            const float* shs, const uint8_t* clamped, const float* opacities, const float* scales,
@@ -27,7 +27,12 @@ void launch_preprocess_bwd(hipStream_t s, int P, int D, int M, const float* mean
 void launch_scan_tiles(hipStream_t s, int tiles, const uint32_t* tile_count, uint2* ranges, uint32_t* total);
 // `cap` = number of instances the binning buffer can hold: tiles whose range does not fit are skipped (speculative launch)
 void launch_scatter(hipStream_t s, int P, const int* radii, const SplatRec* rec, int grid_x, int grid_y,
-                    const uint2* ranges, uint32_t* tile_cursor, uint64_t* keys, uint32_t cap);
+                    const uint2* ranges, uint32_t* tile_cursor, uint64_t* keys, uint32_t cap, int cull);
+void launch_scatter_bucket(hipStream_t s, int P, const int* radii, const SplatRec* rec, int grid_x, int grid_y,
+                           uint32_t* tile_count, uint64_t* keys, uint32_t cap, int cull);
+void launch_tile_sort_bucket(hipStream_t s, int tiles, const uint32_t* tile_count, uint2* ranges, uint32_t* total,
+                             uint64_t* keys, uint32_t* point_list, uint32_t cap);
+uint32_t bucket_cap_limit();
 void launch_tile_sort_small(hipStream_t s, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* point_list,
                             uint32_t cap);
 void launch_tile_sort_big(hipStream_t s, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* point_list,

@@ -104,11 +104,13 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(
     const float* __restrict__ all_map, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
     const float* __restrict__ cam_pos, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
     int* __restrict__ radii, SplatRec* __restrict__ rec, float* __restrict__ rgb, int grid_x, int grid_y,
-    uint32_t* __restrict__ tile_count, int antialiasing) {
+    uint32_t* __restrict__ tile_count, int antialiasing, int cull) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     // radius 0 == "not processed further" (forward.cu:187-190)
     int out_radius = 0;
     uint2 rmin = make_uint2(0, 0), rmax = make_uint2(0, 0);
+    float4 ra = make_float4(0.f, 0.f, 1.f, 0.f);  // (px, py, conic.x, conic.y) of this lane's splat
+    float conic_z = 1.f, tau2 = -1.f;
     if (idx < P) do {
         const float3 p_orig = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
         const float3 p_view = xform4x3(p_orig, viewmatrix);
@@ -162,14 +164,24 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(
         // tau2 = 2 ln(255 * opacity): alpha >= 1/255  <=>  conic quadratic form <= tau2 (used by the quadrant culling)
         r.d = make_float4(p_view.z, my_radius, 2.f * logf(255.f * op_eff), 0.f);
         rec[idx] = r;
+        ra = r.a;
+        conic_z = r.b.x;
+        tau2 = r.d.z;
         out_radius = (int)my_radius;
         rmin = r0;
         rmax = r1;
     } while (false);
     if (idx < P) radii[idx] = out_radius;
     // per-tile instance counts (replaces the reference's per-splat scan K2 + duplicateWithKeys offsets)
-    for_each_rect_tile_coop(out_radius > 0, rmin, rmax, grid_x,
-                            [&](int, uint32_t tile) { atomicAdd(&tile_count[tile], 1u); });
+    // (with `cull`, only the tiles the splat can reach with alpha >= 1/255; k_scatter takes the identical decision)
+    if (!tile_count) return;  // single-pass bucket binning: k_scatter<true> counts while it scatters
+    for_each_rect_tile_coop(out_radius > 0, rmin, rmax, [&](int src, uint32_t tx, uint32_t ty) {
+        if (cull && !tile_reach_det(readlane_f(ra.x, src), readlane_f(ra.y, src), readlane_f(ra.z, src),
+                                    readlane_f(ra.w, src), readlane_f(conic_z, src), readlane_f(tau2, src),
+                                    (float)(tx * TILE), (float)(ty * TILE)))
+            return;
+        atomicAdd(&tile_count[ty * (uint32_t)grid_x + tx], 1u);
+    });
 }
 
 // reference checkFrustum, rasterizer_impl.cu:54-66
@@ -367,12 +379,12 @@ void launch_preprocess_fwd(hipStream_t s, int P, int D, int M, const float* mean
                            const float* all_map, const float* viewmatrix, const float* projmatrix,
                            const float* cam_pos, int W, int H, float tan_fovx, float tan_fovy, float focal_x,
                            float focal_y, int* radii, SplatRec* rec, float* rgb, int grid_x, int grid_y,
-                           uint32_t* tile_count, int antialiasing) {
+                           uint32_t* tile_count, int antialiasing, int cull) {
     ProfScope p("preprocess_fwd", s);
     hipLaunchKernelGGL(k_preprocess_fwd, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, scales,
                        scale_modifier, rotations, opacities, shs, clamped, cov3D_precomp, colors_precomp, all_map,
                        viewmatrix, projmatrix, cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, radii, rec, rgb,
-                       grid_x, grid_y, tile_count, antialiasing);
+                       grid_x, grid_y, tile_count, antialiasing, cull);
 }
 void launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* viewmatrix, uint8_t* present) {
     ProfScope p("mark_visible", s);

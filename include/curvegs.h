@@ -199,6 +199,22 @@ size_t cgs_knn_workspace_bytes(int P);
 int cgs_knn_mean_dist2(int P, const float* points /*[P,3]*/, float* mean_dist2 /*[P]*/, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Tile-level culling switch (process-wide, default on).  The reference bins a splat into EVERY tile of the
+ * bounding square of radius ceil(3 sigma) (forward.cu:318-321 getRect, rasterizer_impl.cu:70-110) and lets the
+ * compositor skip it per pixel when alpha < 1/255 (forward.cu:371-377).  With culling on, an instance
+ * (splat, tile) is only created when the splat can reach alpha >= 1/255 at some pixel of that tile, so
+ * num_rendered is smaller than the reference's while images, radii and every gradient are unchanged (the
+ * dropped instances are exactly those the compositor would skip at all 256 pixels).  With culling off,
+ * num_rendered and the per-tile lists are bit-identical to the reference's.  Returns the previous setting.
+ * ------------------------------------------------------------------------------------------------ */
+int cgs_set_tile_culling(int on);
+/* Introspection of the calling thread's last cgs_rasterize_forward: num_rendered, the longest per-tile list and
+ * which binning path produced it (0 = exact count/scan/scatter layout, 1 = single-pass fixed-capacity buckets). */
+/* Forget the sizes learnt from earlier forwards (the next forward takes the exact path and re-learns them). */
+void cgs_reset_binning_hints(void);
+void cgs_last_forward_stats(int64_t* num_rendered, int64_t* longest_tile_list, int* binning_path);
+
+/* ------------------------------------------------------------------------------------------------
  * Per-kernel timing hook used by bench.py: when enabled, every kernel launched by the library is
  * bracketed by hipEvents on the caller's stream; cgs_prof_collect synchronises and accumulates.
  * ------------------------------------------------------------------------------------------------ */

@@ -175,22 +175,28 @@ def _decode_state(geomBuffer, binningBuffer, imgBuffer, P, H, W, R):
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     ib = imgBuffer.cpu().numpy()
     base = imgBuffer.data_ptr()
-    o = carve_offsets(base, [(H * W, 4), (H * W, 4), (tiles, 8), (tiles, 4), (tiles, 4), (4, 4)])
+    o = carve_offsets(base, [(H * W, 4), (H * W, 4), (tiles, 8), (tiles, 4), (tiles, 4), (516, 4)])
     ranges = ib[o[2]:o[2] + tiles * 8].view(np.uint32).reshape(-1, 2)
     n_contrib = ib[o[1]:o[1] + H * W * 4].view(np.uint32)
     final_T = ib[o[0]:o[0] + H * W * 4].view(np.float32)
     bb = binningBuffer.cpu().numpy()
-    ob = carve_offsets(binningBuffer.data_ptr(), [(max(R, 1), 4)])  # point_list is carved first (csrc/common.h)
-    point_list = bb[ob[0]:ob[0] + R * 4].view(np.uint32)
+    # point_list is carved first (csrc/common.h); ranges index into it (compact in the exact layout, one
+    # fixed-capacity bucket per tile in the single-pass layout)
+    n_entries = max(int(ranges[:, 1].max()) if len(ranges) else 0, R)
+    ob = carve_offsets(binningBuffer.data_ptr(), [(max(n_entries, 1), 4)])
+    point_list = bb[ob[0]:ob[0] + n_entries * 4].view(np.uint32)
     return ranges, point_list, n_contrib, final_T
 
 
-@pytest.mark.parametrize("case", ["ties", "oversized_bucket", "screen_filling"])
-def test_binning_bit_exact(case):
-    """Integer work: num_rendered, tile ranges and the per-tile (depth, idx) order equal the reference's stable
-    radix sort exactly -- including depth ties and buckets larger than the LDS sort capacity."""
-    from curve_gaussian_amd.diff_cur_rasterization import _C
-    dev = torch.device(DEV)
+def _forward_stats():
+    import ctypes
+    from curve_gaussian_amd import _lib
+    r, m, p = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+    _lib.load().cgs_last_forward_stats(ctypes.byref(r), ctypes.byref(m), ctypes.byref(p))
+    return r.value, m.value, p.value
+
+
+def _binning_case(case):
     if case == "ties":
         H, W, P = 64, 64, 3000
         sp = S.random_splats(P, 61)
@@ -198,9 +204,104 @@ def test_binning_bit_exact(case):
     elif case == "oversized_bucket":
         H, W, P = 32, 32, 9000                                   # 4 tiles x ~9000 instances > 4096-key LDS capacity
         sp = S.random_splats(P, 62, scale_range=(0.05, 0.2))
-    else:
+    elif case == "screen_filling":
         H, W, P = 160, 160, 64
         sp = S.random_splats(P, 63, scale_range=(0.5, 2.0))        # every splat covers all 100 tiles
+    else:  # "elongated": thin, long splats (what curve sampling produces) -- most of each bounding square is empty
+        H, W, P = 208, 304, 4000
+        sp = S.random_splats(P, 64, scale_range=(0.01, 0.1))
+        sp["scales"][:, 1:] *= 0.05
+    return H, W, P, sp
+
+
+@pytest.fixture
+def no_tile_culling():
+    from curve_gaussian_amd import _lib
+    prev = _lib.load().cgs_set_tile_culling(0)
+    yield
+    _lib.load().cgs_set_tile_culling(prev)
+
+
+def _raster_raw(sp, cam, H, W, dev, reset_hints=False):
+    from curve_gaussian_amd.diff_cur_rasterization import _C
+    if reset_hints:
+        from curve_gaussian_amd import _lib
+        _lib.load().cgs_reset_binning_hints()
+    rs = hip_settings(cam, torch.zeros(3), dev)
+    d = {k: v.to(dev) for k, v in sp.items()}
+    empty = torch.empty(0, device=dev)
+    out = _C.rasterize_gaussians(
+        rs.bg, d["means3D"], d["colors"], d["opacities"], d["scales"], d["rotations"], 1.0, empty, d["all_map"],
+        rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, empty, 0, rs.campos, False, False, True, False)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("case", ["ties", "oversized_bucket", "screen_filling", "elongated"])
+def test_tile_culling_drops_only_invisible_instances(case):
+    """Default mode (cgs_set_tile_culling(1)): every tile list is a SUBSEQUENCE of the reference's stable-sorted list
+    (same relative order), every dropped (splat, tile) instance stays below alpha 1/255 at all 256 pixels of its tile
+    (checked in float64 from the oracle's conics), and the image is unchanged."""
+    dev = torch.device(DEV)
+    H, W, P, sp = _binning_case(case)
+    cam = S.make_camera(*CAMS[0], H, W)
+    fw = oracle_forward(sp, cam, torch.zeros(3))
+    first = _raster_raw(sp, cam, H, W, dev, reset_hints=True)   # no hints: exact layout
+    assert _forward_stats()[2] == 0
+    (R, color, radii, geomB, binB, imgB, invd, amap) = _raster_raw(sp, cam, H, W, dev)
+    stats = _forward_stats()
+    assert stats[0] == R and stats[1] >= 1
+    if case != "oversized_bucket":                # 2nd call: single-pass bucket layout (lists <= 4096 entries)
+        assert stats[2] == 1, stats
+    else:
+        assert stats[2] == 0 and stats[1] > 4096, stats
+    assert R == first[0] and torch.equal(color, first[1]) and torch.equal(radii, first[2])
+    assert torch.equal(invd, first[6]) and torch.equal(amap, first[7]), "both binning layouts must render identically"
+    assert 0 < R <= fw.num_rendered
+    ranges, point_list, n_contrib, final_T = _decode_state(geomB, binB, imgB, P, H, W, R)
+    lens = (ranges[:, 1] - ranges[:, 0]).astype(np.int64)
+    assert lens.sum() == R
+    ref_ranges, ref_list = fw.ranges, fw.point_list
+    xy = fw.means2D.astype(np.float64)
+    co = fw.conic_opacity.astype(np.float64)
+    gx = (W + 15) // 16
+    yy, xx = np.mgrid[0:16, 0:16]
+    dropped = 0
+    for t in range(len(lens)):
+        mine = point_list[ranges[t, 0]:ranges[t, 1]]
+        ref = ref_list[ref_ranges[t, 0]:ref_ranges[t, 1]]
+        # subsequence check: walk the reference list once
+        keep = np.zeros(len(ref), bool)
+        j = 0
+        for i, r in enumerate(ref):
+            if j < len(mine) and mine[j] == r:
+                keep[i] = True
+                j += 1
+        assert j == len(mine), f"tile {t}: list is not an order-preserving subset of the reference's"
+        gone = ref[~keep]
+        dropped += len(gone)
+        if len(gone):
+            px = (t % gx) * 16 + xx.ravel()[None, :]
+            py = (t // gx) * 16 + yy.ravel()[None, :]
+            dx = xy[gone, 0:1] - px
+            dy = xy[gone, 1:2] - py
+            power = -0.5 * (co[gone, 0:1] * dx * dx + co[gone, 2:3] * dy * dy) - co[gone, 1:2] * dx * dy
+            alpha = co[gone, 3:4] * np.exp(power)
+            assert alpha.max() < 1.0 / 255.0, f"tile {t}: culled an instance with alpha {alpha.max()}"
+    assert dropped == fw.num_rendered - R
+    if case == "elongated":
+        assert R < 0.8 * fw.num_rendered  # the point of the exercise
+    assert_close("color", color.cpu().numpy(), fw.color)
+    fw.free()
+
+
+@pytest.mark.parametrize("case", ["ties", "oversized_bucket", "screen_filling", "elongated"])
+def test_binning_bit_exact(case, no_tile_culling):
+    """Integer work with tile culling off: num_rendered, tile ranges and the per-tile (depth, idx) order equal the
+    reference's stable radix sort exactly -- including depth ties and buckets larger than the LDS sort capacity."""
+    from curve_gaussian_amd.diff_cur_rasterization import _C
+    dev = torch.device(DEV)
+    H, W, P, sp = _binning_case(case)
     cam = S.make_camera(*CAMS[0], H, W)
     bg = torch.zeros(3)
     fw = oracle_forward(sp, cam, bg)
@@ -222,6 +323,29 @@ def test_binning_bit_exact(case):
         mism = (n_contrib.reshape(H, W) != fw.n_contrib).mean()
         assert mism <= 2e-3, mism
     assert_close("color", color.cpu().numpy(), fw.color)
+    fw.free()
+
+
+def test_bucket_overflow_falls_back_to_exact_layout():
+    """A scene whose tile lists are far longer than the previous forward's (bucket capacity = previous longest list
+    x 1.25) must overflow the buckets, be detected and re-binned through the exact path with identical results."""
+    dev = torch.device(DEV)
+    H, W = 96, 96
+    cam = S.make_camera(*CAMS[0], H, W)
+    small = S.random_splats(300, 91)
+    big = S.random_splats(6000, 92, scale_range=(0.02, 0.1))
+    fw = oracle_forward(big, cam, torch.zeros(3))
+    _raster_raw(small, cam, H, W, dev, reset_hints=True)
+    _raster_raw(small, cam, H, W, dev)
+    s_small = _forward_stats()
+    assert s_small[2] == 1
+    out = _raster_raw(big, cam, H, W, dev)
+    s_big = _forward_stats()
+    assert s_big[2] == 0 and s_big[1] > 2 * s_small[1], (s_small, s_big)
+    assert_close("color", out[1].cpu().numpy(), fw.color)
+    assert_close("all_map", out[7].cpu().numpy(), fw.out_all_map)
+    out2 = _raster_raw(big, cam, H, W, dev)  # hint now fits: bucket path, same image
+    assert _forward_stats()[2] == 1 and out2[0] == out[0] and torch.equal(out2[1], out[1])
     fw.free()
 
 
@@ -274,12 +398,13 @@ def test_full_size_properties_cfg3_view():
         True, False)
     torch.cuda.synchronize()
     ranges, point_list, n_contrib, final_T = _decode_state(geomB, binB, imgB, P, H, W, R)
+    # whichever binning layout ran (exact or fixed-capacity buckets), compact the lists tile by tile
+    point_list = np.concatenate([point_list[a:b] for a, b in ranges])
     assert P == 200004 and R > P
-    # instance conservation: sum of per-splat rect areas == R
     rad = radii.cpu().numpy()
     assert (rad > 0).sum() > 0.9 * P
     lens = (ranges[:, 1] - ranges[:, 0]).astype(np.int64)
-    assert lens.sum() == R and (ranges[1:, 0] == ranges[:-1, 1]).all()
+    assert lens.sum() == R and (ranges[1:, 0] >= ranges[:-1, 1]).all()
     # sortedness by (depth_bits, idx) inside every tile
     vm = cam.world_view_transform.numpy()
     depth = (xyz.numpy() @ vm[:3, 2] + vm[3, 2]).astype(np.float32)
