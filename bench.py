@@ -64,6 +64,11 @@ def main():
     ap.add_argument("--no-kernel-times", action="store_true")
     ap.add_argument("--no-train-step", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=3,
+                    help="view mode: independent views kept in flight per GPU (HIP streams); 1 = strictly serial views")
+    ap.add_argument("--views-per-step", type=int, default=8,
+                    help="view mode: views per rank whose gradients are summed before the all-reduce (one optimizer "
+                         "step's view batch per rank)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -135,17 +140,20 @@ def main():
     # curve_points 12 | width 1 | opacity 1 | mask 12 | features_dc 12), so the per-step exchange is a single
     # all-reduce with no packing kernels.
     from curve_gaussian_amd.diff_cur_rasterization import GaussianRasterizationSettings, rasterize_gaussians
-    p_cp = curves["curve_points"].to(dev).requires_grad_(True)
-    p_w = curves["width"].to(dev).requires_grad_(True)
-    p_op = curves["opacity"].to(dev).requires_grad_(True)
-    p_cp.grad = flat_grads[0:12 * B].view(B, 4, 3)
-    p_w.grad = flat_grads[12 * B:13 * B].view(B, 1)
-    p_op.grad = flat_grads[13 * B:14 * B].view(B, 1)
+    base = [curves["curve_points"].to(dev), curves["width"].to(dev), curves["opacity"].to(dev)]
+
+    def make_leaves(flat):
+        # aliases of the same parameter storage with their own autograd identity and their own flat .grad buffer
+        leaves = [t.detach().requires_grad_(True) for t in base]
+        leaves[0].grad = flat[0:12 * B].view(B, 4, 3)
+        leaves[1].grad = flat[12 * B:13 * B].view(B, 1)
+        leaves[2].grad = flat[13 * B:14 * B].view(B, 1)
+        return leaves
     isb = curves["is_bezier"].to(dev)
     settings = {}
 
-    def step_view(cam, collect=False):
-        flat_grads.zero_()
+    def step_view(cam, leaves, collect=False):
+        p_cp, p_w, p_op = leaves
         s_xyz, s_rot, s_scl = curve_sampling.sample_curves(p_cp, p_w, isb, m)            # prepare_scaling_rot
         rot_n, opacity, scales, amap = curve_sampling.splat_attributes(
             s_rot, s_xyz, p_op, s_scl, cam.camera_center, cam.world_view_transform, m)   # render() glue, fused
@@ -157,24 +165,45 @@ def main():
                 campos=cam.camera_center, prefiltered=False, debug=False, antialiasing=False, render_geo=True)
         color, radii, invd, om = rasterize_gaussians(s_xyz, None, empty, colors, opacity, scales, rot_n, empty, amap, rs)
         color.backward(dL_dcolor)   # synthetic upstream gradient; grads accumulate into flat_grads views
-        if world > 1:
-            dist.all_reduce(flat_grads)
         if collect:
             stats["visible"] += int((radii > 0).sum())
 
-    step = step_view if args.mode == "view" else step_raster
+    # One optimizer step's view batch per rank: `views_per_step` independent views, up to `streams` of them in flight,
+    # gradients summed in flat_grads, then ONE all-reduce over the ranks.  (--streams 1 --views-per-step 1 is the
+    # reference's one-view-per-iteration schedule.)
+    from curve_gaussian_amd.view_parallel import ViewStreams
+    vstreams = ViewStreams(args.streams if args.mode == "view" else 1, dev)
+    G = max(1, args.views_per_step) if args.mode == "view" else 1
+    # every stream accumulates into its own flat buffer through its own leaf aliases (a shared .grad would make
+    # autograd funnel all accumulation through one stream and serialise the views); slot 0 is the exchanged buffer
+    stream_flats = [flat_grads] + [torch.zeros_like(flat_grads) for _ in range(max(args.streams, 1) - 1)]
+    stream_leaves = [make_leaves(f) for f in stream_flats]
+
+    def run_views(view_list, collect=False):
+        for g0 in range(0, len(view_list), G):
+            if args.mode == "raster":
+                step_raster(view_list[g0], collect)
+                continue
+            for f in stream_flats[:vstreams.n]:
+                f.zero_()
+            vstreams.fork()
+            for j, cam in enumerate(view_list[g0:g0 + G]):
+                vstreams.run(j, step_view, cam, stream_leaves[j % vstreams.n], collect)
+            vstreams.join()
+            for f in stream_flats[1:vstreams.n]:
+                flat_grads.add_(f)
+            if world > 1:
+                dist.all_reduce(flat_grads)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(Wm):
-        step(my_cams[i])
+    run_views(my_cams[:Wm])
     barrier()
     t0 = time.perf_counter()
-    for i in range(K):
-        step(my_cams[Wm + i])
+    run_views(my_cams[Wm:Wm + K])
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
@@ -183,14 +212,27 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # the reference's schedule for comparison: one view at a time, one stream (latency of a single view's hot path)
+    serial_ms = None
+    if args.mode == "view" and (vstreams.n > 1 or G > 1):
+        keep_s, keep_G = vstreams, G
+        vstreams, G = ViewStreams(1), 1
+        barrier()
+        ts0 = time.perf_counter()
+        run_views(my_cams[Wm:Wm + K])
+        barrier()
+        serial_ms = (time.perf_counter() - ts0) / K * 1e3
+        vstreams, G = keep_s, keep_G
+
     # ---------------------------------------------------------------- per-kernel times (HIP events on the launch stream)
     kernel_ms = {}
     if not args.no_kernel_times and rank == 0:
         lib.cgs_prof_reset()
         lib.cgs_prof_enable(1)
         n_prof = min(K, 16)
-        for i in range(n_prof):
-            step(my_cams[Wm + i], collect=True)
+        vstreams, keep = ViewStreams(1), vstreams   # serial views: per-kernel event times must not overlap
+        run_views(my_cams[Wm:Wm + n_prof], collect=True)
+        vstreams = keep
         torch.cuda.synchronize()
         lib.cgs_prof_enable(0)
         for name, (ms, n) in L.prof_collect().items():
@@ -224,8 +266,11 @@ def main():
                    "mode": args.mode,
                    "splats": P, "curves": B, "width": W, "height": H, "tiles": tiles,
                    "instances_per_view_R": round(R_mean, 1), "visible_per_view": round(vis_mean, 1),
-                   "views_per_rank": K, "parallelism": f"view-parallel x{world}"},
+                   "views_per_rank": K, "views_per_step_per_rank": G, "views_in_flight_per_gpu": vstreams.n,
+                   "parallelism": f"view-parallel x{world}"},
     }
+    if serial_ms is not None:
+        out["serial_view_ms"] = round(serial_ms, 4)   # one view in flight, all-reduce after every view
     if kernel_ms:
         alg_view = algorithmic_bytes(P, R_mean, H, W)
         dom = max(kernel_ms, key=kernel_ms.get)

@@ -540,18 +540,50 @@ int cgs_edge_aware_loss(int channels, int height, int width, const float* image,
     return CGS_OK;
 }
 
-int cgs_adam_step_flat(int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+size_t cgs_photometric_workspace_bytes(int height, int width) {
+    return photometric_workspace_bytes(height > 0 ? height : 1, width > 0 ? width : 1);
+}
+int cgs_edge_count(int channels, int height, int width, const float* gt, float threshold, uint32_t* n_pos, void* stream_) {
+    if (channels <= 0 || height <= 0 || width <= 0 || !gt || !n_pos) {
+        set_error("cgs_edge_count: invalid argument");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    hipStream_t s = (hipStream_t)stream_;
+    if (hipMemsetAsync(n_pos, 0, sizeof(uint32_t), s) != hipSuccess) {
+        set_error("cgs_edge_count: hipMemsetAsync failed");
+        return CGS_ERR_HIP;
+    }
+    launch_edge_count(s, channels, height * width, gt, threshold, n_pos);
+    if (!check_launch("edge_count", false, s)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
+int cgs_photometric_loss(int height, int width, const float* image, const float* gt, float threshold,
+                         const uint32_t* n_pos, float lambda_edge, float lambda_ssim, int clamp_input, void* workspace,
+                         float* dL_dimage, float* loss, void* stream_) {
+    if (height <= 0 || width <= 0 || !image || !gt || !n_pos || !workspace || !dL_dimage || !loss) {
+        set_error("cgs_photometric_loss: invalid argument");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    hipStream_t s = (hipStream_t)stream_;
+    launch_photometric_loss(s, height, width, image, gt, threshold, n_pos, lambda_edge, lambda_ssim, clamp_input, workspace,
+                            dL_dimage, loss);
+    if (!check_launch("photometric_loss", false, s)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
+
+int cgs_adam_step_flat(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                        const void* segments, int n_segments, float beta1, float beta2, float eps, int step,
-                       void* stream_) {
+                       int zero_grads, void* stream_) {
     if (n == 0) return CGS_OK;
-    if (n < 0 || !params || !grads || !exp_avg || !exp_avg_sq || !segments || n_segments <= 0 || step <= 0) {
+    if (n < 0 || !params || !grads || !exp_avg || !exp_avg_sq || !segments || n_segments <= 0 ||
+        n_segments > adam_max_segments() || step <= 0) {
         set_error("cgs_adam_step_flat: invalid argument");
         return CGS_ERR_INVALID_ARGUMENT;
     }
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     launch_adam_flat((hipStream_t)stream_, (long long)n, params, grads, exp_avg, exp_avg_sq, segments, n_segments, beta1,
-                     beta2, eps, (float)bc1, (float)sqrt(bc2));
+                     beta2, eps, (float)bc1, (float)sqrt(bc2), zero_grads);
     if (!check_launch("adam_step_flat", false, (hipStream_t)stream_)) return CGS_ERR_HIP;
     return CGS_OK;
 }

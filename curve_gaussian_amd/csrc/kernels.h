@@ -71,10 +71,16 @@ void launch_ssim_bwd(hipStream_t s, int planes, int H, int W, const float* img1,
                      const float* dL_dmap, const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
                      float* dL_dimg1);
 // loss.hip  (scratch16: 16 zeroed bytes = {u32 n_pos, pad, f64 loss_sum})
+size_t photometric_workspace_bytes(int H, int W);
+void launch_photometric_loss(hipStream_t s, int H, int W, const float* image, const float* gt, float thr,
+                             const unsigned int* n_pos, float lambda_a, float lambda_b, int clamp, void* workspace,
+                             float* grad, float* loss);
+void launch_edge_count(hipStream_t s, int C, int HW, const float* gt, float thr, unsigned int* n_pos);
 void launch_edge_aware_loss(hipStream_t s, int C, int H, int W, const float* image, const float* gt, float thr,
                             void* scratch16, float* grad);
-void launch_adam_flat(hipStream_t s, long long n, float* p, const float* g, float* m, float* v, const void* segs, int nseg,
-                      float b1, float b2, float eps, float bc1, float sqrt_bc2);
+int adam_max_segments();
+void launch_adam_flat(hipStream_t s, long long n, float* p, float* g, float* m, float* v, const void* host_segs, int nseg,
+                      float b1, float b2, float eps, float bc1, float sqrt_bc2, int zero_grad);
 // knn.hip
 size_t knn_workspace_bytes(int P);
 void launch_knn(hipStream_t s, int P, const float* pts, float* dists, void* workspace);

@@ -4,6 +4,7 @@
 //   k_edge_loss  : loss = mean_{c,y,x} (image - gt)^2 * w(y,x),  w = 5 (n_neg+1)/N if edge else (n_pos+1)/N, N = H W
 //                  and d loss / d image in the same pass.
 #include <algorithm>
+#include <cstring>
 
 #include "kernels.h"
 
@@ -63,6 +64,11 @@ __global__ void __launch_bounds__(256) k_edge_loss(int C, int HW, const float* _
     if (threadIdx.x == 0) atomicAdd(loss_sum, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
 }
 
+void launch_edge_count(hipStream_t s, int C, int HW, const float* gt, float thr, unsigned int* n_pos) {
+    ProfScope p("edge_count", s);
+    const int blocks = std::min((HW + 255) / 256, 256);
+    hipLaunchKernelGGL(k_edge_count, dim3(blocks), dim3(256), 0, s, C, HW, gt, thr, n_pos);
+}
 void launch_edge_aware_loss(hipStream_t s, int C, int H, int W, const float* image, const float* gt, float thr,
                             void* scratch16, float* grad) {
     const int HW = H * W;
@@ -78,15 +84,22 @@ void launch_edge_aware_loss(hipStream_t s, int C, int H, int W, const float* ima
 // rates -- the reference steps 6 parameter groups with ~8 foreach kernels each (GaussianCurveModel.training_setup,
 // scene/gaussian_curve_model.py:200-213; train.py:235); here it is one launch.
 //   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// The segment table travels BY VALUE in the kernel arguments: learning rates change every iteration (exponential
+// schedule of the curve points, update_learning_rate :234-244) and a device-side table would need a host-to-device
+// copy -- a stream-blocking hipMemcpy from pageable memory -- per step.
+constexpr int ADAM_MAX_SEGS = 16;
 struct AdamSeg { long long begin; float lr; float pad; };
-__global__ void __launch_bounds__(256) k_adam_flat(long long n, float* __restrict__ p, const float* __restrict__ g,
-                                                   float* __restrict__ m, float* __restrict__ v,
-                                                   const AdamSeg* __restrict__ segs, int nseg, float b1, float b2,
-                                                   float eps, float bc1, float sqrt_bc2) {
+struct AdamSegTable { AdamSeg s[ADAM_MAX_SEGS]; };
+__global__ void __launch_bounds__(256) k_adam_flat(long long n, float* __restrict__ p, float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, AdamSegTable segs,
+                                                   int nseg, float b1, float b2, float eps, float bc1, float sqrt_bc2,
+                                                   int zero_grad) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        float lr = segs[0].lr;
-        for (int s = 1; s < nseg; s++) lr = i >= segs[s].begin ? segs[s].lr : lr;
+        float lr = segs.s[0].lr;
+#pragma unroll
+        for (int s = 1; s < ADAM_MAX_SEGS; s++) lr = (s < nseg && i >= segs.s[s].begin) ? segs.s[s].lr : lr;
         const float gi = g[i];
+        if (zero_grad) g[i] = 0.f;  // optimizer.zero_grad() folded in (grads stay allocated: views of the flat buffer)
         const float mi = m[i] + (gi - m[i]) * (1.f - b1);          // torch: exp_avg.lerp_(grad, 1 - beta1)
         const float vi = v[i] * b2 + (1.f - b2) * gi * gi;          // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
         m[i] = mi;
@@ -95,12 +108,15 @@ __global__ void __launch_bounds__(256) k_adam_flat(long long n, float* __restric
         p[i] = p[i] - (lr / bc1) * (mi / denom);
     }
 }
-void launch_adam_flat(hipStream_t s, long long n, float* p, const float* g, float* m, float* v, const void* segs, int nseg,
-                      float b1, float b2, float eps, float bc1, float sqrt_bc2) {
+int adam_max_segments() { return ADAM_MAX_SEGS; }
+void launch_adam_flat(hipStream_t s, long long n, float* p, float* g, float* m, float* v, const void* host_segs, int nseg,
+                      float b1, float b2, float eps, float bc1, float sqrt_bc2, int zero_grad) {
     ProfScope pr("adam_flat", s);
+    AdamSegTable t{};
+    memcpy(t.s, host_segs, sizeof(AdamSeg) * (size_t)nseg);
     const int blocks = (int)std::min<long long>((n + 255) / 256, 2048);
-    hipLaunchKernelGGL(k_adam_flat, dim3(blocks), dim3(256), 0, s, n, p, g, m, v, reinterpret_cast<const AdamSeg*>(segs),
-                       nseg, b1, b2, eps, bc1, sqrt_bc2);
+    hipLaunchKernelGGL(k_adam_flat, dim3(blocks), dim3(256), 0, s, n, p, g, m, v, t, nseg, b1, b2, eps, bc1, sqrt_bc2,
+                       zero_grad);
 }
 
 }  // namespace cgs

@@ -22,10 +22,37 @@ __device__ __forceinline__ float pix_or_zero(const float* __restrict__ img, int 
     return (x >= W || y >= H || x < 0 || y < 0) ? 0.0f : img[(size_t)y * W + x];  // ssim.cu:36-42
 }
 
+// Training-step fusion (cgs_photometric_loss): FUSED = true additionally
+//   forward : clamps img1 to [0,1] on load (render().clamp(0,1), gaussian_renderer/__init__.py:138), skips the
+//             ssim_map store and accumulates SUM ssim_map into 64 partial f64 slots (fused_ssim(...).mean());
+//   backward: uses a constant dL/dmap, adds the edge_aware_loss gradient (utils/loss_utils.py:94-115) in the epilogue,
+//             accumulates its value, and applies the clamp's gradient mask -- one store of d loss / d image.
+constexpr int PHOTO_SLOTS = 64;
+struct PhotoArgs {
+    int clamp;                 // img1 is the UNclamped render: clamp on load, mask the gradient
+    float dmap_const;          // d loss / d ssim_map (constant): -lambda_b / N
+    float edge_scale;          // lambda_a * 2 / N
+    float thr;                 // edge threshold on gt
+    const unsigned int* n_pos; // #{gt > thr} (device scalar, cached per gt image)
+    double* ssim_slots;        // [PHOTO_SLOTS]
+    double* edge_slots;        // [PHOTO_SLOTS]
+};
+__device__ __forceinline__ void block_sum_to_slot(float v, double* slots) {
+    __shared__ float s_w[4];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicAdd(&slots[(blockIdx.x + blockIdx.y * gridDim.x) % PHOTO_SLOTS], (double)s_w[0] + (double)s_w[1] + (double)s_w[2] + (double)s_w[3]);
+}
+__device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
+
+template <bool FUSED>
 __global__ void __launch_bounds__(256) k_ssim_fwd(int H, int W, float C1, float C2, const float* __restrict__ img1,
                                                   const float* __restrict__ img2, float* __restrict__ ssim_map,
                                                   float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq,
-                                                  float* __restrict__ dm_dsigma12) {
+                                                  float* __restrict__ dm_dsigma12, PhotoArgs pa) {
     __shared__ float s1[SSY][SSX + 1];
     __shared__ float s2[SSY][SSX + 1];
     __shared__ float hq[5][SSY][STX + 1];
@@ -36,7 +63,8 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(int H, int W, float C1, float 
     const int tid = threadIdx.x;
     for (int t = tid; t < SSY * SSX; t += 256) {
         const int ly = t / SSX, lx = t - ly * SSX;
-        s1[ly][lx] = pix_or_zero(p1, y0 + ly - SR, x0 + lx - SR, H, W);
+        const float v1 = pix_or_zero(p1, y0 + ly - SR, x0 + lx - SR, H, W);
+        s1[ly][lx] = (FUSED && pa.clamp) ? clamp01(v1) : v1;
         s2[ly][lx] = pix_or_zero(p2, y0 + ly - SR, x0 + lx - SR, H, W);
     }
     __syncthreads();
@@ -53,6 +81,7 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(int H, int W, float C1, float 
     }
     __syncthreads();
     // vertical pass + SSIM
+    float ssim_acc = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int oy = ty + 8 * j;
@@ -70,7 +99,8 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(int H, int W, float C1, float 
             const float C = 2.0f * mu1_mu2 + C1, D = 2.0f * sigma12 + C2;
             const float A = mu1_sq + mu2_sq + C1, B = sigma1_sq + sigma2_sq + C2;
             const size_t o = plane + (size_t)py * W + px;
-            ssim_map[o] = (C * D) / (A * B);
+            const float val = (C * D) / (A * B);
+            if (FUSED) ssim_acc += val; else ssim_map[o] = val;
             if (dm_dmu1) {  // ssim.cu:274-283
                 dm_dmu1[o] = (mu2 * 2.0f * D) / (A * B) - (mu2 * 2.0f * C) / (A * B) - (mu1 * 2.0f * C * D) / (A * A * B) +
                              (mu1 * 2.0f * C * D) / (A * B * B);
@@ -79,14 +109,17 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(int H, int W, float C1, float 
             }
         }
     }
+    if (FUSED) block_sum_to_slot(ssim_acc, pa.ssim_slots);
 }
 
 // dL/dimg1 = G*(dL_dmap dm_dmu1) + 2 img1 G*(dL_dmap dm_dsigma1_sq) + img2 G*(dL_dmap dm_dsigma12)   (ssim.cu:315-365)
+template <bool FUSED>
 __global__ void __launch_bounds__(256) k_ssim_bwd(int H, int W, const float* __restrict__ img1,
                                                   const float* __restrict__ img2, const float* __restrict__ dL_dmap,
                                                   const float* __restrict__ dm_dmu1,
                                                   const float* __restrict__ dm_dsigma1_sq,
-                                                  const float* __restrict__ dm_dsigma12, float* __restrict__ dL_dimg1) {
+                                                  const float* __restrict__ dm_dsigma12, float* __restrict__ dL_dimg1,
+                                                  PhotoArgs pa) {
     __shared__ float s[3][SSY][SSX + 1];
     __shared__ float hq[3][SSY][STX + 1];
     const size_t plane = (size_t)blockIdx.z * H * W;
@@ -98,7 +131,7 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(int H, int W, const float* __r
         float a = 0.f, b = 0.f, c = 0.f;
         if (x >= 0 && y >= 0 && x < W && y < H) {
             const size_t o = plane + (size_t)y * W + x;
-            const float g = dL_dmap[o];
+            const float g = FUSED ? pa.dmap_const : dL_dmap[o];
             a = dm_dmu1[o] * g; b = dm_dsigma1_sq[o] * g; c = dm_dsigma12[o] * g;
         }
         s[0][ly][lx] = a; s[1][ly][lx] = b; s[2][ly][lx] = c;
@@ -115,6 +148,12 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(int H, int W, const float* __r
         hq[0][r][tx] = a; hq[1][r][tx] = b; hq[2][r][tx] = c;
     }
     __syncthreads();
+    float w_pos = 0.f, w_neg = 0.f, edge_acc = 0.f;
+    if (FUSED) {  // loss_utils.py:100-108 (weights from the class balance of the gt edge mask)
+        const float n_pos = (float)(*pa.n_pos), n_neg = (float)H * (float)W - n_pos;
+        w_pos = 5.f * (n_neg + 1.f) / (n_pos + n_neg);
+        w_neg = 1.0f * (n_pos + 1.f) / (n_pos + n_neg);
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int oy = ty + 8 * j;
@@ -127,26 +166,77 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(int H, int W, const float* __r
         const int px = x0 + tx, py = y0 + oy;
         if (px < W && py < H) {
             const size_t o = plane + (size_t)py * W + px;
+            const float x = img1[o], y = img2[o];
+            const float xc = (FUSED && pa.clamp) ? clamp01(x) : x;
             float dL = a;
-            dL += img1[o] * 2.0f * b;
-            dL += img2[o] * c;
+            dL += xc * 2.0f * b;
+            dL += y * c;
+            if (FUSED) {
+                const float d = xc - y, w = y > pa.thr ? w_pos : w_neg;
+                edge_acc += d * d * w;
+                dL += pa.edge_scale * d * w;
+                if (pa.clamp && (x < 0.f || x > 1.f)) dL = 0.f;  // clamp backward: gradient only where 0 <= x <= 1
+            }
             dL_dimg1[o] = dL;
         }
     }
+    if (FUSED) block_sum_to_slot(edge_acc, pa.edge_slots);
+}
+
+// loss = lambda_a * edge_sum / N + lambda_b * (1 - ssim_sum / N); the slots are cleared for the next call
+__global__ void __launch_bounds__(64) k_photo_finish(double* __restrict__ ssim_slots, double* __restrict__ edge_slots,
+                                                     float lambda_a, float lambda_b, double inv_n,
+                                                     float* __restrict__ loss) {
+    double s = ssim_slots[threadIdx.x], e = edge_slots[threadIdx.x];
+    ssim_slots[threadIdx.x] = 0.0;
+    edge_slots[threadIdx.x] = 0.0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        s += __shfl_xor(s, off, 64);
+        e += __shfl_xor(e, off, 64);
+    }
+    if (threadIdx.x == 0) *loss = (float)((double)lambda_a * e * inv_n + (double)lambda_b - (double)lambda_b * s * inv_n);
 }
 
 void launch_ssim_fwd(hipStream_t s, int planes, int H, int W, float C1, float C2, const float* img1, const float* img2,
                      float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12) {
     ProfScope p("ssim_fwd", s);
-    hipLaunchKernelGGL(k_ssim_fwd, dim3((W + STX - 1) / STX, (H + STY - 1) / STY, planes), dim3(256), 0, s, H, W, C1, C2,
-                       img1, img2, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12);
+    hipLaunchKernelGGL(k_ssim_fwd<false>, dim3((W + STX - 1) / STX, (H + STY - 1) / STY, planes), dim3(256), 0, s, H, W,
+                       C1, C2, img1, img2, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, PhotoArgs{});
 }
 void launch_ssim_bwd(hipStream_t s, int planes, int H, int W, const float* img1, const float* img2,
                      const float* dL_dmap, const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
                      float* dL_dimg1) {
     ProfScope p("ssim_bwd", s);
-    hipLaunchKernelGGL(k_ssim_bwd, dim3((W + STX - 1) / STX, (H + STY - 1) / STY, planes), dim3(256), 0, s, H, W, img1,
-                       img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1);
+    hipLaunchKernelGGL(k_ssim_bwd<false>, dim3((W + STX - 1) / STX, (H + STY - 1) / STY, planes), dim3(256), 0, s, H, W,
+                       img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1, PhotoArgs{});
+}
+
+// workspace: [3 * H*W floats: dm_dmu1, dm_dsigma1_sq, dm_dsigma12][2 * PHOTO_SLOTS doubles, zero on first use]
+size_t photometric_workspace_bytes(int H, int W) {
+    return (((size_t)3 * H * W * sizeof(float) + 127) & ~(size_t)127) + 2 * PHOTO_SLOTS * sizeof(double);
+}
+void launch_photometric_loss(hipStream_t s, int H, int W, const float* image, const float* gt, float thr,
+                             const unsigned int* n_pos, float lambda_a, float lambda_b, int clamp, void* workspace,
+                             float* grad, float* loss) {
+    const size_t N = (size_t)H * W;
+    float* dm1 = reinterpret_cast<float*>(workspace);
+    float* dm2 = dm1 + N;
+    float* dm3 = dm2 + N;
+    double* slots = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + ((3 * N * sizeof(float) + 127) & ~(size_t)127));
+    PhotoArgs pa;
+    pa.clamp = clamp;
+    pa.dmap_const = -lambda_b / (float)N;
+    pa.edge_scale = lambda_a * 2.f / (float)N;
+    pa.thr = thr;
+    pa.n_pos = n_pos;
+    pa.ssim_slots = slots;
+    pa.edge_slots = slots + PHOTO_SLOTS;
+    const dim3 grid((W + STX - 1) / STX, (H + STY - 1) / STY, 1);
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;  // fused_ssim/__init__.py: C1 = 0.01**2, C2 = 0.03**2
+    { ProfScope p("ssim_fwd", s); hipLaunchKernelGGL(k_ssim_fwd<true>, grid, dim3(256), 0, s, H, W, C1, C2, image, gt, nullptr, dm1, dm2, dm3, pa); }
+    { ProfScope p("ssim_bwd", s); hipLaunchKernelGGL(k_ssim_bwd<true>, grid, dim3(256), 0, s, H, W, image, gt, nullptr, dm1, dm2, dm3, grad, pa); }
+    { ProfScope p("photo_finish", s); hipLaunchKernelGGL(k_photo_finish, dim3(1), dim3(64), 0, s, pa.ssim_slots, pa.edge_slots, lambda_a, lambda_b, 1.0 / (double)N, loss); }
 }
 
 }  // namespace cgs

@@ -39,15 +39,34 @@ def edge_aware_loss(image, gt_image, threshold=0.1):
     return _EdgeAwareLoss.apply(image, gt_image, threshold)
 
 
+class _EdgeCountCache:
+    """#{gt > threshold} depends on the gt edge map only; the reference recomputes it every iteration
+    (loss_utils.py:100-103).  One device scalar per (gt storage, version, threshold), computed on first use."""
+    _cache = {}
+
+    @classmethod
+    def get(cls, gt, threshold, stream):
+        key = (gt.data_ptr(), gt._version, tuple(gt.shape), float(threshold), str(gt.device))
+        hit = cls._cache.get(key)
+        if hit is None:
+            if len(cls._cache) > 4096:
+                cls._cache.clear()
+            n_pos = torch.empty(1, dtype=torch.int32, device=gt.device)
+            Cn, H, W = gt.shape
+            rc = L.load().cgs_edge_count(Cn, H, W, L.ptr(gt), C.c_float(threshold), L.ptr(n_pos), stream)
+            L.check(rc, "cgs_edge_count")
+            hit = cls._cache[key] = (n_pos, gt)   # keep gt alive so the data_ptr key cannot be recycled
+        return hit[0]
+
+
 class _PhotometricLoss(torch.autograd.Function):
-    """loss = lambda_mse * ((1 - lambda_dssim) * edge_aware_loss(image, gt) + lambda_dssim * (1 - fused_ssim(image, gt)))
-    (train.py:101-107) with value and d loss / d image produced in one forward: two loss kernels + the two SSIM kernels +
-    one mean + one add, instead of ~25 scalar / elementwise kernels and their autograd graph."""
-    _const_cache = {}
+    """loss = lambda_mse * ((1 - lambda_dssim) * edge_aware_loss(x, gt) + lambda_dssim * (1 - fused_ssim(x, gt))),
+    x = clamp(image, 0, 1) if clamp else image (train.py:101-107 + render()'s clamp), value and d loss / d image from
+    cgs_photometric_loss: three kernels instead of ~30 elementwise / reduction launches and their autograd graph."""
+    _workspaces = {}
 
     @staticmethod
-    def forward(ctx, image, gt_image, lambda_mse, lambda_dssim, threshold):
-        from ..fused_ssim import fusedssim, fusedssim_backward
+    def forward(ctx, image, gt_image, lambda_mse, lambda_dssim, threshold, clamp):
         L.require_gpu_tensor(image, "image")
         lib = L.load()
         dev = image.device
@@ -55,34 +74,32 @@ class _PhotometricLoss(torch.autograd.Function):
             img = image.detach().float().contiguous()
             gt = gt_image.detach().float().contiguous()
             Cn, H, W = img.shape
-            n = float(Cn * H * W)
-            scratch = torch.empty(2, dtype=torch.float64, device=dev)
-            g_edge = torch.empty_like(img)
-            rc = lib.cgs_edge_aware_loss(Cn, H, W, L.ptr(img), L.ptr(gt), C.c_float(threshold), L.ptr(scratch),
-                                         L.ptr(g_edge), torch.cuda.current_stream(dev).cuda_stream)
-            L.check(rc, "cgs_edge_aware_loss")
-            C1, C2 = 0.01 ** 2, 0.03 ** 2
-            i4, g4 = img.unsqueeze(0), gt.unsqueeze(0)
-            ssim_map, dm1, dm2, dm3 = fusedssim(C1, C2, i4, g4, True)
+            if Cn != 1:
+                raise L.CurveGSError("photometric_loss: the fused path renders 1 channel (got %d)" % Cn)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            n_pos = _EdgeCountCache.get(gt, threshold, stream)
+            key = (str(dev), H, W, stream)
+            ws = _PhotometricLoss._workspaces.get(key)
+            if ws is None:
+                ws = _PhotometricLoss._workspaces[key] = torch.zeros(
+                    int(lib.cgs_photometric_workspace_bytes(H, W)), dtype=torch.uint8, device=dev)
+            grad = torch.empty_like(img)
+            loss = torch.empty((), dtype=torch.float32, device=dev)
             a = lambda_mse * (1.0 - lambda_dssim)
             b = lambda_mse * lambda_dssim
-            key = (str(dev), Cn, H, W, b)
-            cmap = _PhotometricLoss._const_cache.get(key)
-            if cmap is None:    # d(b (1 - mean ssim)) / d ssim_map = -b / N everywhere (constant, cached)
-                cmap = torch.full((1, Cn, H, W), -b / n, dtype=torch.float32, device=dev)
-                _PhotometricLoss._const_cache = {key: cmap}
-            g_ssim = fusedssim_backward(C1, C2, i4, g4, cmap, dm1, dm2, dm3)
-            grad = torch.add(g_ssim.squeeze(0), g_edge, alpha=a)
-            loss = (scratch[1] * (a / n) + b - b * ssim_map.mean(dtype=torch.float64)).float()
+            rc = lib.cgs_photometric_loss(H, W, L.ptr(img), L.ptr(gt), C.c_float(threshold), L.ptr(n_pos), C.c_float(a),
+                                          C.c_float(b), 1 if clamp else 0, L.ptr(ws), L.ptr(grad), L.ptr(loss), stream)
+            L.check(rc, "cgs_photometric_loss")
         ctx.save_for_backward(grad)
         return loss
 
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
-        return grad * g, None, None, None, None
+        return grad * g, None, None, None, None, None
 
 
-def photometric_loss(image, gt_image, lambda_mse=10.0, lambda_dssim=0.1, threshold=0.1):
-    """image, gt_image: [C,H,W].  Same value/gradient as composing edge_aware_loss and fused_ssim (tested)."""
-    return _PhotometricLoss.apply(image, gt_image, lambda_mse, lambda_dssim, threshold)
+def photometric_loss(image, gt_image, lambda_mse=10.0, lambda_dssim=0.1, threshold=0.1, clamp=False):
+    """image, gt_image: [1,H,W].  Same value/gradient as composing (clamp,) edge_aware_loss and fused_ssim (tested).
+    clamp=True takes the UNclamped rasterizer output and applies render()'s clamp(0,1) inside the kernels."""
+    return _PhotometricLoss.apply(image, gt_image, lambda_mse, lambda_dssim, threshold, clamp)

@@ -35,25 +35,22 @@ class FlatAdam:
         self.betas, self.eps = betas, eps
         self.step_count = 0
         self.param_groups = [{"name": nm, "lr": float(lrs[nm]), "params": [named_params[nm]]} for nm in self.names]
-        self._seg_dev = torch.empty(len(self.names) * 16, dtype=torch.uint8, device=self.device)
-        self._seg_host = None
-        self._sync_segments()
 
-    def _sync_segments(self):
-        blob = b"".join(struct.pack("<qff", self.grads.slices[g["name"]][0], float(g["lr"]), 0.0) for g in self.param_groups)
-        if blob != self._seg_host:
-            self._seg_host = blob
-            self._seg_dev.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8), non_blocking=False)
+    def _segments(self):
+        """Host-side {begin, lr} table, rebuilt every step: learning rates may have been changed through param_groups
+        (update_learning_rate).  It is passed to the kernel by value -- no host-to-device copy, no stream sync."""
+        return b"".join(struct.pack("<qff", self.grads.slices[g["name"]][0], float(g["lr"]), 0.0) for g in self.param_groups)
 
-    def step(self):
-        self._sync_segments()   # learning rates may have been changed through param_groups (update_learning_rate)
+    def step(self, zero_grad=False):
+        """One Adam step over all groups; zero_grad=True also clears the flat gradient buffer in the same kernel."""
         self.step_count += 1
         lib = L.load()
         with torch.cuda.device(self.device):
             rc = lib.cgs_adam_step_flat(self.flat.numel(), L.ptr(self.flat), L.ptr(self.grads.flat), L.ptr(self.exp_avg),
-                                        L.ptr(self.exp_avg_sq), L.ptr(self._seg_dev), len(self.param_groups),
+                                        L.ptr(self.exp_avg_sq), self._segments(), len(self.param_groups),
                                         C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
-                                        self.step_count, torch.cuda.current_stream(self.device).cuda_stream)
+                                        self.step_count, 1 if zero_grad else 0,
+                                        torch.cuda.current_stream(self.device).cuda_stream)
         L.check(rc, "cgs_adam_step_flat")
 
     def zero_grad(self, set_to_none=False):

@@ -52,10 +52,10 @@ class TrainStep:
         cam, gt = self.cams[vi], self.gts[vi]
         use_mask = it >= self.densify_until_iter
         pkg = render(cam, g, self.pipe, self.bg, use_mask=use_mask, mask_thr=self.mask_threshold,
-                     compute_visibility=not self.fused)
+                     compute_visibility=not self.fused, clamp=not self.fused, compute_rend_dir=not self.fused)
         image = pkg["render"]
-        if self.fused:
-            loss = photometric_loss(image, gt[:1], self.lambda_mse, self.lambda_dssim)
+        if self.fused:   # raw composite in, render()'s clamp applied inside the loss kernels
+            loss = photometric_loss(image, gt[:1], self.lambda_mse, self.lambda_dssim, clamp=True)
         else:
             Ll1 = edge_aware_loss(image, gt[:1])
             ssim_value = fused_ssim(image.unsqueeze(0), gt[:1].unsqueeze(0))
@@ -64,7 +64,10 @@ class TrainStep:
             loss = loss + self.lambda_mask * torch.mean(torch.sigmoid(g._mask))
         loss.backward()
         self.flat.all_reduce()
-        g.optimizer.step()
-        self.flat.zero_()                          # grads are views of the flat buffer: keep them, zero in place
+        if self.fused:
+            g.optimizer.step(zero_grad=True)       # Adam + zero_grad in one launch
+        else:
+            g.optimizer.step()
+            self.flat.zero_()                      # grads are views of the flat buffer: keep them, zero in place
         g.prepare_scaling_rot()                    # train.py:242-243
         return loss.detach(), pkg

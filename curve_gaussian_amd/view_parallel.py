@@ -17,6 +17,37 @@ def shard_views(n_views: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_views, world))
 
 
+class ViewStreams:
+    """Keeps several independent views in flight on one GPU by rotating them over `n` HIP streams.
+
+    The per-view pipeline alternates latency-bound kernels (curve sampling, preprocess, scatter, tile sort: dependent
+    memory round trips and atomics) with VALU-bound ones (forward/backward compositing); views are independent
+    (BASELINE north_star), so running view i+1's binning under view i's compositing fills both.  Gradients of
+    all views of a step accumulate into the same ``.grad`` buffers (autograd serialises the accumulation), exactly
+    like the views of the other ranks do through the all-reduce.  `fork()` / `join()` order the streams against
+    the caller's current stream with events only -- the host never blocks."""
+
+    def __init__(self, n: int, device=None):
+        self.n = max(1, int(n))
+        self.streams = [torch.cuda.Stream(device) for _ in range(self.n)] if self.n > 1 else []
+
+    def fork(self):
+        cur = torch.cuda.current_stream()
+        for st in self.streams:
+            st.wait_stream(cur)
+
+    def run(self, i: int, fn, *args, **kw):
+        if not self.streams:
+            return fn(*args, **kw)
+        with torch.cuda.stream(self.streams[i % self.n]):
+            return fn(*args, **kw)
+
+    def join(self):
+        cur = torch.cuda.current_stream()
+        for st in self.streams:
+            cur.wait_stream(st)
+
+
 class FlatGrads:
     """Owns the flat gradient buffer and installs views of it as the ``.grad`` of the given parameters."""
 

@@ -182,13 +182,29 @@ int cgs_ssim_backward(int batch, int channels, int height, int width, float C1, 
 int cgs_edge_aware_loss(int channels, int height, int width, const float* image, const float* gt, float threshold,
                         void* scratch16, float* dL_dimage, void* stream);
 
+/* The photometric part of the training loss (train.py:101-107) for a 1-channel render, value and gradient in ONE
+ * pass of three kernels (SSIM forward, SSIM backward + edge-loss/clamp epilogue, scalar finish):
+ *   loss = lambda_edge * edge_aware_loss(x, gt, threshold) + lambda_ssim * (1 - fused_ssim(x, gt)),
+ *   x = clamp_input ? clamp(image, 0, 1) : image          (render()'s clamp, gaussian_renderer/__init__.py:138)
+ * with lambda_edge = lambda_mse (1 - lambda_dssim), lambda_ssim = lambda_mse lambda_dssim in train.py's notation.
+ * n_pos: device u32 = #{gt > threshold}, from cgs_edge_count (depends on gt only: compute once per gt image).
+ * workspace: cgs_photometric_workspace_bytes(H, W) bytes, zero-filled before its FIRST use, then reusable as is.
+ * Outputs: dL_dimage [H*W] = d loss / d image (0 where the clamp is active), loss [1]. */
+size_t cgs_photometric_workspace_bytes(int height, int width);
+int cgs_edge_count(int channels, int height, int width, const float* gt, float threshold, uint32_t* n_pos, void* stream);
+int cgs_photometric_loss(int height, int width, const float* image, const float* gt, float threshold,
+                         const uint32_t* n_pos, float lambda_edge, float lambda_ssim, int clamp_input, void* workspace,
+                         float* dL_dimage, float* loss, void* stream);
+
 /* One-launch Adam over a flat parameter buffer (torch.optim.Adam semantics: no weight decay, no amsgrad), replacing
  * the per-group foreach step of the reference (scene/gaussian_curve_model.py:200-213, train.py:235).
- * segments: device array of n_segments x {int64 begin; float lr; float pad}, sorted by begin, segments[0].begin == 0;
- * element i uses the lr of the last segment with begin <= i.  step = 1-based step count (bias correction). */
-int cgs_adam_step_flat(int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+ * segments: HOST array of n_segments (<= 16) x {int64 begin; float lr; float pad}, sorted by begin,
+ * segments[0].begin == 0; element i uses the lr of the last segment with begin <= i (the table is passed to the
+ * kernel by value, so a per-iteration learning-rate change costs no copy).  step = 1-based step count (bias
+ * correction).  zero_grads != 0 also clears grads (optimizer.zero_grad(), train.py:236) in the same pass. */
+int cgs_adam_step_flat(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                        const void* segments, int n_segments, float beta1, float beta2, float eps, int step,
-                       void* stream);
+                       int zero_grads, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * simple-knn.  Replaces distCUDA2 -> SimpleKNN::knn (/root/reference/submodules/simple-knn/spatial.cu:15-26,

@@ -144,23 +144,34 @@ def test_flat_adam_matches_torch_adam():
             ref_p[k].grad = grads[k].clone()
             fg.view(k).copy_(grads[k].to(DEV))
         ref_opt.step()
-        opt.step()
+        opt.step(zero_grad=(it % 2 == 1))
+        assert (float(fg.flat.abs().max()) == 0.0) == (it % 2 == 1)   # zero_grad folded into the Adam launch
     for k in shapes:
         np.testing.assert_allclose(hp[k].detach().cpu().numpy(), ref_p[k].detach().numpy(), rtol=2e-5, atol=1e-7)
         assert hp[k].data_ptr() >= opt.flat.data_ptr()  # parameters are views of the flat buffer
 
 
-def test_photometric_loss_equals_composition():
+@pytest.mark.parametrize("clamp", [False, True])
+def test_photometric_loss_equals_composition(clamp):
+    """cgs_photometric_loss == lambda_mse ((1-l) edge_aware_loss + l (1 - fused_ssim)) composed from the drop-in ops
+    (themselves pinned to reference goldens), with and without render()'s clamp folded in; value, gradient, the clamp's
+    gradient mask, and repeated calls on the same self-cleaning workspace."""
     from curve_gaussian_amd.fused_ssim import fused_ssim
     from curve_gaussian_amd.ops.losses import edge_aware_loss, photometric_loss
     g = torch.Generator().manual_seed(4)
-    img = torch.rand(1, 70, 93, generator=g)
+    img = torch.rand(1, 70, 93, generator=g) * (1.6 if clamp else 1.0) - (0.3 if clamp else 0.0)  # some pixels outside [0,1]
     gt = (torch.rand(1, 70, 93, generator=g) > 0.9).float() * torch.rand(1, 70, 93, generator=g)
+    gt_d = gt.to(DEV)
     a = img.to(DEV).requires_grad_(True)
-    ref = 10.0 * (0.9 * edge_aware_loss(a, gt.to(DEV)) + 0.1 * (1.0 - fused_ssim(a.unsqueeze(0), gt.to(DEV).unsqueeze(0))))
+    x = a.clamp(0, 1) if clamp else a
+    ref = 10.0 * (0.9 * edge_aware_loss(x, gt_d) + 0.1 * (1.0 - fused_ssim(x.unsqueeze(0), gt_d.unsqueeze(0))))
     ref.backward()
-    b = img.to(DEV).requires_grad_(True)
-    val = photometric_loss(b, gt.to(DEV), 10.0, 0.1)
-    (2.0 * val).backward()
-    np.testing.assert_allclose(float(val), float(ref), rtol=1e-5)
-    np.testing.assert_allclose(b.grad.cpu().numpy(), 2.0 * a.grad.cpu().numpy(), rtol=1e-4, atol=1e-9)
+    for rep in range(3):
+        b = img.to(DEV).requires_grad_(True)
+        val = photometric_loss(b, gt_d, 10.0, 0.1, clamp=clamp)
+        (2.0 * val).backward()
+        np.testing.assert_allclose(float(val), float(ref), rtol=1e-5)
+        np.testing.assert_allclose(b.grad.cpu().numpy(), 2.0 * a.grad.cpu().numpy(), rtol=1e-4, atol=1e-9)
+    if clamp:
+        outside = ((img < 0) | (img > 1)).numpy()
+        assert outside.any() and (b.grad.cpu().numpy()[outside] == 0).all()
