@@ -423,7 +423,7 @@ int cgs_sample_curves_forward(int B, int m, const float* curve_points, const flo
         set_error("cgs_sample_curves_forward: invalid argument (NULL or misaligned pointer, B=%d m=%d)", B, m);
         return CGS_ERR_INVALID_ARGUMENT;
     }
-    if (hipMemsetAsync(norms, 0, 4 * sizeof(double), s) != hipSuccess) {
+    if (hipMemsetAsync(norms, 0, (size_t)sample_norm_words() * sizeof(double), s) != hipSuccess) {
         set_error("hipMemsetAsync(norms) failed");
         return CGS_ERR_HIP;
     }
@@ -444,7 +444,7 @@ int cgs_sample_curves_backward(int B, int m, const float* curve_points, const fl
         set_error("cgs_sample_curves_backward: invalid argument");
         return CGS_ERR_INVALID_ARGUMENT;
     }
-    if (hipMemsetAsync(norms + 2, 0, 2 * sizeof(double), s) != hipSuccess) {
+    if (hipMemsetAsync(norms + sample_norm_words() / 2, 0, (size_t)(sample_norm_words() / 2) * sizeof(double), s) != hipSuccess) {
         set_error("hipMemsetAsync(norms) failed");
         return CGS_ERR_HIP;
     }

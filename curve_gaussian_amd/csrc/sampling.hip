@@ -18,7 +18,11 @@
 
 namespace cgs {
 
-constexpr int REDUCE_BLOCKS = 256;  // one workgroup per CU for the grid-wide sums
+// Grid-wide sums: every workgroup adds its partial to one of NORM_SLOTS f64 slots per quantity (same-address f64
+// atomics serialise at ~20 ns each: 782 blocks on one address cost more than the kernels themselves, 49 per slot do
+// not), and every consumer sums the slots while staging its constants.
+constexpr int NORM_SLOTS = 16;
+constexpr int NORM_WORDS = 4 * NORM_SLOTS;  // norms[q * NORM_SLOTS + slot], q = 0: |v1|^2, 1: |v2|^2, 2: D2, 3: D1
 
 struct SampleCoef {  // per-sample coefficients, computed on the host with the reference's float32 torch expressions
     float c[4];      // Bezier point weights at t_i
@@ -61,18 +65,22 @@ __device__ __forceinline__ void stage_consts(const SampleCoef* __restrict__ coef
     const float* src = reinterpret_cast<const float*>(coef);
     float* dst = reinterpret_cast<float*>(s_coef);
     for (int t = threadIdx.x; t < m * 16; t += blockDim.x) dst[t] = src[t];
-    if (threadIdx.x == 0) {
-        s_bc->N1 = (float)sqrt(norms[0]);
-        s_bc->N2 = (float)sqrt(norms[1]);
-        s_bc->D2 = (float)norms[2];
-        s_bc->D1 = (float)norms[3];
+    if (threadIdx.x < 64) {  // wave 0: lane = q * NORM_SLOTS + slot
+        double v = norms[threadIdx.x];
+#pragma unroll
+        for (int off = NORM_SLOTS / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (threadIdx.x == 0 * NORM_SLOTS) s_bc->N1 = (float)sqrt(v);
+        if (threadIdx.x == 1 * NORM_SLOTS) s_bc->N2 = (float)sqrt(v);
+        if (threadIdx.x == 2 * NORM_SLOTS) s_bc->D2 = (float)v;
+        if (threadIdx.x == 3 * NORM_SLOTS) s_bc->D1 = (float)v;
     }
     __syncthreads();
 }
 constexpr int MAX_M = 32;  // samples per curve supported by the LDS table (reference default 12)
 
-// block-wide sum -> one f64 atomic
-__device__ __forceinline__ void block_accumulate(double v, double* target) {
+// block-wide sum -> one f64 atomic on this block's slot of quantity q
+__device__ __forceinline__ void block_accumulate(double v, double* norms, int q) {
+    double* target = norms + q * NORM_SLOTS + (blockIdx.x % NORM_SLOTS);
     __shared__ double s_part[4];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -100,7 +108,7 @@ __global__ void __launch_bounds__(256) k_sample_f1(int B, int m, const float* __
         const V3 t = curve_tangent(c, s_coef[i]);
         acc += (double)(t.y * t.y) + (double)(t.x * t.x);  // |cross(tan,(0,0,1))|^2 = ty^2 + tx^2
     }
-    block_accumulate(acc, &norms[0]);  // <= REDUCE_BLOCKS same-address f64 atomics
+    block_accumulate(acc, norms, 0);
 }
 __global__ void __launch_bounds__(256) k_sample_f2(int B, int m, const float* __restrict__ cp,
                                                    const uint8_t* __restrict__ is_bezier,
@@ -118,10 +126,14 @@ __global__ void __launch_bounds__(256) k_sample_f2(int B, int m, const float* __
         const V3 c2 = cross(t, v1);
         acc += (double)(c2.x * c2.x) + (double)(c2.y * c2.y) + (double)(c2.z * c2.z);
     }
-    block_accumulate(acc, &norms[1]);
+    block_accumulate(acc, norms, 1);
 }
 
 struct QuatFwd { float a[4], qa[4], N[4], D; int k; bool flip; };
+// arr[k] for a runtime k without a runtime-indexed (scratch-resident) array: three selects
+__device__ __forceinline__ float sel4(const float (&arr)[4], int k) {
+    return k == 0 ? arr[0] : (k == 1 ? arr[1] : (k == 2 ? arr[2] : arr[3]));
+}
 // rot_to_quat_batch for one 3x3 (rows m0*, m1*, m2*), utils/general_utils.py:33-86
 __device__ __forceinline__ QuatFwd quat_forward(const float M[3][3], float q[4]) {
     QuatFwd f;
@@ -132,15 +144,20 @@ __device__ __forceinline__ QuatFwd quat_forward(const float M[3][3], float q[4])
     int k = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) f.qa[j] = f.a[j] > 0.f ? sqrtf(f.a[j]) : 0.f;  // _sqrt_positive_part
+    float qak = f.qa[0];
 #pragma unroll
-    for (int j = 1; j < 4; j++) k = f.qa[j] > f.qa[k] ? j : k;                  // argmax, first maximum wins
+    for (int j = 1; j < 4; j++) {                                                 // argmax, first maximum wins
+        const bool gt = f.qa[j] > qak;
+        k = gt ? j : k;
+        qak = gt ? f.qa[j] : qak;
+    }
     f.k = k;
-    const float sq = f.qa[k] * f.qa[k];
+    const float sq = qak * qak;
     if (k == 0) { f.N[0] = sq; f.N[1] = m21 - m12; f.N[2] = m02 - m20; f.N[3] = m10 - m01; }
     else if (k == 1) { f.N[0] = m21 - m12; f.N[1] = sq; f.N[2] = m10 + m01; f.N[3] = m02 + m20; }
     else if (k == 2) { f.N[0] = m02 - m20; f.N[1] = m10 + m01; f.N[2] = sq; f.N[3] = m12 + m21; }
     else { f.N[0] = m10 - m01; f.N[1] = m20 + m02; f.N[2] = m21 + m12; f.N[3] = sq; }
-    f.D = 2.0f * fmaxf(f.qa[k], 0.1f);
+    f.D = 2.0f * fmaxf(qak, 0.1f);
 #pragma unroll
     for (int j = 0; j < 4; j++) q[j] = f.N[j] / f.D;
     f.flip = q[0] < 0.f;  // standardize_quaternion
@@ -161,9 +178,9 @@ __device__ __forceinline__ void quat_backward(const QuatFwd& f, const float g_ou
         gD -= gc[j] * f.N[j] / (f.D * f.D);
     }
     const int k = f.k;
-    const float qak = f.qa[k];
-    const float g_qa = (qak > 0.1f ? 2.f * gD : 0.f) + gN[k] * 2.f * qak;
-    const float g_a = f.a[k] > 0.f ? g_qa / (2.f * qak) : 0.f;
+    const float qak = sel4(f.qa, k);
+    const float g_qa = (qak > 0.1f ? 2.f * gD : 0.f) + sel4(gN, k) * 2.f * qak;
+    const float g_a = sel4(f.a, k) > 0.f ? g_qa / (2.f * qak) : 0.f;
 #pragma unroll
     for (int r = 0; r < 3; r++)
 #pragma unroll
@@ -357,8 +374,8 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_sample_bwd(int B, int m, int c
         }
         break;
     }
-    if (PASS == 1) block_accumulate(acc, &norms[2]);
-    if (PASS == 2) block_accumulate(acc, &norms[3]);
+    if (PASS == 1) block_accumulate(acc, norms, 2);
+    if (PASS == 2) block_accumulate(acc, norms, 3);
     if (PASS == 3) {
         const int t = threadIdx.x;
         s_part[0][t] = gp0.x; s_part[1][t] = gp0.y; s_part[2][t] = gp0.z;
@@ -506,7 +523,7 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_attrs_bwd(
 void launch_sample_forward(hipStream_t s, int B, int m, const float* cp, const float* width, const uint8_t* is_bezier,
                            const void* coef, float eps, double* norms, float* xyz, float* rot, float* scaling) {
     const dim3 grid((B * m + 255) / 256), block(256);
-    const dim3 rgrid(std::min((B * m + 255) / 256, REDUCE_BLOCKS));
+    const dim3 rgrid(std::max((B * m + 255) / 256, 1));
     const SampleCoef* k = reinterpret_cast<const SampleCoef*>(coef);
     { ProfScope p("sample_f1", s); hipLaunchKernelGGL(k_sample_f1, rgrid, block, 0, s, B, m, cp, is_bezier, k, norms); }
     { ProfScope p("sample_f2", s); hipLaunchKernelGGL(k_sample_f2, rgrid, block, 0, s, B, m, cp, is_bezier, k, norms); }
@@ -518,7 +535,7 @@ void launch_sample_backward(hipStream_t s, int B, int m, const float* cp, const 
     const int cpb = SAMPLE_BLOCK / m;  // whole curves per block
     const dim3 grid((B + cpb - 1) / cpb), block(SAMPLE_BLOCK);
     const SampleCoef* k = reinterpret_cast<const SampleCoef*>(coef);
-    const dim3 rgrid(std::min((B * m + SAMPLE_BLOCK - 1) / SAMPLE_BLOCK, REDUCE_BLOCKS));
+    const dim3 rgrid(std::max((B * m + SAMPLE_BLOCK - 1) / SAMPLE_BLOCK, 1));
     { ProfScope p("sample_b1", s); hipLaunchKernelGGL(k_sample_bwd<1>, rgrid, block, 0, s, B, m, cpb, cp, width, is_bezier, k, eps, norms, g_xyz, g_rot, g_scaling, g_cp, g_width, gv_cache); }
     { ProfScope p("sample_b2", s); hipLaunchKernelGGL(k_sample_bwd<2>, rgrid, block, 0, s, B, m, cpb, cp, width, is_bezier, k, eps, norms, g_xyz, g_rot, g_scaling, g_cp, g_width, gv_cache); }
     { ProfScope p("sample_b3", s); hipLaunchKernelGGL(k_sample_bwd<3>, grid, block, 0, s, B, m, cpb, cp, width, is_bezier, k, eps, norms, g_xyz, g_rot, g_scaling, g_cp, g_width, gv_cache); }
@@ -541,5 +558,7 @@ void launch_attrs_backward(hipStream_t s, int B, int m, const float* rot_raw, co
                        mask_thr, scaling, campos, vm, g_rot_n, g_opac, g_scl_out, g_all_map, g_rot_raw, g_opacity_logit,
                        g_mask_logit, g_scaling);
 }
+
+int sample_norm_words() { return NORM_WORDS; }
 
 }  // namespace cgs
