@@ -166,41 +166,95 @@ __device__ __forceinline__ uint2 bucket_range(const uint32_t* __restrict__ tile_
     return make_uint2(base, base + n);
 }
 
+// rank[q] += #{ k in s[0..n) : k < mine[q] }, RANK_U broadcast keys per iteration, the next RANK_U already in flight.
+// s is padded with the maximum value up to a multiple of RANK_U.
+#ifndef CGS_RANK_U
+#define CGS_RANK_U 4
+#endif
+constexpr uint32_t RANK_U = CGS_RANK_U;
+template <int NQ, typename K>
+__device__ __forceinline__ void rank_loop(const K* s, uint32_t n, const K (&mine)[4], uint32_t (&rank)[4]) {
+    const uint32_t nu = (n + RANK_U - 1) / RANK_U * RANK_U;
+    K k[RANK_U], p[RANK_U];
+#pragma unroll
+    for (uint32_t e = 0; e < RANK_U; e++) k[e] = s[e];
+    for (uint32_t u = RANK_U; u < nu; u += RANK_U) {
+#pragma unroll
+        for (uint32_t e = 0; e < RANK_U; e++) p[e] = s[u + e];  // uniform address: LDS broadcast
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+#pragma unroll
+            for (uint32_t e = 0; e < RANK_U; e++) rank[q] += (uint32_t)(k[e] < mine[q]);
+#pragma unroll
+        for (uint32_t e = 0; e < RANK_U; e++) k[e] = p[e];
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+#pragma unroll
+        for (uint32_t e = 0; e < RANK_U; e++) rank[q] += (uint32_t)(k[e] < mine[q]);
+}
+template <typename K>
+__device__ __forceinline__ void rank_dispatch(int nq, const K* s, uint32_t n, const K (&mine)[4], uint32_t (&rank)[4]) {
+    switch (nq) {  // the compare loop is specialised: no per-key branches inside it
+        case 1: rank_loop<1>(s, n, mine, rank); break;
+        case 2: rank_loop<2>(s, n, mine, rank); break;
+        case 3: rank_loop<3>(s, n, mine, rank); break;
+        default: rank_loop<4>(s, n, mine, rank); break;
+    }
+}
+
+// Fast path: rank on the 32-bit depth alone (a full-rate v_cmp_lt_u32 + add-with-carry per compare; the 64-bit compare
+// of the full (depth, idx) key is several times slower).  Distinct depths give distinct ranks; if two splats of the
+// tile share a depth, two keys collide on a rank -- detected through a claim array in LDS -- and the whole tile is
+// redone with the full 64-bit keys, which reproduces the reference's stable (depth, then index) order.
 template <bool BUCKET>
 __global__ void __launch_bounds__(256) k_tile_rank_sort(const uint2* __restrict__ ranges,
                                                         const uint64_t* __restrict__ keys,
                                                         uint32_t* __restrict__ point_list, uint32_t cap,
                                                         const uint32_t* __restrict__ tile_count,
                                                         uint2* __restrict__ ranges_out, uint32_t* __restrict__ total) {
-    __shared__ uint64_t sk[RANK_MAX];
+    __shared__ uint64_t sk[RANK_MAX + RANK_U];
+    __shared__ uint32_t sd[RANK_MAX + RANK_U];   // depth bits, then reused as the claim array
     const uint2 rg = BUCKET ? bucket_range(tile_count, ranges_out, total, cap, true) : ranges[blockIdx.x];
     const uint32_t n = rg.y - rg.x;
     if (n == 0 || n > RANK_MAX || (!BUCKET && rg.y > cap)) return;
     const uint32_t tid = threadIdx.x;
+    // a wave that owns no key leaves at once (the hardware drops finished waves from the workgroup barriers): its
+    // slot goes to the next tile's workgroup -- the kernel is bound by dependent-load latency, i.e. by tiles in flight
+    if ((tid & ~63u) >= n) return;
     const uint64_t* gk = keys + rg.x;
     uint32_t* out = point_list + rg.x;
     uint64_t mine[4];
+    uint32_t mine_d[4];
     uint32_t rank[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const uint32_t i = tid + 256u * q;
         mine[q] = i < n ? gk[i] : ~0ull;
-        if (i < n) sk[i] = mine[q];
+        mine_d[q] = (uint32_t)(mine[q] >> 32);
+        if (i < n) { sk[i] = mine[q]; sd[i] = mine_d[q]; }
+    }
+    if (tid < RANK_U) { sk[n + tid] = ~0ull; sd[n + tid] = ~0u; }  // +inf padding: never "less than" a real key
+    __syncthreads();
+    const int nq = (n + 255) / 256;  // keys per thread actually in use (block-uniform)
+    rank_dispatch(nq, sd, n, mine_d, rank);
+    __syncthreads();                 // everyone is done reading the depths: sd becomes the claim array
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t i = tid + 256u * q;
+        if (i < n) sd[rank[q]] = i;
     }
     __syncthreads();
-    const int nq = (n + 255) / 256;  // keys per thread actually in use (wave-uniform)
-    const uint32_t n2 = n & ~1u;
-    for (uint32_t u = 0; u < n2; u += 2) {
-        const uint64_t k0 = sk[u], k1 = sk[u + 1];  // uniform address: LDS broadcast
+    bool lost = false;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if (q < nq) rank[q] += (uint32_t)(k0 < mine[q]) + (uint32_t)(k1 < mine[q]);
-        }
+    for (int q = 0; q < 4; q++) {
+        const uint32_t i = tid + 256u * q;
+        if (i < n) lost |= sd[rank[q]] != i;
     }
-    if (n & 1u) {
-        const uint64_t k0 = sk[n - 1];
+    if (__syncthreads_or(lost)) {    // equal depths in this tile: full-key ranking (block-uniform branch)
 #pragma unroll
-        for (int q = 0; q < 4; q++) rank[q] += (uint32_t)(k0 < mine[q]);
+        for (int q = 0; q < 4; q++) rank[q] = 0;
+        rank_dispatch(nq, sk, n, mine, rank);
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
