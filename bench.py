@@ -310,8 +310,29 @@ def main():
         for _ in range(n_ts):
             ts.step()
         torch.cuda.synchronize()
-        out["train_step_ms"] = round((time.perf_counter() - tt0) / n_ts * 1e3, 4)
-        out["train_step_note"] = ("lr update + view pick + render (fused attrs + raster) + edge_aware_loss + fused_ssim "
+        eager_ms = (time.perf_counter() - tt0) / n_ts * 1e3
+        # the same iteration replayed as one hipGraph launch (sync-free forward, device-state Adam)
+        from curve_gaussian_amd.train_step import GraphedTrainStep
+        gm2 = GaussianCurveModel(0, m, device=dev).create_from_curves(curves["curve_points"], curves["width"],
+                                                                      curves["opacity"], curves["mask"],
+                                                                      curves["is_bezier"])
+        gs = GraphedTrainStep(gm2, tcams, gts)
+        for _ in range(3):
+            gs.step()
+        gs.finish()
+        torch.cuda.synchronize()
+        n_gs = 32
+        tt0 = time.perf_counter()
+        for _ in range(n_gs):
+            gs.step()
+        gs.finish()
+        torch.cuda.synchronize()
+        graph_ms = (time.perf_counter() - tt0) / n_gs * 1e3
+        out["train_step_ms"] = round(graph_ms, 4)
+        out["train_step_eager_ms"] = round(eager_ms, 4)
+        out["train_step_graph_recaptures"] = gs.recaptures
+        out["train_step_note"] = ("train_step_ms: GraphedTrainStep (whole iteration = one hipGraph replay); "
+                                  "train_step_eager_ms: TrainStep (Python autograd, ~30 launches).  Iteration = lr update + view pick + render (fused attrs + raster) + edge_aware_loss + fused_ssim "
                                   "+ backward + Adam (6 groups) + prepare_scaling_rot; regularisers of train.py:110-146 "
                                   "excluded (SURVEY 8d)")
 

@@ -20,6 +20,14 @@ SIGNATURES = {
     "cgs_geometry_bytes": (C.c_size_t, [_i]),
     "cgs_image_bytes": (C.c_size_t, [_i, _i]),
     "cgs_binning_bytes": (C.c_size_t, [_i64]),
+    "cgs_rasterize_forward_static": (_i, [_vp, _vp, C.c_size_t, _vp, C.c_uint32, _i, _i, _i, _vp, _i, _i,
+                                          _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f,
+                                          _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "cgs_image_status_offset": (C.c_size_t, [_i, _i]),
+    "cgs_status_words": (_i, []),
+    "cgs_bucket_capacity_limit": (C.c_uint32, []),
+    "cgs_adam_step_flat_dev": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _i, _vp, _vp]),
+    "cgs_adam_state_bytes": (C.c_size_t, []),
     "cgs_set_tile_culling": (_i, [_i]),
     "cgs_reset_binning_hints": (None, []),
     "cgs_last_forward_stats": (None, [C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i)]),
@@ -88,6 +96,14 @@ def check(rc, what: str):
 def require_gpu_tensor(t, name: str):
     if not t.is_cuda:
         raise CurveGSError(f"{name} must be a GPU tensor (got device {t.device}); libcurvegs has no CPU path")
+
+
+def raw_stream(dev):
+    """hipStream_t of torch's current stream on `dev` as an int (one C call; torch.cuda.current_stream() builds a
+    Stream object and is ~10x slower)."""
+    import torch
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(idx)
 
 
 def ptr(t):

@@ -3,7 +3,9 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <map>
 #include <mutex>
@@ -65,6 +67,32 @@ static void update_max_hint(uint32_t longest) {
     g_max_hint.store(std::max<int64_t>((int64_t)longest, decayed), std::memory_order_relaxed);
 }
 static thread_local int64_t g_last_stats[3] = {0, 0, 0};  // num_rendered, longest tile list, binning path (0 exact, 1 bucket)
+
+// Device-side zero fill.  hipMemsetAsync is NOT used anywhere in the library: captured into a hipGraph (ROCm 7.0 runtime
+// under PyTorch 2.10) its memset node cleared the buffer on the first replay only -- later replays ran on stale
+// histograms / partial sums.  A plain kernel node replays correctly, and hipMemsetAsync is a fill kernel anyway.
+__global__ void __launch_bounds__(256) k_zero_words(uint32_t* __restrict__ p, size_t words) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += stride) p[i] = 0u;
+}
+__global__ void __launch_bounds__(256) k_zero_vec(uint4* __restrict__ p, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+static hipError_t zero_async(void* p, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    if (!(bytes & 15u) && !(reinterpret_cast<uintptr_t>(p) & 15u)) {
+        const size_t n = bytes / 16;
+        const int blocks = (int)std::min<size_t>((n + 255) / 256, 8192);
+        hipLaunchKernelGGL(k_zero_vec, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint4*>(p), n);
+        return hipGetLastError();
+    }
+    if ((bytes & 3u) || (reinterpret_cast<uintptr_t>(p) & 3u)) return hipMemsetAsync(p, 0, bytes, s);  // never the case here
+    const size_t words = bytes / 4;
+    const int blocks = (int)std::min<size_t>((words + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_zero_words, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint32_t*>(p), words);
+    return hipGetLastError();
+}
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -155,9 +183,9 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
     }
     const size_t npix = (size_t)width * height;
     if (P == 0) {  // rasterize_points.cu:91: outputs stay zero-filled, nothing is rendered (not even background)
-        if (hipMemsetAsync(out_color, 0, npix * 4, s) != hipSuccess || hipMemsetAsync(out_invdepth, 0, npix * 4, s) != hipSuccess ||
-            hipMemsetAsync(out_all_map, 0, npix * 16, s) != hipSuccess) {
-            set_error("hipMemsetAsync failed");
+        if (zero_async(out_color, npix * 4, s) != hipSuccess || zero_async(out_invdepth, npix * 4, s) != hipSuccess ||
+            zero_async(out_all_map, npix * 16, s) != hipSuccess) {
+            set_error("zero_async failed");
             return CGS_ERR_HIP;
         }
         return 0;
@@ -234,8 +262,8 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
     if (cull && !debug && max_hint > 0) {
         const uint64_t cap = (((uint64_t)max_hint * 5 / 4 + 64) + 63) & ~63ull;
         if (cap <= bucket_cap_limit() && cap * (uint64_t)tiles < (1ull << 31)) {
-            if (hipMemsetAsync(img.tile_count, 0, clear_bytes, s) != hipSuccess) {
-                set_error("hipMemsetAsync(tile histogram) failed");
+            if (zero_async(img.tile_count, clear_bytes, s) != hipSuccess) {
+                set_error("zero_async(tile histogram) failed");
                 return CGS_ERR_HIP;
             }
             if (!preprocess(nullptr)) return CGS_ERR_HIP;
@@ -250,6 +278,9 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
             launch_tile_sort_bucket(s, tiles, img.tile_count, img.ranges, img.total, bin.keys, bin.point_list, (uint32_t)cap);
             if (!read_totals()) return CGS_ERR_HIP;
             if (!render(bin.point_list)) return CGS_ERR_HIP;
+#ifdef CGS_EXPERIMENT_NOWAIT
+            if (getenv("CGS_NOWAIT")) return g_R_hint.load(std::memory_order_relaxed);
+#endif
             if (!wait_totals()) return CGS_ERR_HIP;
             int64_t Rb = 0;
             uint32_t longest = 0;
@@ -269,8 +300,8 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
 
     // ---- path A: exact layout (count -> scan -> scatter -> sort); bit-identical to the reference's binning when
     // tile culling is off.  Used for the first forward, in debug mode, with culling off and after a bucket overflow.
-    if (hipMemsetAsync(img.tile_count, 0, clear_bytes, s) != hipSuccess) {
-        set_error("hipMemsetAsync(tile histogram) failed");
+    if (zero_async(img.tile_count, clear_bytes, s) != hipSuccess) {
+        set_error("zero_async(tile histogram) failed");
         return CGS_ERR_HIP;
     }
     if (!preprocess(img.tile_count)) return CGS_ERR_HIP;
@@ -305,8 +336,8 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
     g_R_hint.store(R, std::memory_order_relaxed);
     update_max_hint(max_count);
     if (!bchunk || R > cap) {  // first call, debug mode, or the speculative buffer was too small: exact-size (re)run
-        if (cap > 0 && hipMemsetAsync(img.tile_cursor, 0, (size_t)tiles * sizeof(uint32_t), s) != hipSuccess) {
-            set_error("hipMemsetAsync(tile cursors) failed");
+        if (cap > 0 && zero_async(img.tile_cursor, (size_t)tiles * sizeof(uint32_t), s) != hipSuccess) {
+            set_error("zero_async(tile cursors) failed");
             return CGS_ERR_HIP;
         }
         cap = R;
@@ -331,6 +362,72 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
     g_last_stats[0] = R; g_last_stats[1] = (int64_t)max_count; g_last_stats[2] = 0;
     return R;
 }
+
+// Sync-free forward for stream-ordered / hipGraph-captured pipelines: caller-owned buffers, caller-chosen bucket
+// capacity, single-pass bucket binning only, nothing read back.  Status lives in the image buffer (see header).
+int cgs_rasterize_forward_static(void* geometry_buffer, void* binning_buffer, size_t binning_bytes, void* image_buffer,
+                                 uint32_t bucket_capacity, int P, int D, int M, const float* background, int width,
+                                 int height, const float* means3D, const float* shs, const float* colors_precomp,
+                                 const float* opacities, const float* scales, float scale_modifier,
+                                 const float* rotations, const float* cov3D_precomp, const float* all_map,
+                                 const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                                 float tan_fovy, float* out_color, float* out_invdepth, float* out_all_map,
+                                 int antialiasing, int render_geo, int* radii, void* stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    if (P <= 0 || width <= 0 || height <= 0 || !out_color || !out_invdepth || !out_all_map || !background ||
+        !viewmatrix || !projmatrix || !geometry_buffer || !binning_buffer || !image_buffer || bucket_capacity == 0) {
+        set_error("cgs_rasterize_forward_static: invalid argument (P=%d W=%d H=%d, NULL pointer or zero capacity)", P, width, height);
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    if (!means3D || !opacities || !radii || (!shs == !colors_precomp) ||
+        (cov3D_precomp ? (scales || rotations) : (!scales || !rotations)) || (render_geo && !all_map) ||
+        (shs && (!cam_pos || M <= 0)) || !aligned16(rotations) || !aligned16(all_map)) {
+        set_error("cgs_rasterize_forward_static: inconsistent or misaligned inputs");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE;
+    const int tiles = gx * gy;
+    const uint64_t cap = bucket_capacity;
+    if (cap > bucket_cap_limit() || cap * (uint64_t)tiles >= (1ull << 31) ||
+        binning_bytes < cgs_binning_bytes((int64_t)(cap * tiles))) {
+        set_error("cgs_rasterize_forward_static: bucket capacity %u needs %zu binning bytes (got %zu; limit %u per tile)",
+                  bucket_capacity, cgs_binning_bytes((int64_t)(cap * tiles)), binning_bytes, bucket_cap_limit());
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    const size_t npix = (size_t)width * height;
+    const float focal_y = height / (2.0f * tan_fovy);
+    const float focal_x = width / (2.0f * tan_fovx);
+    char* gchunk = (char*)geometry_buffer;
+    char* bchunk = (char*)binning_buffer;
+    char* ichunk = (char*)image_buffer;
+    GeomState geom = geom_from_chunk(gchunk, (size_t)P);
+    BinState bin = bin_from_chunk(bchunk, (size_t)(cap * tiles));
+    ImageState img = image_from_chunk(ichunk, npix, (size_t)tiles);
+    const size_t clear_bytes = (size_t)((char*)(img.total + TOTAL_WORDS) - (char*)img.tile_count);
+    if (zero_async(img.tile_count, clear_bytes, s) != hipSuccess) {
+        set_error("zero_async(tile histogram) failed");
+        return CGS_ERR_HIP;
+    }
+    launch_preprocess_fwd(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, geom.clamped,
+                          cov3D_precomp, colors_precomp, render_geo ? all_map : nullptr, viewmatrix, projmatrix, cam_pos,
+                          width, height, tan_fovx, tan_fovy, focal_x, focal_y, radii, geom.rec, geom.rgb, gx, gy, nullptr,
+                          antialiasing, 1);
+    launch_scatter_bucket(s, P, radii, geom.rec, gx, gy, img.tile_count, bin.keys, (uint32_t)cap, 1);
+    launch_tile_sort_bucket(s, tiles, img.tile_count, img.ranges, img.total, bin.keys, bin.point_list, (uint32_t)cap);
+    launch_render_fwd(s, render_geo != 0, tiles, img.ranges, bin.point_list, width, height, gx, geom.rec, img.final_T,
+                      img.n_contrib, background, out_color, out_invdepth, out_all_map);
+    if (!check_launch("rasterize_forward_static", false, s)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
+
+size_t cgs_image_status_offset(int width, int height) {
+    char* c = nullptr;
+    const size_t tiles = (size_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+    ImageState img = image_from_chunk(c, (size_t)width * height, tiles);
+    return (size_t)((char*)img.total - (char*)nullptr);
+}
+int cgs_status_words(void) { return TOTAL_WORDS; }
+uint32_t cgs_bucket_capacity_limit(void) { return bucket_cap_limit(); }
 
 void cgs_last_forward_stats(int64_t* num_rendered, int64_t* longest_tile_list, int* binning_path) {
     if (num_rendered) *num_rendered = g_last_stats[0];
@@ -380,8 +477,8 @@ int cgs_rasterize_backward(int P, int D, int M, int64_t R, const float* backgrou
     BinState bin = bin_from_chunk(bchunk, (size_t)(R > 0 ? R : 1));
     ImageState img = image_from_chunk(ichunk, npix, (size_t)tiles);
 
-    if (hipMemsetAsync(geom.grad_acc, 0, (size_t)P * ACC_STRIDE * sizeof(float), s) != hipSuccess) {
-        set_error("hipMemsetAsync(gradient accumulators) failed");
+    if (zero_async(geom.grad_acc, (size_t)P * ACC_STRIDE * sizeof(float), s) != hipSuccess) {
+        set_error("zero_async(gradient accumulators) failed");
         return CGS_ERR_HIP;
     }
     if (R > 0) {
@@ -423,8 +520,8 @@ int cgs_sample_curves_forward(int B, int m, const float* curve_points, const flo
         set_error("cgs_sample_curves_forward: invalid argument (NULL or misaligned pointer, B=%d m=%d)", B, m);
         return CGS_ERR_INVALID_ARGUMENT;
     }
-    if (hipMemsetAsync(norms, 0, (size_t)sample_norm_words() * sizeof(double), s) != hipSuccess) {
-        set_error("hipMemsetAsync(norms) failed");
+    if (zero_async(norms, (size_t)sample_norm_words() * sizeof(double), s) != hipSuccess) {
+        set_error("zero_async(norms) failed");
         return CGS_ERR_HIP;
     }
     launch_sample_forward(s, B, m, curve_points, width, is_bezier, coef, eps, norms, xyz, rotation, scaling);
@@ -444,8 +541,8 @@ int cgs_sample_curves_backward(int B, int m, const float* curve_points, const fl
         set_error("cgs_sample_curves_backward: invalid argument");
         return CGS_ERR_INVALID_ARGUMENT;
     }
-    if (hipMemsetAsync(norms + sample_norm_words() / 2, 0, (size_t)(sample_norm_words() / 2) * sizeof(double), s) != hipSuccess) {
-        set_error("hipMemsetAsync(norms) failed");
+    if (zero_async(norms + sample_norm_words() / 2, (size_t)(sample_norm_words() / 2) * sizeof(double), s) != hipSuccess) {
+        set_error("zero_async(norms) failed");
         return CGS_ERR_HIP;
     }
     launch_sample_backward(s, B, m, curve_points, width, is_bezier, coef, eps, norms, dL_dxyz, dL_drotation, dL_dscaling,
@@ -531,8 +628,8 @@ int cgs_edge_aware_loss(int channels, int height, int width, const float* image,
         set_error("cgs_edge_aware_loss: invalid argument");
         return CGS_ERR_INVALID_ARGUMENT;
     }
-    if (hipMemsetAsync(scratch16, 0, 16, s) != hipSuccess) {
-        set_error("hipMemsetAsync failed");
+    if (zero_async(scratch16, 16, s) != hipSuccess) {
+        set_error("zero_async failed");
         return CGS_ERR_HIP;
     }
     launch_edge_aware_loss(s, channels, height, width, image, gt, threshold, scratch16, dL_dimage);
@@ -549,8 +646,8 @@ int cgs_edge_count(int channels, int height, int width, const float* gt, float t
         return CGS_ERR_INVALID_ARGUMENT;
     }
     hipStream_t s = (hipStream_t)stream_;
-    if (hipMemsetAsync(n_pos, 0, sizeof(uint32_t), s) != hipSuccess) {
-        set_error("cgs_edge_count: hipMemsetAsync failed");
+    if (zero_async(n_pos, sizeof(uint32_t), s) != hipSuccess) {
+        set_error("cgs_edge_count: zero_async failed");
         return CGS_ERR_HIP;
     }
     launch_edge_count(s, channels, height * width, gt, threshold, n_pos);
@@ -587,6 +684,22 @@ int cgs_adam_step_flat(int64_t n, float* params, float* grads, float* exp_avg, f
     if (!check_launch("adam_step_flat", false, (hipStream_t)stream_)) return CGS_ERR_HIP;
     return CGS_OK;
 }
+
+int cgs_adam_step_flat_dev(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                           const void* device_state, int n_segments, float beta1, float beta2, float eps, int zero_grads,
+                           const uint32_t* skip_flag, void* stream_) {
+    if (n == 0) return CGS_OK;
+    if (n < 0 || !params || !grads || !exp_avg || !exp_avg_sq || !device_state || n_segments <= 0 ||
+        n_segments > adam_max_segments()) {
+        set_error("cgs_adam_step_flat_dev: invalid argument");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    launch_adam_flat_dev((hipStream_t)stream_, (long long)n, params, grads, exp_avg, exp_avg_sq, device_state, n_segments,
+                         beta1, beta2, eps, zero_grads, skip_flag);
+    if (!check_launch("adam_step_flat_dev", false, (hipStream_t)stream_)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
+size_t cgs_adam_state_bytes(void) { return adam_state_bytes(); }
 
 size_t cgs_knn_workspace_bytes(int P) { return knn_workspace_bytes(P); }
 

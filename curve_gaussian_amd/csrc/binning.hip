@@ -161,6 +161,7 @@ __device__ __forceinline__ uint2 bucket_range(const uint32_t* __restrict__ tile_
             uint32_t* part = total + 4 + 2 * (blockIdx.x % TOTAL_PARTS);
             atomicAdd(&part[0], n);
             atomicMax(&part[1], cnt);  // > cap  <=>  this bucket overflowed
+            if (cnt > cap) total[2] = 1u;  // device-visible overflow flag (read by sync-free consumers)
         }
     }
     return make_uint2(base, base + n);

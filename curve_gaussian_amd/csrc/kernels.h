@@ -80,6 +80,9 @@ void launch_edge_count(hipStream_t s, int C, int HW, const float* gt, float thr,
 void launch_edge_aware_loss(hipStream_t s, int C, int H, int W, const float* image, const float* gt, float thr,
                             void* scratch16, float* grad);
 int adam_max_segments();
+size_t adam_state_bytes();
+void launch_adam_flat_dev(hipStream_t s, long long n, float* p, float* g, float* m, float* v, const void* dev_state,
+                          int nseg, float b1, float b2, float eps, int zero_grad, const unsigned int* skip_flag);
 void launch_adam_flat(hipStream_t s, long long n, float* p, float* g, float* m, float* v, const void* host_segs, int nseg,
                       float b1, float b2, float eps, float bc1, float sqrt_bc2, int zero_grad);
 // knn.hip

@@ -108,6 +108,38 @@ __global__ void __launch_bounds__(256) k_adam_flat(long long n, float* __restric
         p[i] = p[i] - (lr / bc1) * (mi / denom);
     }
 }
+// Graph-replayable variant: the per-step scalars (segment learning rates, bias corrections) come from DEVICE memory
+// (refreshed by a stream-ordered copy before each replay), and the update is skipped -- gradients still cleared --
+// when *skip_flag != 0 (the captured forward raised its bucket-overflow flag: the host redoes that step eagerly).
+struct AdamDevState { AdamSeg s[ADAM_MAX_SEGS]; float bc1; float sqrt_bc2; float pad[2]; };
+__global__ void __launch_bounds__(256) k_adam_flat_dev(long long n, float* __restrict__ p, float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v,
+                                                       const AdamDevState* __restrict__ st, int nseg, float b1, float b2,
+                                                       float eps, int zero_grad, const unsigned int* __restrict__ skip_flag) {
+    const bool skip = skip_flag && *skip_flag != 0u;
+    const float bc1 = st->bc1, sqrt_bc2 = st->sqrt_bc2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        if (zero_grad) g[i] = 0.f;
+        if (skip) continue;
+        float lr = st->s[0].lr;
+        for (int s = 1; s < nseg; s++) lr = i >= st->s[s].begin ? st->s[s].lr : lr;
+        const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+        p[i] = p[i] - (lr / bc1) * (mi / denom);
+    }
+}
+size_t adam_state_bytes() { return sizeof(AdamDevState); }
+void launch_adam_flat_dev(hipStream_t s, long long n, float* p, float* g, float* m, float* v, const void* dev_state,
+                          int nseg, float b1, float b2, float eps, int zero_grad, const unsigned int* skip_flag) {
+    ProfScope pr("adam_flat", s);
+    const int blocks = (int)std::min<long long>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_adam_flat_dev, dim3(blocks), dim3(256), 0, s, n, p, g, m, v,
+                       reinterpret_cast<const AdamDevState*>(dev_state), nseg, b1, b2, eps, zero_grad, skip_flag);
+}
 int adam_max_segments() { return ADAM_MAX_SEGS; }
 void launch_adam_flat(hipStream_t s, long long n, float* p, float* g, float* m, float* v, const void* host_segs, int nseg,
                       float b1, float b2, float eps, float bc1, float sqrt_bc2, int zero_grad) {

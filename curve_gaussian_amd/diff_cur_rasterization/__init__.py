@@ -79,6 +79,53 @@ class _Ext:
                 bufs.get("img", empty), out_invdepth, out_all_map)
 
     @staticmethod
+    def rasterize_gaussians_static(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                                   all_map, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh,
+                                   degree, campos, prefiltered, antialiasing, render_geo, debug, bucket_capacity):
+        """Extension (no reference counterpart): the sync-free forward, cgs_rasterize_forward_static.  Same returns as
+        ``rasterize_gaussians`` except that num_rendered is the constant 1 (nothing is read back; the real count and
+        the overflow flag are the status words of the image buffer, see ``forward_status``).  Capturable in a HIP
+        graph: every buffer is a plain torch allocation made on the current stream."""
+        lib = L.load()
+        L.require_gpu_tensor(means3D, "means3D")
+        dev = means3D.device
+        P, H, W = means3D.size(0), int(image_height), int(image_width)
+        if P == 0:
+            raise L.CurveGSError("rasterize_gaussians_static: P == 0 (use rasterize_gaussians)")
+        means3D = _f32c(means3D, "means3D")
+        colors, opacity, scales, rotations = _f32c(colors, "colors"), _f32c(opacity, "opacity"), _f32c(scales, "scales"), _f32c(rotations, "rotations")
+        cov3D_precomp, all_map, sh = _f32c(cov3D_precomp, "cov3D_precomp"), _f32c(all_map, "all_map"), _f32c(sh, "sh")
+        fopt = dict(dtype=torch.float32, device=dev)
+        out_color = torch.empty((NUM_CHANNELS, H, W), **fopt)
+        out_invdepth = torch.empty((1, H, W), **fopt)
+        out_all_map = torch.empty((NUM_ALL_MAP, H, W), **fopt)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        cap = int(bucket_capacity)
+        nbin = int(lib.cgs_binning_bytes(cap * tiles))
+        geom = torch.empty((int(lib.cgs_geometry_bytes(P)),), dtype=torch.uint8, device=dev)
+        binb = torch.empty((nbin,), dtype=torch.uint8, device=dev)
+        img = torch.empty((int(lib.cgs_image_bytes(W, H)),), dtype=torch.uint8, device=dev)
+        M = sh.size(1) if (sh is not None and sh.numel() != 0) else 0
+        rc = lib.cgs_rasterize_forward_static(
+            L.ptr(geom), L.ptr(binb), nbin, L.ptr(img), cap, P, int(degree), int(M), L.ptr(background), W, H,
+            L.ptr(means3D), L.ptr(sh), L.ptr(colors), L.ptr(opacity), L.ptr(scales), float(scale_modifier),
+            L.ptr(rotations), L.ptr(cov3D_precomp), L.ptr(all_map), L.ptr(viewmatrix), L.ptr(projmatrix),
+            L.ptr(campos), float(tan_fovx), float(tan_fovy), L.ptr(out_color), L.ptr(out_invdepth), L.ptr(out_all_map),
+            int(bool(antialiasing)), int(bool(render_geo)), L.ptr(radii), L.raw_stream(dev))
+        L.check(rc, "cgs_rasterize_forward_static")
+        return (1, out_color, radii, geom, binb, img, out_invdepth, out_all_map)
+
+    @staticmethod
+    def forward_status(imageBuffer, image_height, image_width):
+        """int32 view of the status words of an image buffer (device tensor, valid in stream order):
+        [2] = bucket-overflow flag, [4 + 2k] / [5 + 2k] = partial sums / maxima of the tile list lengths."""
+        lib = L.load()
+        off = int(lib.cgs_image_status_offset(int(image_width), int(image_height)))
+        n = int(lib.cgs_status_words())
+        return imageBuffer[off:off + 4 * n].view(torch.int32)
+
+    @staticmethod
     def rasterize_gaussians_backward(background, all_map_pixels, means3D, radii, colors, all_maps, opacities, scales,
                                      rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx,
                                      tan_fovy, dL_dout_color, dL_dout_invdepth, dL_dout_all_map, sh, degree, campos,
@@ -182,8 +229,15 @@ class _RasterizeGaussians(torch.autograd.Function):
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 all_maps, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
                 rs.sh_degree, rs.campos, rs.prefiltered, rs.antialiasing, rs.render_geo, rs.debug)
-        num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, invdepths, out_all_map = \
-            _C.rasterize_gaussians(*args)
+        cap = getattr(rs, "static_bucket_cap", 0)
+        if cap:   # extension: sync-free forward with caller-chosen bucket capacity (stream-ordered / graph capture)
+            num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, invdepths, out_all_map = \
+                _C.rasterize_gaussians_static(*args, cap)
+            if rs.status_sink is not None:
+                rs.status_sink.append(_C.forward_status(imgBuffer, rs.image_height, rs.image_width))
+        else:
+            num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, invdepths, out_all_map = \
+                _C.rasterize_gaussians(*args)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         # out_all_map is NOT saved: the reference passes it to the backward kernel which never reads it (quirk 21)
@@ -233,6 +287,10 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
     antialiasing: bool
     render_geo: bool
+    # extensions (defaults = the reference's behaviour): static_bucket_cap > 0 selects the sync-free forward
+    # (cgs_rasterize_forward_static) with that many slots per tile; its status-word tensor is appended to status_sink
+    static_bucket_cap: int = 0
+    status_sink: object = None
 
 
 class GaussianRasterizer(nn.Module):

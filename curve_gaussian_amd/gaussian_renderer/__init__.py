@@ -31,7 +31,7 @@ def _ones(n, dev):
 
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_sh=False, override_color=None,
            use_trained_exp=False, use_mask=False, mask_thr=0.01, compute_visibility=True, clamp=True,
-           compute_rend_dir=True):
+           compute_rend_dir=True, static_bucket_cap=0, status_sink=None):
     """Render the scene.  Background tensor (bg_color) must be on the GPU.  Returns the reference's dict
     {render, viewspace_points, visibility_filter, radii, depth, rend_dir, rend_alpha} (:147-155)."""
     dev = pc.get_xyz.device
@@ -44,7 +44,9 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_
         tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,
         viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
         sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug,
-        antialiasing=pipe.antialiasing, render_geo=pipe.render_geo)
+        antialiasing=pipe.antialiasing, render_geo=pipe.render_geo,
+        # extensions: sync-free forward for stream-ordered / graph-captured steps (train_step.GraphedTrainStep)
+        static_bucket_cap=static_bucket_cap, status_sink=status_sink)
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
     means3D = pc.get_xyz
     means2D = screenspace_points

@@ -66,7 +66,7 @@ class _PhotometricLoss(torch.autograd.Function):
     _workspaces = {}
 
     @staticmethod
-    def forward(ctx, image, gt_image, lambda_mse, lambda_dssim, threshold, clamp):
+    def forward(ctx, image, gt_image, lambda_mse, lambda_dssim, threshold, clamp, n_pos):
         L.require_gpu_tensor(image, "image")
         lib = L.load()
         dev = image.device
@@ -77,7 +77,8 @@ class _PhotometricLoss(torch.autograd.Function):
             if Cn != 1:
                 raise L.CurveGSError("photometric_loss: the fused path renders 1 channel (got %d)" % Cn)
             stream = torch.cuda.current_stream(dev).cuda_stream
-            n_pos = _EdgeCountCache.get(gt, threshold, stream)
+            if n_pos is None:
+                n_pos = _EdgeCountCache.get(gt, threshold, stream)
             key = (str(dev), H, W, stream)
             ws = _PhotometricLoss._workspaces.get(key)
             if ws is None:
@@ -96,10 +97,17 @@ class _PhotometricLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
-        return grad * g, None, None, None, None, None
+        return grad * g, None, None, None, None, None, None
 
 
-def photometric_loss(image, gt_image, lambda_mse=10.0, lambda_dssim=0.1, threshold=0.1, clamp=False):
+def edge_pixel_count(gt_image, threshold=0.1):
+    """Device int32 scalar #{mean_c gt > threshold} (loss_utils.py:100-103), cached per gt tensor."""
+    gt = gt_image.detach().float().contiguous()
+    return _EdgeCountCache.get(gt, threshold, L.raw_stream(gt.device))
+
+
+def photometric_loss(image, gt_image, lambda_mse=10.0, lambda_dssim=0.1, threshold=0.1, clamp=False, n_pos=None):
     """image, gt_image: [1,H,W].  Same value/gradient as composing (clamp,) edge_aware_loss and fused_ssim (tested).
-    clamp=True takes the UNclamped rasterizer output and applies render()'s clamp(0,1) inside the kernels."""
-    return _PhotometricLoss.apply(image, gt_image, lambda_mse, lambda_dssim, threshold, clamp)
+    clamp=True takes the UNclamped rasterizer output and applies render()'s clamp(0,1) inside the kernels.
+    n_pos: optional device int32 scalar from ``edge_pixel_count`` (graph-captured steps feed it through a static buffer)."""
+    return _PhotometricLoss.apply(image, gt_image, lambda_mse, lambda_dssim, threshold, clamp, n_pos)

@@ -14,6 +14,8 @@ from .. import _lib as L
 
 
 class FlatAdam:
+    STATE_RING = 64
+
     def __init__(self, named_params, lrs, flat_grads, betas=(0.9, 0.999), eps=1e-15):
         """named_params: dict name -> nn.Parameter (insertion order = flat layout, must match flat_grads.names);
         lrs: dict name -> lr; flat_grads: view_parallel.FlatGrads built over the same dict."""
@@ -52,6 +54,41 @@ class FlatAdam:
                                         self.step_count, 1 if zero_grad else 0,
                                         torch.cuda.current_stream(self.device).cuda_stream)
         L.check(rc, "cgs_adam_step_flat")
+
+    # ---- graph-replayable variant: per-step scalars in device memory, optional device-side skip flag
+    def device_state(self):
+        """(device uint8 tensor, pinned host mirror) holding {segments, 1 - b1^t, sqrt(1 - b2^t)} for cgs_adam_step_flat_dev."""
+        if getattr(self, "_state_dev", None) is None:
+            n = int(L.load().cgs_adam_state_bytes())
+            self._state_dev = torch.zeros(n, dtype=torch.uint8, device=self.device)
+            # ring of pinned staging slots: the host-to-device copy is asynchronous, so the slot of step t must not be
+            # rewritten before that copy has run (callers keep fewer than STATE_RING steps in flight)
+            self._state_host = torch.zeros(self.STATE_RING, n, dtype=torch.uint8).pin_memory()
+        return self._state_dev, self._state_host
+
+    def stage_step(self):
+        """Advance the step count and enqueue (stream-ordered, non-blocking) the scalars of that step."""
+        dev, host = self.device_state()
+        self.step_count += 1
+        b1, b2 = self.betas
+        segs = self._segments()
+        blob = segs + b"\0" * (16 * 16 - len(segs)) + struct.pack("<ffff", 1.0 - b1 ** self.step_count,
+                                                                  (1.0 - b2 ** self.step_count) ** 0.5, 0.0, 0.0)
+        slot = host[self.step_count % self.STATE_RING]
+        slot.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+        dev.copy_(slot, non_blocking=True)
+
+    def step_dev(self, zero_grad=True, skip_flag=None):
+        """Adam step whose scalars come from ``device_state()`` (call ``stage_step()`` first, outside any graph
+        capture); skip_flag: optional device int32/uint32 scalar -- non-zero leaves parameters and moments untouched."""
+        dev, _ = self.device_state()
+        lib = L.load()
+        rc = lib.cgs_adam_step_flat_dev(self.flat.numel(), L.ptr(self.flat), L.ptr(self.grads.flat), L.ptr(self.exp_avg),
+                                        L.ptr(self.exp_avg_sq), L.ptr(dev), len(self.param_groups),
+                                        C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
+                                        1 if zero_grad else 0, L.ptr(skip_flag) if skip_flag is not None else None,
+                                        L.raw_stream(self.device))
+        L.check(rc, "cgs_adam_step_flat_dev")
 
     def zero_grad(self, set_to_none=False):
         self.grads.zero_()

@@ -41,14 +41,17 @@ class TrainStep:
             gaussians.prepare_scaling_rot()   # parameters moved into the flat buffer: rebuild the derived tensors
         self.iteration = 0
 
-    def step(self):
+    def _next_view(self):
+        if not self.stack:
+            self.stack = list(range(len(self.cams)))
+        return self.stack.pop(self.rng.randint(0, len(self.stack) - 1))   # train.py:85-90
+
+    def step(self, view_index=None):
         g = self.g
         self.iteration += 1
         it = self.iteration
         g.update_learning_rate(it)
-        if not self.stack:
-            self.stack = list(range(len(self.cams)))
-        vi = self.stack.pop(self.rng.randint(0, len(self.stack) - 1))   # train.py:85-90
+        vi = self._next_view() if view_index is None else view_index
         cam, gt = self.cams[vi], self.gts[vi]
         use_mask = it >= self.densify_until_iter
         pkg = render(cam, g, self.pipe, self.bg, use_mask=use_mask, mask_thr=self.mask_threshold,
@@ -71,3 +74,201 @@ class TrainStep:
             self.flat.zero_()                      # grads are views of the flat buffer: keep them, zero in place
         g.prepare_scaling_rot()                    # train.py:242-243
         return loss.detach(), pkg
+
+
+class _StaticCamera:
+    """Camera whose pose tensors are fixed device buffers refreshed before every graph replay."""
+
+    def __init__(self, proto, device):
+        self.image_height, self.image_width = int(proto.image_height), int(proto.image_width)
+        self.FoVx, self.FoVy = proto.FoVx, proto.FoVy
+        self.pack = torch.zeros(35, dtype=torch.float32, device=device)   # view 16 | proj 16 | centre 3
+        self.world_view_transform = self.pack[0:16].view(4, 4)
+        self.full_proj_transform = self.pack[16:32].view(4, 4)
+        self.camera_center = self.pack[32:35]
+
+    @staticmethod
+    def packed(cam):
+        return torch.cat([cam.world_view_transform.reshape(-1), cam.full_proj_transform.reshape(-1),
+                          cam.camera_center.reshape(-1)]).float().contiguous()
+
+
+class GraphedTrainStep(TrainStep):
+    """The same iteration as ``TrainStep(fused=True)`` replayed as ONE hipGraph launch.
+
+    An eager iteration costs ~30 kernel launches through Python autograd, ctypes and the HIP runtime (~0.4 ms of host
+    time); small scenes are bound by that, large ones leave the GPU idle between kernels.  Here the whole sequence
+    (render with the sync-free forward -> fused photometric loss -> backward -> Adam -> prepare_scaling_rot) is captured
+    once; per step the host refreshes four small static buffers (camera pose, gt edge map, edge-pixel count, Adam
+    scalars) with stream-ordered copies and replays the graph.
+
+    The captured forward bins into fixed-capacity tile buckets sized from an eager probe (x ``cap_margin``).  If a
+    bucket still overflows, the device-side flag makes the captured Adam skip its update (gradients are cleared);
+    the host sees the flag one step later, redoes that view eagerly through the exact path, enlarges the buckets and
+    re-captures.  All cameras must share the image size and field of view (they are graph constants)."""
+
+    def __init__(self, *args, cap_margin=1.5, **kw):
+        kw["fused"] = True
+        super().__init__(*args, **kw)
+        if self.world != 1:
+            raise ValueError("GraphedTrainStep: view-parallel runs use TrainStep (the all-reduce is not captured)")
+        dev = self.g.device
+        c0 = self.cams[0]
+        for c in self.cams:
+            if (c.image_height, c.image_width, c.FoVx, c.FoVy) != (c0.image_height, c0.image_width, c0.FoVx, c0.FoVy):
+                raise ValueError("GraphedTrainStep: all cameras must share image size and field of view")
+        self.cap_margin = float(cap_margin)
+        self._cam = _StaticCamera(c0, dev)
+        self._cam_packs = [_StaticCamera.packed(c).to(dev) for c in self.cams]
+        self._gt = torch.empty_like(self.gts[0][:1]).contiguous()
+        from .ops.losses import edge_pixel_count
+        self._npos_all = [edge_pixel_count(g[:1]) for g in self.gts]
+        self._npos = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._graph = None
+        self._cap = 0
+        self._loss = None
+        self._status = None
+        self._flag_host = torch.zeros(64, dtype=torch.int32).pin_memory()
+        self._inflight = []   # (event, slot, view index, iteration)
+        self.recaptures = 0
+        self._t0 = self.g.optimizer.step_count - self.iteration   # Adam step number = _t0 + iteration
+
+    # -- the captured sequence ---------------------------------------------------------------------------------
+    def _body(self):
+        g = self.g
+        sink = []
+        # prepare_scaling_rot opens the captured sequence (the reference runs it at the END of the previous iteration,
+        # train.py:242-243 -- same data flow, but every replay must read the parameters, not a tensor of an older replay)
+        g.prepare_scaling_rot()
+        pkg = render(self._cam, g, self.pipe, self.bg, compute_visibility=False, clamp=False, compute_rend_dir=False,
+                     static_bucket_cap=self._cap, status_sink=sink)
+        loss = photometric_loss(pkg["render"], self._gt, self.lambda_mse, self.lambda_dssim, clamp=True, n_pos=self._npos)
+        if getattr(self, "_debug_keep", None) is not None:
+            import os
+            allk = dict(xyz=g._xyz, rot=g._rotation, scl=g._scaling, radii=pkg["radii"], img=pkg["render"], depth=pkg["depth"])
+            self._debug_keep.update({k: v for k, v in allk.items() if k in os.environ.get("CGS_DBG_KEEP", "").split(",")})
+        loss.backward()
+        status = sink[0]
+        g.optimizer.step_dev(zero_grad=True, skip_flag=status[2:3])
+        return loss.detach(), status
+
+    def _probe_capacity(self):
+        """Longest tile list over a few eager (exact-path) renders -> bucket capacity."""
+        from . import _lib as L
+        import ctypes
+        lib = L.load()
+        longest = 1
+        with torch.no_grad():
+            for cam in self.cams[:min(8, len(self.cams))]:
+                render(cam, self.g, self.pipe, self.bg, compute_visibility=False, clamp=False, compute_rend_dir=False)
+                m = ctypes.c_int64()
+                lib.cgs_last_forward_stats(None, ctypes.byref(m), None)
+                longest = max(longest, int(m.value))
+        limit = int(lib.cgs_bucket_capacity_limit())
+        cap = (int(longest * self.cap_margin) + 64 + 63) // 64 * 64
+        if cap > limit:
+            raise RuntimeError(f"GraphedTrainStep: tile lists of {longest} entries need buckets beyond the limit "
+                               f"({limit}); use TrainStep for this scene")
+        return cap
+
+    def _load_inputs(self, vi):
+        self._cam.pack.copy_(self._cam_packs[vi], non_blocking=True)
+        self._gt.copy_(self.gts[vi][:1], non_blocking=True)
+        self._npos.copy_(self._npos_all[vi], non_blocking=True)
+
+    def _capture(self, vi):
+        if self._cap == 0:
+            self._cap = self._probe_capacity()
+        opt = self.g.optimizer
+        # warm-up replicas of the body must not change the model: snapshot, run on a side stream, restore
+        snap = (opt.flat.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.step_count)
+        # The gradient accumulators of the parameters live as long as an autograd graph references them, and they keep
+        # the stream they were created on.  Eager steps create them on the default stream, and a captured backward
+        # that has to synchronise with the default stream cannot be captured: drop the old graph (the derived splat
+        # tensors of the last prepare_scaling_rot hold it) so the warm-up below re-creates them on a side stream.
+        g = self.g
+        g._xyz, g._rotation, g._scaling = g._xyz.detach(), g._rotation.detach(), g._scaling.detach()
+        self._loss = self._status = None
+        self._load_inputs(vi)
+        opt.stage_step()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        # capture on the warm-up stream: the gradient accumulators created there then share the capture stream, and the
+        # captured backward stays single-stream (a cross-stream AccumulateGrad inside the capture lets the allocator
+        # recycle blocks the other stream still uses -- later replays then read clobbered intermediates)
+        with torch.cuda.graph(graph, stream=side):
+            self._loss, self._status = self._body()
+        opt.flat.copy_(snap[0]); opt.exp_avg.copy_(snap[1]); opt.exp_avg_sq.copy_(snap[2])
+        opt.step_count = snap[3]
+        opt.grads.zero_()
+        self.g.prepare_scaling_rot()
+        self._graph = graph
+        self.recaptures += 1
+
+    def _check_overflow(self, block=False):
+        """Steps whose status has arrived: a raised flag means that step was skipped on the device -> redo it."""
+        redo = []
+        keep = []
+        for ev, slot, vi, it in self._inflight:
+            if block:
+                ev.synchronize()
+            if ev.query():
+                if int(self._flag_host[slot]) != 0:
+                    redo.append((vi, it))
+            else:
+                keep.append((ev, slot, vi, it))
+        self._inflight = keep
+        opt = self.g.optimizer
+        for vi, it in redo:
+            now = self.iteration
+            self.iteration = it - 1                    # redo with the learning rate ...
+            opt.step_count = self._t0 + it - 1         # ... and the Adam step number of its own iteration
+            self._refresh_derived()
+            TrainStep.step(self, view_index=vi)        # exact path, eager
+            self.iteration = now
+            opt.step_count = self._t0 + now            # every iteration up to `now` is applied, redone or in flight
+            self._cap = 0                              # re-probe and re-capture with larger buckets
+            self._graph = None
+        return len(redo)
+
+    def step(self, view_index=None):
+        g = self.g
+        if self.iteration + 1 >= self.densify_until_iter:   # mask regulariser phase: not captured
+            self._check_overflow(block=True)
+            self._refresh_derived()
+            return TrainStep.step(self, view_index)
+        self._check_overflow()
+        self.iteration += 1
+        g.update_learning_rate(self.iteration)
+        vi = self._next_view() if view_index is None else view_index
+        if self._graph is None:
+            self._capture(vi)
+        self._load_inputs(vi)
+        g.optimizer.stage_step()
+        self._graph.replay()
+        self._derived_stale = True   # g._xyz/_rotation/_scaling now hold the values of BEFORE this step's update
+        slot = self.iteration % 64
+        self._flag_host[slot:slot + 1].copy_(self._status[2:3], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._inflight.append((ev, slot, vi, self.iteration))
+        if len(self._inflight) > 32:
+            self._check_overflow(block=True)
+        return self._loss, None
+
+    def _refresh_derived(self):
+        if getattr(self, "_derived_stale", False):
+            self.g.prepare_scaling_rot()
+            self._derived_stale = False
+
+    def finish(self):
+        """Drain: no skipped step left behind and the derived splat tensors match the parameters (call before reading
+        the model from outside)."""
+        while self._inflight:
+            self._check_overflow(block=True)
+        self._refresh_derived()

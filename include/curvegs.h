@@ -206,6 +206,16 @@ int cgs_adam_step_flat(int64_t n, float* params, float* grads, float* exp_avg, f
                        const void* segments, int n_segments, float beta1, float beta2, float eps, int step,
                        int zero_grads, void* stream);
 
+/* Graph-replayable Adam: as cgs_adam_step_flat, but the per-step scalars live in DEVICE memory
+ * (device_state: cgs_adam_state_bytes() bytes = 16 x {int64 begin; float lr; float pad} followed by
+ * {float 1 - beta1^t; float sqrt(1 - beta2^t); float pad[2]}, refreshed by the caller with a stream-ordered copy), and
+ * when skip_flag != NULL and *skip_flag != 0 (e.g. status word [2] of a cgs_rasterize_forward_static image buffer) the
+ * parameters and moments are left untouched (gradients are still cleared if zero_grads). */
+int cgs_adam_step_flat_dev(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                           const void* device_state, int n_segments, float beta1, float beta2, float eps, int zero_grads,
+                           const uint32_t* skip_flag, void* stream);
+size_t cgs_adam_state_bytes(void);
+
 /* ------------------------------------------------------------------------------------------------
  * simple-knn.  Replaces distCUDA2 -> SimpleKNN::knn (/root/reference/submodules/simple-knn/spatial.cu:15-26,
  * simple_knn.cu:186-222): mean_dist2[i] = mean of the 3 smallest SQUARED distances from point i to other points.
@@ -226,6 +236,33 @@ int cgs_knn_mean_dist2(int P, const float* points /*[P,3]*/, float* mean_dist2 /
 int cgs_set_tile_culling(int on);
 /* Introspection of the calling thread's last cgs_rasterize_forward: num_rendered, the longest per-tile list and
  * which binning path produced it (0 = exact count/scan/scatter layout, 1 = single-pass fixed-capacity buckets). */
+/* ------------------------------------------------------------------------------------------------
+ * Sync-free forward for stream-ordered and hipGraph-captured pipelines (no counterpart in the reference, whose
+ * forward blocks on a device-to-host copy of num_rendered, rasterizer_impl.cu:287).  Same inputs, outputs and saved
+ * state as cgs_rasterize_forward, but:
+ *   - the three buffers are allocated by the caller: cgs_geometry_bytes(P), cgs_image_bytes(W, H) and
+ *     cgs_binning_bytes(bucket_capacity * tiles) bytes, tiles = ceil(W/16) * ceil(H/16);
+ *   - binning is the single-pass bucket layout with `bucket_capacity` slots per tile (<= cgs_bucket_capacity_limit());
+ *     a good value is 1.25-2 x the longest tile list reported by cgs_last_forward_stats after a normal forward;
+ *   - nothing is read back: no num_rendered, no host wait -- the call only enqueues work on `stream`.
+ * Status words (u32) at byte offset cgs_image_status_offset(W, H) of the image buffer, valid in stream order:
+ *   [2] != 0: some tile list outgrew its bucket -> the image and every gradient of this forward are INVALID (redo it
+ *       with cgs_rasterize_forward or a larger capacity); [4 + 2k], [5 + 2k], k < (cgs_status_words() - 4) / 2:
+ *       partial sums / maxima of the tile list lengths (num_rendered = sum of the sums, longest list = max of maxima).
+ * The backward is cgs_rasterize_backward with R = 1.
+ * ------------------------------------------------------------------------------------------------ */
+int cgs_rasterize_forward_static(void* geometry_buffer, void* binning_buffer, size_t binning_bytes, void* image_buffer,
+                                 uint32_t bucket_capacity, int P, int D, int M, const float* background, int width,
+                                 int height, const float* means3D, const float* shs, const float* colors_precomp,
+                                 const float* opacities, const float* scales, float scale_modifier,
+                                 const float* rotations, const float* cov3D_precomp, const float* all_map,
+                                 const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                                 float tan_fovy, float* out_color, float* out_invdepth, float* out_all_map,
+                                 int antialiasing, int render_geo, int* radii, void* stream);
+size_t cgs_image_status_offset(int width, int height);
+int cgs_status_words(void);
+uint32_t cgs_bucket_capacity_limit(void);
+
 /* Forget the sizes learnt from earlier forwards (the next forward takes the exact path and re-learns them). */
 void cgs_reset_binning_hints(void);
 void cgs_last_forward_stats(int64_t* num_rendered, int64_t* longest_tile_list, int* binning_path);

@@ -122,6 +122,59 @@ def test_train_step_reduces_loss_and_keeps_layout():
     assert np.isfinite(l2).all() and abs(l2[0] - losses[0]) < 1e-3 * abs(losses[0])
 
 
+def _train_fixture(n_curves=200, seed=11, H=64, W=96):
+    from curve_gaussian_amd.gaussian_renderer import PipelineParams, render
+    gm, c, cam = _model(n_curves, seed, H, W)
+    cams = [S.make_camera((0.5 + 1.8 * math.cos(a), 0.5 + 1.8 * math.sin(a), 0.9), (0.5, 0.5, 0.5), (0, 0, 1), H, W).to(DEV)
+            for a in (0.3, 1.7, 3.1, 4.4)]
+    with torch.no_grad():
+        gts = []
+        tgt, _, _ = _model(n_curves, seed, H, W)
+        tgt._curve_points.add_(0.01 * torch.randn_like(tgt._curve_points))
+        tgt.prepare_scaling_rot()
+        for cm in cams:
+            gts.append(render(cm, tgt, PipelineParams(), torch.zeros(3, device=DEV))["render"].detach())
+    return gm, cams, gts
+
+
+def test_graphed_train_step_equals_eager_and_recovers_from_bucket_overflow():
+    """GraphedTrainStep (one hipGraph launch per iteration, sync-free forward, device-state Adam) walks the same
+    parameter trajectory as the eager fused TrainStep; with deliberately tiny buckets the overflow flag makes the
+    captured Adam skip, the host redoes those views through the exact path, and the trajectory is still the same."""
+    from curve_gaussian_amd.train_step import GraphedTrainStep, TrainStep
+    torch.manual_seed(0)
+    gm_a, cams, gts = _train_fixture()
+    torch.manual_seed(0)
+    gm_b, _, _ = _train_fixture()
+    torch.manual_seed(0)
+    gm_c, _, _ = _train_fixture()
+    n = 12
+    eager = TrainStep(gm_a, cams, gts, seed=3)
+    la = [float(eager.step()[0]) for _ in range(n)]
+    graphed = GraphedTrainStep(gm_b, cams, gts, seed=3)
+    lb = []
+    for _ in range(n):
+        lb.append(graphed.step()[0])
+    graphed.finish()
+    lb = [float(x) for x in lb[-1:]]
+    assert graphed.recaptures == 1 and not graphed._inflight
+    tol = dict(rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(lb[-1], la[-1], rtol=1e-4)
+    for name in ("_curve_points", "_width", "_opacity"):
+        np.testing.assert_allclose(getattr(gm_b, name).detach().cpu().numpy(), getattr(gm_a, name).detach().cpu().numpy(), **tol)
+    np.testing.assert_allclose(gm_b._xyz.detach().cpu().numpy(), gm_a._xyz.detach().cpu().numpy(), **tol)
+    # overflow: 64-slot buckets are far too small for this scene -> every captured step is skipped and redone eagerly
+    tiny = GraphedTrainStep(gm_c, cams, gts, seed=3)
+    tiny._cap = 64
+    tiny._probe_capacity = lambda: 64
+    for _ in range(n):
+        tiny.step()
+    tiny.finish()
+    assert tiny.recaptures > 1 and gm_c.optimizer.step_count == n   # every view applied exactly once
+    for name in ("_curve_points", "_width", "_opacity"):
+        np.testing.assert_allclose(getattr(gm_c, name).detach().cpu().numpy(), getattr(gm_a, name).detach().cpu().numpy(), **tol)
+
+
 def test_flat_adam_matches_torch_adam():
     """cgs_adam_step_flat == torch.optim.Adam over the reference's parameter groups (per-group lr, eps=1e-15)."""
     from curve_gaussian_amd.ops.optim import FlatAdam

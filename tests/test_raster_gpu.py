@@ -349,6 +349,44 @@ def test_bucket_overflow_falls_back_to_exact_layout():
     fw.free()
 
 
+def test_static_forward_matches_and_flags_overflow():
+    """cgs_rasterize_forward_static (caller-owned buffers, no host sync): identical images, radii and gradients to the
+    normal forward when the buckets are large enough; with buckets that are too small the status flag is raised."""
+    from curve_gaussian_amd.diff_cur_rasterization import (GaussianRasterizationSettings, _C, rasterize_gaussians)
+    dev = torch.device(DEV)
+    H, W, P = 112, 176, 5000
+    sp = S.random_splats(P, 72)
+    cam = S.make_camera(*CAMS[1], H, W)
+    bg = torch.tensor([0.2, 0, 0])
+    g = rand_grads(H, W, 3)
+    ref = run_hip(sp, cam, bg, g)
+    rs0 = hip_settings(cam, bg, dev)
+    import ctypes
+    from curve_gaussian_amd import _lib
+    m = ctypes.c_int64()
+    _lib.load().cgs_last_forward_stats(None, ctypes.byref(m), None)
+    longest = int(m.value)
+    for cap, expect_overflow in ((((longest + 63) // 64) * 64, False), (max(64, (longest // 2) // 64 * 64), True)):
+        sink = []
+        rs = rs0._replace(static_bucket_cap=cap, status_sink=sink)
+        d = {k: v.to(dev).requires_grad_(k in ("means3D", "opacities", "scales", "rotations", "all_map")) for k, v in sp.items()}
+        empty = torch.empty(0, device=dev)
+        color, radii, invd, amap = rasterize_gaussians(d["means3D"], None, empty, d["colors"], d["opacities"], d["scales"],
+                                                       d["rotations"], empty, d["all_map"], rs)
+        status = sink[0].cpu().numpy()
+        assert bool(status[2]) == expect_overflow, (cap, longest, status[:8])
+        assert int(status[5::2].max()) == longest           # longest list from the partial maxima
+        if expect_overflow:
+            continue
+        assert int(status[4::2].sum()) > 0                   # num_rendered from the partial sums
+        assert np.array_equal(color.detach().cpu().numpy(), ref["color"]) and np.array_equal(radii.cpu().numpy(), ref["radii"])
+        assert np.array_equal(amap.detach().cpu().numpy(), ref["all_map"])
+        (color * g[0].to(dev)).sum().add((invd * g[1].to(dev)).sum()).add((amap * g[2].to(dev)).sum()).backward()
+        for k, name in (("means3D", "dL_dmeans3D"), ("opacities", "dL_dopacity"), ("scales", "dL_dscales"),
+                        ("rotations", "dL_drotations"), ("all_map", "dL_dall_map")):
+            assert_close("static grad " + k, d[k].grad.cpu().numpy(), ref["g"][name], rel=2e-5, outlier_frac=0.0, abs_floor=1e-7)
+
+
 def test_forward_is_deterministic_and_backward_linear():
     H, W = 112, 176
     sp = S.random_splats(6000, 71)
