@@ -13,7 +13,7 @@ from .fused_ssim import fused_ssim
 from .gaussian_renderer import PipelineParams, render
 from .ops.losses import edge_aware_loss, photometric_loss
 from .ops.optim import FlatAdam
-from .view_parallel import FlatGrads
+from .view_parallel import FlatGrads, StaticCamera as _StaticCamera
 
 
 class TrainStep:
@@ -74,23 +74,6 @@ class TrainStep:
             self.flat.zero_()                      # grads are views of the flat buffer: keep them, zero in place
         g.prepare_scaling_rot()                    # train.py:242-243
         return loss.detach(), pkg
-
-
-class _StaticCamera:
-    """Camera whose pose tensors are fixed device buffers refreshed before every graph replay."""
-
-    def __init__(self, proto, device):
-        self.image_height, self.image_width = int(proto.image_height), int(proto.image_width)
-        self.FoVx, self.FoVy = proto.FoVx, proto.FoVy
-        self.pack = torch.zeros(35, dtype=torch.float32, device=device)   # view 16 | proj 16 | centre 3
-        self.world_view_transform = self.pack[0:16].view(4, 4)
-        self.full_proj_transform = self.pack[16:32].view(4, 4)
-        self.camera_center = self.pack[32:35]
-
-    @staticmethod
-    def packed(cam):
-        return torch.cat([cam.world_view_transform.reshape(-1), cam.full_proj_transform.reshape(-1),
-                          cam.camera_center.reshape(-1)]).float().contiguous()
 
 
 class GraphedTrainStep(TrainStep):

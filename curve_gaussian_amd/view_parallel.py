@@ -48,6 +48,42 @@ class ViewStreams:
             cur.wait_stream(st)
 
 
+class StaticCamera:
+    """Camera whose pose tensors are fixed device buffers (one packed [35] float tensor: view 16 | proj 16 | centre 3),
+    so that a captured hipGraph can be replayed for any view after one small stream-ordered copy."""
+
+    def __init__(self, proto, device):
+        self.image_height, self.image_width = int(proto.image_height), int(proto.image_width)
+        self.FoVx, self.FoVy = proto.FoVx, proto.FoVy
+        self.pack = torch.zeros(35, dtype=torch.float32, device=device)
+        self.world_view_transform = self.pack[0:16].view(4, 4)
+        self.full_proj_transform = self.pack[16:32].view(4, 4)
+        self.camera_center = self.pack[32:35]
+
+    @staticmethod
+    def packed(cam):
+        return torch.cat([cam.world_view_transform.reshape(-1), cam.full_proj_transform.reshape(-1),
+                          cam.camera_center.reshape(-1)]).float().contiguous()
+
+    def load(self, packed):
+        self.pack.copy_(packed, non_blocking=True)
+
+
+def capture_graph(fn, stream, warmup=2):
+    """Warm `fn` up on `stream`, then capture it there as a hipGraph; returns (graph, fn's captured return value).
+    Warm-up and capture share the stream so the autograd gradient accumulators created by the warm-up live on the
+    capture stream (a captured backward that has to synchronise with the default stream cannot be captured)."""
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):
+        for _ in range(warmup):
+            fn()
+    torch.cuda.current_stream().wait_stream(stream)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        out = fn()
+    return graph, out
+
+
 class FlatGrads:
     """Owns the flat gradient buffer and installs views of it as the ``.grad`` of the given parameters."""
 
