@@ -1,0 +1,74 @@
+"""Turns the raw rocprofv3 output of profiles/collect.sh (gpurun_out/<tag>/) into the committed summaries:
+   profiles/<round>_kernel_stats.csv, <round>_kernel_stats_graph.csv, <round>_pmc.csv, <round>_traffic.json
+usage: python profiles/summarise.py <tag> <round-prefix, e.g. r01>"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+tag, rnd = sys.argv[1], sys.argv[2]
+root = f"gpurun_out/{tag}"
+
+SHORT = [("k_render_bwd", "render_bwd"), ("k_render_fwd", "render_fwd"), ("k_tile_rank_sort", "tile_sort"),
+         ("k_tile_sort", "tile_sort_big"), ("k_scatter", "scatter"), ("k_preprocess_fwd", "preprocess_fwd"),
+         ("k_preprocess_bwd", "preprocess_bwd"), ("k_scan_tiles", "scan_tiles"), ("k_sample_f1", "sample_f1"),
+         ("k_sample_f2", "sample_f2"), ("k_sample_f3", "sample_f3"), ("k_sample_bwd<1>", "sample_b1"),
+         ("k_sample_bwd<2>", "sample_b2"), ("k_sample_bwd<3>", "sample_b3"), ("k_attrs_fwd", "attrs_fwd"),
+         ("k_attrs_bwd", "attrs_bwd"), ("k_zero_vec", "zero_fill"), ("k_zero_words", "zero_fill")]
+
+
+def short(name):
+    for pat, s in SHORT:
+        if pat in name:
+            return s
+    return None
+
+
+def stats(sub, out, header):
+    f = sorted(glob.glob(f"{root}/{sub}/*/*_kernel_stats.csv"))[-1]
+    rows = list(csv.DictReader(open(f)))
+    with open(out, "w") as o:
+        o.write(header)
+        o.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
+        for r in rows:
+            nm = re.sub(r"\(.*", "", r["Name"])
+            if float(r["Percentage"]) < 0.05:
+                continue
+            o.write(f'"{nm}",{r["Calls"]},{r["TotalDurationNs"]},{float(r["AverageNs"]):.1f},{r["Percentage"]},{r["MinNs"]},{r["MaxNs"]}\n')
+
+
+stats("trace", f"profiles/{rnd}_kernel_stats.csv",
+      "# rocprofv3 --kernel-trace --stats -- python bench.py --streams 1 --views-per-step 1 --no-graph --no-cpu-baseline "
+      "--no-kernel-times --no-train-step --steps 16 --warmup 2   (cfg3, serial eager schedule; MI355X gfx950)\n")
+stats("trace_graph", f"profiles/{rnd}_kernel_stats_graph.csv",
+      "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-kernel-times --no-train-step --steps 16 "
+      "--warmup 2   (default schedule: 3 views in flight, one hipGraph replay per view; kernels of different views overlap, "
+      "so per-kernel durations are inflated relative to the serial schedule)\n")
+
+agg = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
+for f in glob.glob(f"{root}/*/*/*_counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        if k:
+            agg[k][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+with open(f"profiles/{rnd}_pmc.csv", "w") as o:
+    o.write("# rocprofv3 --pmc <8 counters> --kernel-trace, three SQ passes + FETCH_SIZE + WRITE_SIZE passes (profiles/collect.sh); "
+            "per-launch averages (summed over XCDs/SEs), serial eager schedule, cfg3\nKernel,Counter,AvgPerLaunch\n")
+    for k in sorted(agg):
+        for c in sorted(agg[k]):
+            v = agg[k][c]
+            o.write(f"{k},{c},{sum(v.values()) / len(v):.1f}\n")
+traffic = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, profiles/collect.sh), bench.py --steps 4 serial "
+                   "eager view mode cfg3, per-launch averages; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE "
+                   "half-count correction of MI355X_MICROARCH.md; WRITE_SIZE uncalibrated)",
+           "round": int(rnd[1:]), "snapshot": tag, "kernels": {}}
+for k in agg:
+    if "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
+        fv, wv = agg[k]["FETCH_SIZE"], agg[k]["WRITE_SIZE"]
+        fkb, wkb = sum(fv.values()) / len(fv), sum(wv.values()) / len(wv)
+        traffic["kernels"][k] = {"FETCH_SIZE_KB": round(fkb, 1), "WRITE_SIZE_KB": round(wkb, 1),
+                                 "hbm_bytes_per_launch": int((2 * fkb + wkb) * 1024)}
+json.dump(traffic, open(f"profiles/{rnd}_traffic.json", "w"), indent=1)
+print("wrote", rnd, "kernels with traffic:", sorted(traffic["kernels"]))
