@@ -80,12 +80,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-    else:
-        dist = None
+    dist = None   # the process group is created after the hipGraph captures (below): no RCCL thread runs during capture
 
     from curve_gaussian_amd import _lib as L
     from curve_gaussian_amd import synthetic as S
@@ -132,7 +127,7 @@ def main():
             bg, empty, xyz, radii, colors, amaps[id(cam)], opac, scl, rotn, 1.0, empty, cam.world_view_transform,
             cam.full_proj_transform, tanx, tany, dL_dcolor, empty, empty, empty, 0, cam.camera_center, gB, R, bB, iB,
             False, True, False)
-        if world > 1:
+        if dist is not None:
             dist.all_reduce(flat_grads)
         if collect:
             stats["R"] += R
@@ -197,7 +192,9 @@ def main():
                 lib.cgs_last_forward_stats(None, ctypes.byref(mlen), None)
                 longest = max(longest, int(mlen.value))
         cap = (int(longest * 1.5) + 64 + 63) // 64 * 64
-        if cap <= int(lib.cgs_bucket_capacity_limit()):
+        try:
+            if cap > int(lib.cgs_bucket_capacity_limit()):
+                raise RuntimeError(f'tile lists of {longest} entries exceed the bucket limit')
             packs = {id(c): StaticCamera.packed(c) for c in my_cams}
             overflow_acc = torch.zeros(1, dtype=torch.int32, device=dev)
             view_graphs = []
@@ -220,6 +217,9 @@ def main():
                 f.zero_()
             overflow_acc.zero_()
             torch.cuda.synchronize()
+        except Exception as e:   # capture is an optimisation: fall back to eager launches
+            print(f"bench: hipGraph capture unavailable ({e}); using eager launches", file=sys.stderr)
+            view_graphs = None
 
     def replay_view(j, cam):
         graph, scam, st = view_graphs[j % min(len(view_graphs), vstreams.n)]
@@ -247,15 +247,19 @@ def main():
             vstreams.join()
             for f in stream_flats[1:vstreams.n]:
                 flat_grads.add_(f)
-            if world > 1:
+            if dist is not None:
                 dist.all_reduce(flat_grads)
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
     use_graphs = [view_graphs is not None]
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
 
     def timed():
         run_views(my_cams[:Wm])
