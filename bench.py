@@ -426,19 +426,41 @@ def main():
         a_xyz, a_col, a_op, a_sc, a_rot = n(xyz), n(colors), n(opac), n(scl), n(rotn)
         dcol = n(dL_dcolor)
         nv = max(1, args.cpu_views)
-        tc0 = time.perf_counter()
+        t_fwd = t_bwd = 0.0
+        err = {}
         for i in range(nv):
             cam = my_cams[Wm + i]
+            tc0 = time.perf_counter()
             fw = ORA.forward(n(bg), a_xyz, a_col, a_op, a_sc, a_rot, 1.0, None, n(amaps[id(cam)]),
                              n(cam.world_view_transform), n(cam.full_proj_transform), tanx, tany, H, W, None, 0,
                              n(cam.camera_center))
-            ORA.backward(fw, dcol, None, None)
+            tc1 = time.perf_counter()
+            gr = ORA.backward(fw, dcol, None, None)
+            t_fwd += tc1 - tc0
+            t_bwd += time.perf_counter() - tc1
+            if i == 0:   # GPU vs CPU on the same inputs: worst error normalised by the tensor's max
+                (R_g, color_g, radii_g, gB, bB, iB, invd_g, om_g) = _C.rasterize_gaussians(
+                    bg, xyz, colors, opac, scl, rotn, 1.0, empty, amaps[id(cam)], cam.world_view_transform,
+                    cam.full_proj_transform, tanx, tany, H, W, empty, 0, cam.camera_center, False, False, True, False)
+                g_g = _C.rasterize_gaussians_backward(
+                    bg, empty, xyz, radii_g, colors, amaps[id(cam)], opac, scl, rotn, 1.0, empty,
+                    cam.world_view_transform, cam.full_proj_transform, tanx, tany, dL_dcolor, empty, empty, empty, 0,
+                    cam.camera_center, gB, R_g, bB, iB, False, True, False)
+                def nrm(a, b):   # parity criterion of tests/util.py: fraction of elements off by > 1e-4 * max|ref|
+                    e = np.abs(np.asarray(a, np.float64) - b) / (np.abs(b).max() + 1e-30)
+                    return float((e > 1e-4).mean())
+                err = {"color": nrm(n(color_g), fw.color), "all_map": nrm(n(om_g), fw.out_all_map),
+                       "dL_dmeans3D": nrm(n(g_g[3]), gr["dL_dmeans3D"]), "dL_dscales": nrm(n(g_g[6]), gr["dL_dscales"]),
+                       "dL_dopacity": nrm(n(g_g[2]), gr["dL_dopacity"]),
+                       "radii_equal": bool((n(radii_g) == fw.radii).all())}
             fw.free()
-        tc = time.perf_counter() - tc0
+        tc = t_fwd + t_bwd
         out["cpu_baseline"] = {"value": round(P * nv / tc / 1e6, 4), "unit": "Msplats/s", "cores": threads,
-                               "kind": "port",
-                               "sample": f"{nv} views of the same workload, fwd+bwd, oracle/raster_ref.c with OpenMP "
-                                         f"({threads} threads of {cores} host cores), {tc:.1f} s"}
+                               "kind": "port", "fwd_ms_per_view": round(t_fwd / nv * 1e3, 1),
+                               "bwd_ms_per_view": round(t_bwd / nv * 1e3, 1),
+                               "gpu_vs_cpu_frac_over_1e-4_of_max": {k: (v if isinstance(v, bool) else float(f"{v:.2e}")) for k, v in err.items()},
+                               "sample": f"{nv} views of the same workload (raster fwd+bwd), oracle/raster_ref.c with "
+                                         f"OpenMP ({threads} threads of {cores} host cores), {tc:.1f} s"}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
