@@ -95,6 +95,37 @@ def main():
         shd[f"sh_{deg_}"] = coeffs.numpy()
         shd[f"out_{deg_}"] = SH.eval_sh(deg_, coeffs, dirs).numpy()
     np.savez(os.path.join(OUT, "sh.npz"), **shd)
+
+    # --- EMAP frame -> camera (scene/dataset_readers.py:303-322 arithmetic on the reference's own graphics_utils,
+    #     then scene/cameras.py:59-66), own generator so the fixtures above keep their random streams
+    g2 = torch.Generator().manual_seed(4321)
+    q = torch.randn(5, 4, generator=g2)
+    q = q / q.norm(dim=1, keepdim=True)
+    r, x, y, z = q.unbind(1)
+    Rc = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y), 2 * (x * y + r * z),
+                      1 - 2 * (x * x + z * z), 2 * (y * z - r * x), 2 * (x * z - r * y), 2 * (y * z + r * x),
+                      1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3).double().numpy()
+    em = {"H": np.array(600), "W": np.array(800)}
+    c2ws, Ks, wvs, fulls, centers, fovs = [], [], [], [], [], []
+    for i in range(5):
+        c2w = np.eye(4)
+        c2w[:3, :3] = Rc[i]
+        c2w[:3, 3] = torch.randn(3, generator=g2).double().numpy() * 2.0
+        K = np.eye(4)
+        K[0, 0], K[1, 1], K[0, 2], K[1, 2] = 700.0 + 50 * i, 650.0 + 40 * i, 400.0, 300.0
+        w2c = np.linalg.inv(c2w)
+        Rr = np.transpose(w2c[:3, :3])
+        Tt = w2c[:3, 3]
+        fovy = GR.focal2fov(K[1, 1], 600)
+        fovx = GR.focal2fov(K[0, 0], 800)
+        wv = torch.tensor(GR.getWorld2View2(Rr, Tt)).transpose(0, 1)
+        pr = GR.getProjectionMatrix(znear=0.01, zfar=100.0, fovX=fovx, fovY=fovy).transpose(0, 1)
+        full = (wv.unsqueeze(0).bmm(pr.unsqueeze(0))).squeeze(0)
+        c2ws.append(c2w); Ks.append(K); wvs.append(wv.numpy()); fulls.append(full.numpy())
+        centers.append(wv.inverse()[3, :3].numpy()); fovs.append([fovx, fovy])
+    np.savez(os.path.join(OUT, "emap_camera.npz"), camtoworld=np.stack(c2ws), intrinsics=np.stack(Ks),
+             world_view_transform=np.stack(wvs), full_proj_transform=np.stack(fulls), camera_center=np.stack(centers),
+             fov=np.array(fovs), **em)
     print("golden fixtures written to", OUT)
 
 

@@ -1,0 +1,81 @@
+"""On-disk formats either side of the hot path: EMAP scan reader/writer, parametric_edges.json."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from curve_gaussian_amd import synthetic as S
+from curve_gaussian_amd.scene import dataset_io as IO
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_emap_frame_to_camera_matches_reference_golden():
+    """camtoworld + intrinsics -> R, T, FoV, world_view / full_proj / centre: the reference's own graphics_utils
+    (imported by tests/golden/make_golden.py) composed as dataset_readers.py:303-322 and cameras.py:59-66."""
+    d = np.load(os.path.join(GOLD, "emap_camera.npz"))
+    H, W = int(d["H"]), int(d["W"])
+    for i in range(d["camtoworld"].shape[0]):
+        cam = IO.camera_from_emap_frame(i, str(i), d["camtoworld"][i], d["intrinsics"][i], torch.zeros(3, H, W))
+        np.testing.assert_allclose([cam.FoVx, cam.FoVy], d["fov"][i], rtol=1e-12)
+        np.testing.assert_allclose(cam.world_view_transform.numpy(), d["world_view_transform"][i], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(cam.full_proj_transform.numpy(), d["full_proj_transform"][i], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(cam.camera_center.numpy(), d["camera_center"][i], rtol=1e-5, atol=1e-5)
+
+
+def test_emap_scan_round_trip(tmp_path):
+    """write_emap -> read_emap reproduces the cameras (pose, field of view, size) and the edge maps up to 8-bit
+    quantisation; RGBA opening replicates the single-channel map into three equal channels (dataset_readers.py:319)."""
+    cams = S.fibonacci_cameras(5, 48, 64)
+    g = torch.Generator().manual_seed(0)
+    maps = [torch.rand(1, 48, 64, generator=g) for _ in cams]
+    IO.write_emap(str(tmp_path), cams, maps)
+    meta = json.load(open(tmp_path / "meta_data.json"))
+    assert meta["height"] == 48 and meta["width"] == 64 and len(meta["frames"]) == 5
+    assert set(meta["frames"][0]) == {"rgb_path", "camtoworld", "intrinsics"}
+    back = IO.read_emap(str(tmp_path))
+    assert len(back) == 5
+    for a, b, m in zip(cams, back, maps):
+        assert (b.image_height, b.image_width) == (48, 64)
+        np.testing.assert_allclose([b.FoVx, b.FoVy], [a.FoVx, a.FoVy], rtol=1e-9)
+        np.testing.assert_allclose(b.world_view_transform.numpy(), a.world_view_transform.numpy(), atol=2e-6)
+        np.testing.assert_allclose(b.full_proj_transform.numpy(), a.full_proj_transform.numpy(), atol=2e-5)
+        np.testing.assert_allclose(b.camera_center.numpy(), a.camera_center.numpy(), atol=2e-5)
+        assert b.original_image.shape == (3, 48, 64)
+        assert torch.equal(b.original_image[0], b.original_image[1]) and torch.equal(b.original_image[0], b.original_image[2])
+        assert float((b.original_image[:1] - m).abs().max()) <= 0.5 / 255 + 1e-6
+    import pytest
+    with pytest.raises(ValueError, match="not supported"):
+        IO.read_emap(str(tmp_path), detector="Canny")
+
+
+def test_parametric_edges_writer(tmp_path):
+    """parametric_edges.json layout (train.py:266-293 through process_geometry_data): Bezier curves as 4x3 control
+    points, line segments as 6 floats (first and last control point); edge points every 5 mm of arc length."""
+    class G:
+        pass
+    g = G()
+    cp = torch.tensor([[[0, 0, 0], [0.1, 0, 0], [0.2, 0, 0], [0.3, 0, 0]],          # straight Bezier, length 0.3
+                       [[0, 0, 0], [0, 0.5, 0], [0, 0.5, 0], [0, 1.0, 0]],           # becomes a line segment
+                       [[0, 0, 0], [0.0, 0.1, 0], [0.1, 0.1, 0], [0.1, 0.0, 0]]], dtype=torch.float32)
+    g.get_curve_points = cp
+    g.is_bezier = torch.tensor([True, False, True])
+    edge_dict, pts = IO.write_parametric_edges(g, str(tmp_path))
+    saved = json.load(open(tmp_path / "parametric_edges.json"))
+    assert saved == edge_dict
+    assert np.array(saved["curves_ctl_pts"]).shape == (2, 4, 3) and np.array(saved["lines_end_pts"]).shape == (1, 6)
+    np.testing.assert_allclose(saved["lines_end_pts"][0], [0, 0, 0, 0, 1.0, 0])
+    np.testing.assert_allclose(IO.bezier_curve_length(cp[0].numpy()), 0.3, rtol=1e-6)   # float32 control points
+    # arc length of the third curve against a fine polyline
+    t = np.linspace(0, 1, 20001)[:, None]
+    P = cp[2].numpy().astype(np.float64)
+    poly = (1 - t) ** 3 * P[0] + 3 * (1 - t) ** 2 * t * P[1] + 3 * (1 - t) * t ** 2 * P[2] + t ** 3 * P[3]
+    L = np.linalg.norm(np.diff(poly, axis=0), axis=1).sum()
+    np.testing.assert_allclose(IO.bezier_curve_length(P), L, rtol=1e-6)
+    n_expected = (int(IO.bezier_curve_length(cp[0].numpy()) // 0.005) + int(IO.bezier_curve_length(P) // 0.005) +
+                  int(np.linalg.norm(cp[1, 0].numpy().astype(np.float64) - cp[1, 3].numpy()) // 0.005))
+    assert abs(n_expected - (60 + int(L // 0.005) + 200)) <= 2
+    assert len(pts) == n_expected
+    head = open(tmp_path / "edge_points.ply").read().split("end_header")[0]
+    assert "format ascii 1.0" in head and f"element vertex {n_expected}" in head

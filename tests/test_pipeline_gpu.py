@@ -228,3 +228,43 @@ def test_photometric_loss_equals_composition(clamp):
     if clamp:
         outside = ((img < 0) | (img > 1)).numpy()
         assert outside.any() and (b.grad.cpu().numpy()[outside] == 0).all()
+
+
+def test_cfg1_plumbing_scan_on_disk_to_parametric_edges(tmp_path):
+    """BASELINE cfg1 end to end without the reference's loaders: a synthetic EMAP-format scan is written to disk
+    (meta_data.json + edge_DexiNed/*.png), read back with scene.dataset_io, trained for a few iterations on the HIP
+    path (graphed train step), and the curves are written out as parametric_edges.json / edge_points.ply."""
+    import json
+    from curve_gaussian_amd.gaussian_renderer import PipelineParams, render
+    from curve_gaussian_amd.scene import GaussianCurveModel, dataset_io as IO
+    from curve_gaussian_amd.train_step import GraphedTrainStep
+    H = W = 160
+    curves = S.make_curves(417, 1)
+    cams = S.fibonacci_cameras(6, H, W)
+    tgt = GaussianCurveModel(0, 12, device=DEV).create_from_curves(curves["curve_points"], curves["width"], curves["opacity"],
+                                                                   curves["mask"], curves["is_bezier"])
+    with torch.no_grad():
+        maps = [render(c.to(DEV), tgt, PipelineParams(), torch.zeros(3, device=DEV))["render"].cpu() for c in cams]
+    IO.write_emap(str(tmp_path / "scan"), cams, maps)
+    loaded = [c.to(DEV) for c in IO.read_emap(str(tmp_path / "scan"))]
+    assert len(loaded) == 6 and loaded[0].original_image.shape == (3, H, W)
+    for a, b in zip(cams, loaded):
+        np.testing.assert_allclose(b.full_proj_transform.cpu().numpy(), a.full_proj_transform.numpy(), atol=2e-5)
+    # start from perturbed curves and fit the loaded edge maps (train.py uses channel 0 of the edge map)
+    start = {k: v.clone() for k, v in curves.items()}
+    start["curve_points"] = start["curve_points"] + 0.004 * torch.randn(start["curve_points"].shape, generator=torch.Generator().manual_seed(2))
+    gm = GaussianCurveModel(0, 12, device=DEV).create_from_curves(start["curve_points"], start["width"], start["opacity"],
+                                                                  start["mask"], start["is_bezier"])
+    ts = GraphedTrainStep(gm, loaded, [c.original_image[:1].contiguous() for c in loaded], seed=0)
+    losses = []
+    for it in range(40):
+        l, _ = ts.step()
+        if it % 10 == 0 or it == 39:
+            losses.append(float(l))
+    ts.finish()
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    edge_dict, pts = IO.write_parametric_edges(gm, str(tmp_path / "out"))
+    saved = json.load(open(tmp_path / "out" / "parametric_edges.json"))
+    assert np.array(saved["curves_ctl_pts"]).shape == (417, 4, 3) and saved["lines_end_pts"] == []
+    assert len(pts) > 417 and os.path.getsize(tmp_path / "out" / "edge_points.ply") > 0
+    np.testing.assert_allclose(np.array(saved["curves_ctl_pts"]), gm._curve_points.detach().cpu().numpy(), rtol=1e-6)
