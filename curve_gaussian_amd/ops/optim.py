@@ -55,6 +55,45 @@ class FlatAdam:
                                         torch.cuda.current_stream(self.device).cuda_stream)
         L.check(rc, "cgs_adam_step_flat")
 
+    # ---- topology edits (scene/topology.py): per-curve tensors change their first dimension
+    def state_of(self, name):
+        """(exp_avg, exp_avg_sq) views shaped like the parameter, or None before the first step (torch.optim.Adam
+        creates its state lazily; the reference's surgery code branches on that)."""
+        if self.step_count == 0:
+            return None
+        a, b = self.grads.slices[name]
+        p = self.params[name]
+        return self.exp_avg[a:b].view_as(p), self.exp_avg_sq[a:b].view_as(p)
+
+    def rebuild(self, new_params, new_state):
+        """Replace every group's values (dict name -> tensor, new leading dimension allowed) and Adam moments (dict name
+        -> (exp_avg, exp_avg_sq) or None = zeros): new flat parameter / gradient / moment buffers, new nn.Parameters
+        that are views of them.  Returns name -> nn.Parameter; step count and learning rates are kept."""
+        from ..view_parallel import FlatGrads
+        import torch.nn as nn
+        shapes = {n: tuple(new_params[n].shape) for n in self.names}
+        total = sum(int(torch.tensor(s).prod()) if len(s) else 1 for s in shapes.values())
+        flat = torch.empty(total, dtype=torch.float32, device=self.device)
+        m = torch.zeros(total, dtype=torch.float32, device=self.device)
+        v = torch.zeros(total, dtype=torch.float32, device=self.device)
+        out, o = {}, 0
+        for n in self.names:
+            t = new_params[n].detach().float()
+            k = t.numel()
+            flat[o:o + k].copy_(t.reshape(-1))
+            st = new_state.get(n) if new_state else None
+            if st is not None:
+                m[o:o + k].copy_(st[0].reshape(-1))
+                v[o:o + k].copy_(st[1].reshape(-1))
+            out[n] = nn.Parameter(flat[o:o + k].view(shapes[n]))
+            o += k
+        self.flat, self.exp_avg, self.exp_avg_sq = flat, m, v
+        self.params = out
+        self.grads = FlatGrads(out)
+        for g in self.param_groups:
+            g["params"] = [out[g["name"]]]
+        return out
+
     # ---- graph-replayable variant: per-step scalars in device memory, optional device-side skip flag
     def device_state(self):
         """(device uint8 tensor, pinned host mirror) holding {segments, 1 - b1^t, sqrt(1 - b2^t)} for cgs_adam_step_flat_dev."""

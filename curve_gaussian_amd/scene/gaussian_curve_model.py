@@ -1,7 +1,7 @@
 """Hot-path part of the reference's ``scene.gaussian_curve_model.GaussianCurveModel``
 (/root/reference/scene/gaussian_curve_model.py:54-198): the learnable curve tensors, their layout, and the
-per-step derivation of per-splat tensors (``prepare_scaling_rot``).  Topology edits (densify / split / merge,
-:246-727) are out of scope.
+per-step derivation of per-splat tensors (``prepare_scaling_rot``).  Topology edits (densify / split / prune / trim, :246-463) live in scene/topology.py and are
+installed as methods below; merge_curves (:466ff) is not reproduced.
 
 Tensor layout (kept exactly): ``_curve_points [B,4,3]``, ``_width [B,1]`` (log), ``_opacity [B,1]`` (logit),
 ``_mask [B,m,1]``, ``_features_dc [B,m,1,1]``, ``_features_rest [B,m,(D+1)^2-1,1]``, ``is_bezier [B]``; derived
@@ -160,3 +160,17 @@ class GaussianCurveModel:
         self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1,
                                                              keepdim=True)
         self.denom[update_filter] += 1
+
+
+def _install_topology():
+    from . import topology
+    for name, fn in topology.METHODS.items():
+        setattr(GaussianCurveModel, name, fn)
+
+    def add_topology_listener(self, cb):
+        """cb() runs after every topology edit (the train step rebinds its flat buffers / drops its captured graph)."""
+        self.__dict__.setdefault("_topology_listeners", []).append(cb)
+    GaussianCurveModel.add_topology_listener = add_topology_listener
+
+
+_install_topology()

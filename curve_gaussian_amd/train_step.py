@@ -40,6 +40,18 @@ class TrainStep:
             gaussians.optimizer = FlatAdam(named, lrs, self.flat, eps=1e-15)
             gaussians.prepare_scaling_rot()   # parameters moved into the flat buffer: rebuild the derived tensors
         self.iteration = 0
+        if hasattr(gaussians, "add_topology_listener"):
+            gaussians.add_topology_listener(self._on_topology_change)
+
+    def _on_topology_change(self):
+        """The per-curve tensors were resized (scene/topology.py): rebind the flat gradient buffer."""
+        g = self.g
+        named = {"curve_points": g._curve_points, "width": g._width, "opacity": g._opacity, "mask": g._mask,
+                 "f_dc": g._features_dc, "f_rest": g._features_rest}
+        if self.fused:
+            self.flat = g.optimizer.grads          # FlatAdam.rebuild made new flat buffers and views
+        else:
+            self.flat = FlatGrads(named)
 
     def _next_view(self):
         if not self.stack:
@@ -243,6 +255,13 @@ class GraphedTrainStep(TrainStep):
         if len(self._inflight) > 32:
             self._check_overflow(block=True)
         return self._loss, None
+
+    def _on_topology_change(self):
+        TrainStep._on_topology_change(self)
+        self._graph = None      # sizes are graph constants: re-probe the bucket capacity and re-capture
+        self._cap = 0
+        self._loss = self._status = None
+        self._derived_stale = False
 
     def _refresh_derived(self):
         if getattr(self, "_derived_stale", False):

@@ -1,0 +1,158 @@
+"""Curve-topology edits on the GPU model (restatement of gaussian_curve_model.py:246-463, parity
+unpinned -- the reference's scene package cannot be imported here): checked through mathematical properties and
+through agreement between the two optimizer back ends (torch.optim.Adam bookkeeping of the reference vs the flat
+buffers of the hot path)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from util import S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _bezier(cp, t):
+    t = t.reshape(-1, 1)
+    return ((1 - t) ** 3 * cp[:, 0] + 3 * (1 - t) ** 2 * t * cp[:, 1] + 3 * (1 - t) * t ** 2 * cp[:, 2] + t ** 3 * cp[:, 3])
+
+
+def _model(B=60, seed=5, lines=False):
+    from curve_gaussian_amd.scene import GaussianCurveModel
+    c = S.make_curves(B, seed)
+    isb = c["is_bezier"].clone()
+    if lines:
+        isb[::3] = False
+    return GaussianCurveModel(0, 12, device=DEV).create_from_curves(c["curve_points"], c["width"], c["opacity"], c["mask"], isb), c
+
+
+@pytest.mark.parametrize("lines", [False, True])
+def test_de_casteljau_split_and_trim_reproduce_the_curve(lines):
+    g, c = _model(40, 3, lines)
+    cp = g.get_curve_points.detach()
+    gen = torch.Generator().manual_seed(0)
+    t = (0.1 + 0.8 * torch.rand(40, generator=gen)).to(DEV)
+    left, right = g.de_casteljau_split(cp, t, g.is_bezier)
+    s = torch.linspace(0, 1, 9, device=DEV)
+    for si in s:
+        sv = torch.full((40,), float(si), device=DEV)
+        ref_l = _bezier(cp, t * sv)
+        ref_r = _bezier(cp, t + (1 - t) * sv)
+        isb = g.is_bezier
+        # Bezier curves: the halves are re-parametrisations of the original; straight segments: halves of the chord
+        np.testing.assert_allclose(_bezier(left, sv)[isb].cpu().numpy(), ref_l[isb].cpu().numpy(), atol=2e-6)
+        np.testing.assert_allclose(_bezier(right, sv)[isb].cpu().numpy(), ref_r[isb].cpu().numpy(), atol=2e-6)
+        if lines:
+            chord = lambda u: cp[:, 0] + u.reshape(-1, 1) * (cp[:, 3] - cp[:, 0])
+            np.testing.assert_allclose(_bezier(left, sv)[~isb].cpu().numpy(), chord(t * sv)[~isb].cpu().numpy(), atol=2e-6)
+            np.testing.assert_allclose(_bezier(right, sv)[~isb].cpu().numpy(), chord(t + (1 - t) * sv)[~isb].cpu().numpy(), atol=2e-6)
+    # trim = right part after from_t, then left part of THAT at end_t (parameters as written in the reference)
+    a = torch.full((40,), 0.25, device=DEV)
+    b = torch.full((40,), 0.5, device=DEV)
+    tr = g.de_casteljau_trim(cp, a, b, g.is_bezier)
+    isb = g.is_bezier
+    np.testing.assert_allclose(tr[isb][:, 0].cpu().numpy(), _bezier(cp, a)[isb].cpu().numpy(), atol=2e-6)
+    np.testing.assert_allclose(tr[isb][:, 3].cpu().numpy(), _bezier(cp, a + (1 - a) * b)[isb].cpu().numpy(), atol=2e-6)
+
+
+def _train_pair(B=80):
+    """Two identical models/trainers: reference-style torch Adam (fused=False) and the flat hot-path optimizer."""
+    from curve_gaussian_amd.gaussian_renderer import PipelineParams, render
+    from curve_gaussian_amd.train_step import TrainStep
+    cams = [S.make_camera((0.5 + 1.8 * math.cos(a), 0.5 + 1.8 * math.sin(a), 0.9), (0.5, 0.5, 0.5), (0, 0, 1), 64, 96).to(DEV)
+            for a in (0.3, 1.7, 3.1)]
+    ga, _ = _model(B, 7)
+    gb, _ = _model(B, 7)
+    with torch.no_grad():
+        tgt, _ = _model(B, 7)
+        tgt._curve_points.add_(0.01 * torch.randn(tgt._curve_points.shape, generator=torch.Generator().manual_seed(1)).to(DEV))
+        tgt.prepare_scaling_rot()
+        gts = [render(c, tgt, PipelineParams(), torch.zeros(3, device=DEV))["render"].detach() for c in cams]
+    return (ga, TrainStep(ga, cams, gts, seed=2, fused=False)), (gb, TrainStep(gb, cams, gts, seed=2, fused=True))
+
+
+def _params(g):
+    return {n: getattr(g, n).detach().cpu().numpy() for n in ("_curve_points", "_width", "_opacity", "_mask")}
+
+
+def test_prune_and_split_keep_both_optimizers_in_step():
+    """Train, prune, split, reset opacity, train again: the torch.optim.Adam path (the reference's own state surgery)
+    and the flat-buffer path end with the same parameters, and the Adam moments of surviving curves are carried over
+    (new curves start from zero moments)."""
+    (ga, ta), (gb, tb) = _train_pair()
+    for _ in range(4):
+        ta.step(); tb.step()
+    B0 = ga._curve_points.shape[0]
+    kill = torch.zeros(B0, dtype=torch.bool, device=DEV)
+    kill[::7] = True
+    m_before = gb.optimizer.state_of("curve_points")[0].clone()
+    for g in (ga, gb):
+        g.prune_curves(kill)
+    B1 = B0 - int(kill.sum())
+    assert ga._curve_points.shape[0] == gb._curve_points.shape[0] == B1 and gb._xyz.shape[0] == B1 * 12
+    np.testing.assert_array_equal(gb.optimizer.state_of("curve_points")[0].cpu().numpy(), m_before[~kill].cpu().numpy())
+    assert gb._curve_points.grad.data_ptr() == tb.flat.flat.data_ptr()          # rebinding happened
+    sel = torch.zeros(B1, dtype=torch.bool, device=DEV)
+    sel[1::5] = True
+    t = torch.full((int(sel.sum()),), 0.4, device=DEV)
+    cp_before = gb.get_curve_points.detach().clone()
+    for g in (ga, gb):
+        g.densify_and_split_curve(sel, t)
+    k = int(sel.sum())
+    B2 = B1 + k
+    assert gb._curve_points.shape[0] == B2 and gb.is_bezier.shape[0] == B2 and gb.xyz_gradient_accum.shape == (B2 * 12, 1)
+    # survivors first (order kept), then the k left halves, then the k right halves; new curves have zero moments
+    np.testing.assert_array_equal(gb._curve_points[:B1 - k].detach().cpu().numpy(), cp_before[~sel].cpu().numpy())
+    np.testing.assert_allclose(gb._curve_points[B1 - k:B1, 3].detach().cpu().numpy(),
+                               gb._curve_points[B1:, 0].detach().cpu().numpy(), atol=1e-7)   # halves meet at S
+    assert float(gb.optimizer.state_of("curve_points")[0][B1 - k:].abs().max()) == 0.0
+    for g in (ga, gb):
+        g.reset_opacity()
+    assert float(gb.get_curve_opacity.max()) <= 0.1 + 1e-6
+    assert float(gb.optimizer.state_of("opacity")[0].abs().max()) == 0.0
+    for _ in range(3):
+        la = ta.step()[0]; lb = tb.step()[0]
+    assert np.isfinite(float(la)) and abs(float(la) - float(lb)) < 1e-4 * abs(float(la)) + 1e-6
+    pa, pb = _params(ga), _params(gb)
+    for n in pa:
+        np.testing.assert_allclose(pb[n], pa[n], rtol=2e-4, atol=2e-5, err_msg=n)
+
+
+def test_densify_and_prune_selects_by_mean_gradient_and_opacity():
+    g, _ = _model(30, 9)
+    g.training_setup()
+    P = 30 * 12
+    g.xyz_gradient_accum = torch.zeros(P, 1, device=DEV)
+    g.denom = torch.zeros(P, 1, device=DEV)
+    # curve 4: large mean gradient at sample 7; every other splat was never observed (0 / 0 -> NaN -> 0)
+    g.xyz_gradient_accum[4 * 12 + 7] = 6.0
+    g.denom[4 * 12 + 7] = 2.0
+    with torch.no_grad():
+        g._opacity[11] = -9.0        # sigmoid << min_opacity -> pruned
+    cp4 = g.get_curve_points.detach()[4].clone()
+    g.densify_and_prune(max_grad=2.5, min_opacity=0.005, extent=1.0, max_screen_size=None, radii=torch.zeros(P, device=DEV))
+    assert g._curve_points.shape[0] == 30 + 1 - 1          # one split (+2 -1), one pruned
+    t = (7 + 0.5) / 12
+    S_pt = _bezier(cp4[None], torch.tensor([t], device=DEV))[0]
+    ends = g._curve_points.detach()[:, 3]
+    assert float((ends - S_pt).abs().sum(-1).min()) < 1e-6  # some curve now ends at the split point
+    assert float(g.get_curve_opacity.min()) >= 0.005
+
+
+def test_graphed_train_step_recaptures_after_topology_change():
+    from curve_gaussian_amd.train_step import GraphedTrainStep
+    (ga, ta), (gb, _) = _train_pair(60)
+    gs = GraphedTrainStep(gb, ta.cams, ta.gts, seed=2)
+    for _ in range(3):
+        gs.step()
+    gs.finish()
+    kill = torch.zeros(60, dtype=torch.bool, device=DEV)
+    kill[:10] = True
+    gb.prune_curves(kill)
+    assert gs._graph is None
+    for _ in range(3):
+        l = gs.step()[0]
+    gs.finish()
+    assert gs.recaptures == 2 and np.isfinite(float(l)) and gb._xyz.shape[0] == 50 * 12
