@@ -541,7 +541,7 @@ int cgs_sample_curves_backward(int B, int m, const float* curve_points, const fl
         set_error("cgs_sample_curves_backward: invalid argument");
         return CGS_ERR_INVALID_ARGUMENT;
     }
-    if (zero_async(norms + sample_norm_words() / 2, (size_t)(sample_norm_words() / 2) * sizeof(double), s) != hipSuccess) {
+    if (zero_async(norms + sample_norm_fwd_words(), (size_t)(sample_norm_words() - sample_norm_fwd_words()) * sizeof(double), s) != hipSuccess) {
         set_error("zero_async(norms) failed");
         return CGS_ERR_HIP;
     }

@@ -50,6 +50,7 @@ void launch_render_bwd(hipStream_t s, bool geo, bool invd, bool colg, int tiles,
 
 // sampling.hip
 int sample_norm_words();
+int sample_norm_fwd_words();
 void launch_sample_forward(hipStream_t s, int B, int m, const float* cp, const float* width, const uint8_t* is_bezier,
                            const void* coef, float eps, double* norms, float* xyz, float* rot, float* scaling);
 void launch_sample_backward(hipStream_t s, int B, int m, const float* cp, const float* width, const uint8_t* is_bezier,

@@ -22,7 +22,13 @@ namespace cgs {
 // atomics serialise at ~20 ns each: 782 blocks on one address cost more than the kernels themselves, 49 per slot do
 // not), and every consumer sums the slots while staging its constants.
 constexpr int NORM_SLOTS = 16;
-constexpr int NORM_WORDS = 4 * NORM_SLOTS;  // norms[q * NORM_SLOTS + slot], q = 0: |v1|^2, 1: |v2|^2, 2: D2, 3: D1
+// norms[q * NORM_SLOTS + slot].  Forward (k_sample_f12, ONE pass): q0 = S1 = sum |c1v|^2, q1 = S2 = sum |cross(tan,c1v)|^2,
+// q2 = BS = sum dot(cross(cross(tan,c1v), tan), c1v), from which N1 = sqrt(S1), N2 = sqrt(S2) / N1 (c2v = cross(tan,
+// c1v / N1)).  Backward (k_sample_bwd<1>, ONE pass): q3 = D2 = sum dot(g_v2, c2v), q4 = A = sum dot(g_v1 +
+// cross(g_v2, tan) / N2, c1v); the second global term follows in closed form, D1 = A - D2 / N2^3 * BS / N1 (it is
+// linear in D2), so neither direction needs a second grid-wide pass.
+constexpr int NQ_FWD = 3, NQ_ALL = 5;
+constexpr int NORM_WORDS = NQ_ALL * NORM_SLOTS;
 
 struct SampleCoef {  // per-sample coefficients, computed on the host with the reference's float32 torch expressions
     float c[4];      // Bezier point weights at t_i
@@ -65,14 +71,20 @@ __device__ __forceinline__ void stage_consts(const SampleCoef* __restrict__ coef
     const float* src = reinterpret_cast<const float*>(coef);
     float* dst = reinterpret_cast<float*>(s_coef);
     for (int t = threadIdx.x; t < m * 16; t += blockDim.x) dst[t] = src[t];
-    if (threadIdx.x < 64) {  // wave 0: lane = q * NORM_SLOTS + slot
+    __shared__ double s_q[NQ_ALL];
+    if (threadIdx.x < NQ_ALL * NORM_SLOTS) {  // 16-lane groups: lane = q * NORM_SLOTS + slot
         double v = norms[threadIdx.x];
 #pragma unroll
         for (int off = NORM_SLOTS / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (threadIdx.x == 0 * NORM_SLOTS) s_bc->N1 = (float)sqrt(v);
-        if (threadIdx.x == 1 * NORM_SLOTS) s_bc->N2 = (float)sqrt(v);
-        if (threadIdx.x == 2 * NORM_SLOTS) s_bc->D2 = (float)v;
-        if (threadIdx.x == 3 * NORM_SLOTS) s_bc->D1 = (float)v;
+        if ((threadIdx.x % NORM_SLOTS) == 0) s_q[threadIdx.x / NORM_SLOTS] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double N1 = sqrt(s_q[0]), N2 = sqrt(s_q[1]) / N1;
+        s_bc->N1 = (float)N1;
+        s_bc->N2 = (float)N2;
+        s_bc->D2 = (float)s_q[3];
+        s_bc->D1 = (float)(s_q[4] - s_q[3] / (N2 * N2 * N2) * (s_q[2] / N1));
     }
     __syncthreads();
 }
@@ -92,41 +104,32 @@ __device__ __forceinline__ void block_accumulate(double v, double* norms, int q)
         for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += s_part[w];
         atomicAdd(target, t);
     }
+    __syncthreads();  // s_part is reused by the next quantity
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-__global__ void __launch_bounds__(256) k_sample_f1(int B, int m, const float* __restrict__ cp,
-                                                   const uint8_t* __restrict__ is_bezier,
-                                                   const SampleCoef* __restrict__ coef, double* __restrict__ norms) {
+__global__ void __launch_bounds__(256) k_sample_f12(int B, int m, const float* __restrict__ cp,
+                                                    const uint8_t* __restrict__ is_bezier,
+                                                    const SampleCoef* __restrict__ coef, double* __restrict__ norms) {
     __shared__ SampleCoef s_coef[MAX_M];
-    __shared__ BlockConst s_bc;
-    stage_consts(coef, m, norms, s_coef, &s_bc);
-    double acc = 0;
+    const float* src = reinterpret_cast<const float*>(coef);
+    float* dst = reinterpret_cast<float*>(s_coef);
+    for (int t = threadIdx.x; t < m * 16; t += blockDim.x) dst[t] = src[t];
+    __syncthreads();
+    double a1 = 0, a2 = 0, a3 = 0;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < B * m; p += gridDim.x * blockDim.x) {
         const int b = p / m, i = p - b * m;
         const CurveCP c = load_curve(cp, is_bezier, b);
         const V3 t = curve_tangent(c, s_coef[i]);
-        acc += (double)(t.y * t.y) + (double)(t.x * t.x);  // |cross(tan,(0,0,1))|^2 = ty^2 + tx^2
+        const V3 c1 = {t.y, -t.x, 0.f};                 // cross(tan, (0,0,1))
+        const V3 x = cross(t, c1);                      // N1 * c2v
+        a1 += (double)(t.y * t.y) + (double)(t.x * t.x);
+        a2 += (double)(x.x * x.x) + (double)(x.y * x.y) + (double)(x.z * x.z);
+        a3 += (double)dot(cross(x, t), c1);
     }
-    block_accumulate(acc, norms, 0);
-}
-__global__ void __launch_bounds__(256) k_sample_f2(int B, int m, const float* __restrict__ cp,
-                                                   const uint8_t* __restrict__ is_bezier,
-                                                   const SampleCoef* __restrict__ coef, double* __restrict__ norms) {
-    __shared__ SampleCoef s_coef[MAX_M];
-    __shared__ BlockConst s_bc;
-    stage_consts(coef, m, norms, s_coef, &s_bc);
-    const float N1 = s_bc.N1;
-    double acc = 0;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < B * m; p += gridDim.x * blockDim.x) {
-        const int b = p / m, i = p - b * m;
-        const CurveCP c = load_curve(cp, is_bezier, b);
-        const V3 t = curve_tangent(c, s_coef[i]);
-        const V3 v1 = {t.y / N1, -t.x / N1, 0.f / N1};
-        const V3 c2 = cross(t, v1);
-        acc += (double)(c2.x * c2.x) + (double)(c2.y * c2.y) + (double)(c2.z * c2.z);
-    }
-    block_accumulate(acc, norms, 1);
+    block_accumulate(a1, norms, 0);
+    block_accumulate(a2, norms, 1);
+    block_accumulate(a3, norms, 2);
 }
 
 struct QuatFwd { float a[4], qa[4], N[4], D; int k; bool flip; };
@@ -255,7 +258,7 @@ __global__ void __launch_bounds__(256) k_sample_f3(int B, int m, const float* __
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-// PASS 1: D2 (norms[2]);  PASS 2: D1 (norms[3]);  PASS 3: write dL/dcurve_points, dL/dwidth.
+// PASS 1: the two global sums D2 and A (one pass, see NORM layout);  PASS 3: write dL/dcurve_points, dL/dwidth.
 // Blocks hold CURVES_PER_BLOCK whole curves (CURVES_PER_BLOCK * m threads are active); pass 3 reduces the per-sample
 // contributions to the 13 per-curve outputs through LDS.
 constexpr int SAMPLE_BLOCK = 256;
@@ -277,10 +280,10 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_sample_bwd(int B, int m, int c
     stage_consts(coef, m, norms, s_coef, &s_bc);
     const float N1 = s_bc.N1, N2 = s_bc.N2;
     const float D2 = PASS >= 2 ? s_bc.D2 : 0.f, D1 = PASS >= 3 ? s_bc.D1 : 0.f;
-    double acc = 0;
+    double acc = 0, acc_a = 0;
     V3 gp0 = {0, 0, 0}, gp1 = {0, 0, 0}, gp2 = {0, 0, 0}, gp3 = {0, 0, 0};
     float gw = 0.f;
-    // passes 1,2: grid-stride over splats (few blocks => few same-address f64 atomics); pass 3: whole curves per block
+    // pass 1: grid-stride over splats; pass 3: whole curves per block
     int b, i;
     bool valid;
     int sp = blockIdx.x * blockDim.x + threadIdx.x;
@@ -320,6 +323,7 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_sample_bwd(int B, int m, int c
         }
         if (PASS == 1) {
             acc += (double)dot(g_v2, s.c2v);
+            acc_a += (double)dot(g_v1, s.c1v) + (double)((1.f / N2) * dot(cross(g_v2, s.tan), s.c1v));
             sp += gridDim.x * blockDim.x;
             valid = sp < B * m;
             b = valid ? sp / m : 0;
@@ -374,8 +378,10 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_sample_bwd(int B, int m, int c
         }
         break;
     }
-    if (PASS == 1) block_accumulate(acc, norms, 2);
-    if (PASS == 2) block_accumulate(acc, norms, 3);
+    if (PASS == 1) {
+        block_accumulate(acc, norms, 3);
+        block_accumulate(acc_a, norms, 4);
+    }
     if (PASS == 3) {
         const int t = threadIdx.x;
         s_part[0][t] = gp0.x; s_part[1][t] = gp0.y; s_part[2][t] = gp0.z;
@@ -525,8 +531,7 @@ void launch_sample_forward(hipStream_t s, int B, int m, const float* cp, const f
     const dim3 grid((B * m + 255) / 256), block(256);
     const dim3 rgrid(std::max((B * m + 255) / 256, 1));
     const SampleCoef* k = reinterpret_cast<const SampleCoef*>(coef);
-    { ProfScope p("sample_f1", s); hipLaunchKernelGGL(k_sample_f1, rgrid, block, 0, s, B, m, cp, is_bezier, k, norms); }
-    { ProfScope p("sample_f2", s); hipLaunchKernelGGL(k_sample_f2, rgrid, block, 0, s, B, m, cp, is_bezier, k, norms); }
+    { ProfScope p("sample_f12", s); hipLaunchKernelGGL(k_sample_f12, rgrid, block, 0, s, B, m, cp, is_bezier, k, norms); }
     { ProfScope p("sample_f3", s); hipLaunchKernelGGL(k_sample_f3, grid, block, 0, s, B, m, cp, width, is_bezier, k, eps, norms, xyz, rot, scaling); }
 }
 void launch_sample_backward(hipStream_t s, int B, int m, const float* cp, const float* width, const uint8_t* is_bezier,
@@ -537,7 +542,6 @@ void launch_sample_backward(hipStream_t s, int B, int m, const float* cp, const 
     const SampleCoef* k = reinterpret_cast<const SampleCoef*>(coef);
     const dim3 rgrid(std::max((B * m + SAMPLE_BLOCK - 1) / SAMPLE_BLOCK, 1));
     { ProfScope p("sample_b1", s); hipLaunchKernelGGL(k_sample_bwd<1>, rgrid, block, 0, s, B, m, cpb, cp, width, is_bezier, k, eps, norms, g_xyz, g_rot, g_scaling, g_cp, g_width, gv_cache); }
-    { ProfScope p("sample_b2", s); hipLaunchKernelGGL(k_sample_bwd<2>, rgrid, block, 0, s, B, m, cpb, cp, width, is_bezier, k, eps, norms, g_xyz, g_rot, g_scaling, g_cp, g_width, gv_cache); }
     { ProfScope p("sample_b3", s); hipLaunchKernelGGL(k_sample_bwd<3>, grid, block, 0, s, B, m, cpb, cp, width, is_bezier, k, eps, norms, g_xyz, g_rot, g_scaling, g_cp, g_width, gv_cache); }
 }
 void launch_attrs_forward(hipStream_t s, int B, int m, const float* rot_raw, const float* xyz, const float* opacity_logit,
@@ -560,5 +564,6 @@ void launch_attrs_backward(hipStream_t s, int B, int m, const float* rot_raw, co
 }
 
 int sample_norm_words() { return NORM_WORDS; }
+int sample_norm_fwd_words() { return NQ_FWD * NORM_SLOTS; }
 
 }  // namespace cgs
