@@ -362,6 +362,25 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                            "kernel_ms": round(kernel_ms[dom], 5), "algorithmic_bytes_per_launch": int(alg_dom)}
+        # what actually binds the dominant kernel: vector-instruction issue.  Instruction count per
+        # launch from the committed PMC pass (profiles/r01_pmc.csv, same workload), rate from the live kernel time; peak =
+        # 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (v_fma_f32 measured at 2 cycles, most others more).
+        try:
+            insts = {}
+            for line in open(os.path.join(ROOT, "profiles", "r01_pmc.csv")):
+                f = line.strip().split(",")
+                if len(f) == 3 and f[0] == dom and f[1] in ("SQ_INSTS_VALU", "SQ_INSTS_SALU"):
+                    insts[f[1]] = float(f[2])
+            if "SQ_INSTS_VALU" in insts:
+                rate = insts["SQ_INSTS_VALU"] / (kernel_ms[dom] * 1e-3) / 1e9
+                peak = 1024 * 2.4 / 2.0
+                out["issue_roofline"] = {"bound": "valu-issue", "kernel": dom,
+                                         "valu_wave_instr_per_launch": int(insts["SQ_INSTS_VALU"]),
+                                         "salu_instr_per_launch": int(insts.get("SQ_INSTS_SALU", 0)),
+                                         "achieved": round(rate, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
+                                         "frac": round(rate / peak, 4)}
+        except Exception:
+            pass
         out["kernel_ms_per_view"] = {k: round(v, 5) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])}
         out["whole_path"] = {"algorithmic_bytes_per_view": int(alg_view),
                              "achieved_GBps": round(alg_view / (ms_per_step * 1e-3) / 1e9, 2),
