@@ -21,7 +21,7 @@ namespace cgs {
 // Grid-wide sums: every workgroup adds its partial to one of NORM_SLOTS f64 slots per quantity (same-address f64
 // atomics serialise at ~20 ns each: 782 blocks on one address cost more than the kernels themselves, 49 per slot do
 // not), and every consumer sums the slots while staging its constants.
-constexpr int NORM_SLOTS = 16;
+constexpr int NORM_SLOTS = 64;
 // norms[q * NORM_SLOTS + slot].  Forward (k_sample_f12, ONE pass): q0 = S1 = sum |c1v|^2, q1 = S2 = sum |cross(tan,c1v)|^2,
 // q2 = BS = sum dot(cross(cross(tan,c1v), tan), c1v), from which N1 = sqrt(S1), N2 = sqrt(S2) / N1 (c2v = cross(tan,
 // c1v / N1)).  Backward (k_sample_bwd<1>, ONE pass): q3 = D2 = sum dot(g_v2, c2v), q4 = A = sum dot(g_v1 +
@@ -72,11 +72,12 @@ __device__ __forceinline__ void stage_consts(const SampleCoef* __restrict__ coef
     float* dst = reinterpret_cast<float*>(s_coef);
     for (int t = threadIdx.x; t < m * 16; t += blockDim.x) dst[t] = src[t];
     __shared__ double s_q[NQ_ALL];
-    if (threadIdx.x < NQ_ALL * NORM_SLOTS) {  // 16-lane groups: lane = q * NORM_SLOTS + slot
-        double v = norms[threadIdx.x];
+    for (int base = 0; base < NQ_ALL * NORM_SLOTS; base += blockDim.x) {  // NORM_SLOTS-lane groups: q * NORM_SLOTS + slot
+        const int idx = base + threadIdx.x;
+        double v = idx < NQ_ALL * NORM_SLOTS ? norms[idx] : 0.0;
 #pragma unroll
         for (int off = NORM_SLOTS / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-        if ((threadIdx.x % NORM_SLOTS) == 0) s_q[threadIdx.x / NORM_SLOTS] = v;
+        if (idx < NQ_ALL * NORM_SLOTS && (idx % NORM_SLOTS) == 0) s_q[idx / NORM_SLOTS] = v;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -90,21 +91,24 @@ __device__ __forceinline__ void stage_consts(const SampleCoef* __restrict__ coef
 }
 constexpr int MAX_M = 32;  // samples per curve supported by the LDS table (reference default 12)
 
-// block-wide sum -> one f64 atomic on this block's slot of quantity q
-__device__ __forceinline__ void block_accumulate(double v, double* norms, int q) {
-    double* target = norms + q * NORM_SLOTS + (blockIdx.x % NORM_SLOTS);
-    __shared__ double s_part[4];
+// block-wide sums of N quantities -> one f64 atomic each on this block's slot of quantities q0, q0+1, ...
+template <int N>
+__device__ __forceinline__ void block_accumulate(const double (&v)[N], double* norms, int q0) {
+    __shared__ double s_part[N][4];
+    double w[N];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    for (int k = 0; k < N; k++) w[k] = (double)wave_sum((float)v[k]);  // 64 addends in f32 (DPP), the rest in f64
     const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) s_part[wave] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += s_part[w];
-        atomicAdd(target, t);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < N; k++) s_part[k][wave] = w[k];
     }
-    __syncthreads();  // s_part is reused by the next quantity
+    __syncthreads();
+    if (threadIdx.x < N) {
+        double t = 0;
+        for (int wv = 0; wv < (int)(blockDim.x >> 6); wv++) t += s_part[threadIdx.x][wv];
+        atomicAdd(norms + (q0 + threadIdx.x) * NORM_SLOTS + (blockIdx.x % NORM_SLOTS), t);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -116,20 +120,19 @@ __global__ void __launch_bounds__(256) k_sample_f12(int B, int m, const float* _
     float* dst = reinterpret_cast<float*>(s_coef);
     for (int t = threadIdx.x; t < m * 16; t += blockDim.x) dst[t] = src[t];
     __syncthreads();
-    double a1 = 0, a2 = 0, a3 = 0;
+    float a1 = 0, a2 = 0, a3 = 0;   // the grid covers every splat once: at most one addend per thread
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < B * m; p += gridDim.x * blockDim.x) {
         const int b = p / m, i = p - b * m;
         const CurveCP c = load_curve(cp, is_bezier, b);
         const V3 t = curve_tangent(c, s_coef[i]);
         const V3 c1 = {t.y, -t.x, 0.f};                 // cross(tan, (0,0,1))
         const V3 x = cross(t, c1);                      // N1 * c2v
-        a1 += (double)(t.y * t.y) + (double)(t.x * t.x);
-        a2 += (double)(x.x * x.x) + (double)(x.y * x.y) + (double)(x.z * x.z);
-        a3 += (double)dot(cross(x, t), c1);
+        a1 += t.y * t.y + t.x * t.x;
+        a2 += x.x * x.x + x.y * x.y + x.z * x.z;
+        a3 += dot(cross(x, t), c1);
     }
-    block_accumulate(a1, norms, 0);
-    block_accumulate(a2, norms, 1);
-    block_accumulate(a3, norms, 2);
+    const double acc3[3] = {(double)a1, (double)a2, (double)a3};
+    block_accumulate<3>(acc3, norms, 0);
 }
 
 struct QuatFwd { float a[4], qa[4], N[4], D; int k; bool flip; };
@@ -379,8 +382,8 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_sample_bwd(int B, int m, int c
         break;
     }
     if (PASS == 1) {
-        block_accumulate(acc, norms, 3);
-        block_accumulate(acc_a, norms, 4);
+        const double acc2[2] = {acc, acc_a};
+        block_accumulate<2>(acc2, norms, 3);
     }
     if (PASS == 3) {
         const int t = threadIdx.x;

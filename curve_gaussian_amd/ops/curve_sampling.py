@@ -70,7 +70,7 @@ class _SampleCurves(torch.autograd.Function):
             P = B * m
             isb = _bezier_mask(is_bezier, dev)
             coef = sample_coefficients(m, dev)
-            norms = torch.empty(128, dtype=torch.float64, device=dev)
+            norms = torch.empty(384, dtype=torch.float64, device=dev)
             xyz = torch.empty((P, 3), dtype=torch.float32, device=dev)
             rot = torch.empty((P, 4), dtype=torch.float32, device=dev)
             scl = torch.empty((P, 3), dtype=torch.float32, device=dev)
@@ -93,7 +93,7 @@ class _SampleCurves(torch.autograd.Function):
             g_xyz, g_rot, g_scl = c(g_xyz), c(g_rot), c(g_scl)
             g_cp = torch.empty_like(cp)
             g_w = torch.empty_like(w)
-            # norms[48:80] are backward scratch (re-zeroed by every call); norms[:48] (forward partial sums) are only read
+            # norms[192:320] are backward scratch (re-zeroed by every call); norms[:192] (forward partial sums) are only read
             scratch = torch.empty((B * ctx.m, 9), dtype=torch.float32, device=dev) if g_rot is not None else None
             rc = lib.cgs_sample_curves_backward(B, ctx.m, L.ptr(cp), L.ptr(w), L.ptr(isb), L.ptr(coef), _f(ctx.eps),
                                                 L.ptr(norms), L.ptr(g_xyz), L.ptr(g_rot), L.ptr(g_scl), L.ptr(g_cp),

@@ -131,9 +131,9 @@ size_t cgs_binning_bytes(int64_t R);
  *   curve_points [B,4,3], width [B,1] (log), is_bezier [B] u8 or NULL (= all Bezier).  P = B*m, splat = b*m + i.
  *   coef [m,16] f32: per-sample weights computed by the host with the reference's float32 expressions
  *     {c0..c3 at t_i, c0..c3 at t_i-0.5/m, 3(1-t)^2, 6(1-t)t, 3t^2, (1-t), t, (1-t'), t', pad}.
- *   norms [128] f64 scratch: [0..47] = 16 partial sums each of three global sums written by the forward and needed
+ *   norms [384] f64 scratch: [0..191] = 64 partial sums each of three global sums written by the forward and needed
  *     by the backward (the two Frobenius norms of the reference's global normalisations and one cross term);
- *     [48..79] are backward scratch; the rest is reserved.
+ *     [192..319] are backward scratch; the rest is reserved.
  *   outputs xyz [P,3], rotation [P,4] (w,x,y,z, un-normalised), scaling [P,3].
  * The backward accepts NULL for any upstream gradient (treated as zero).  m <= 32.
  * ------------------------------------------------------------------------------------------------ */
