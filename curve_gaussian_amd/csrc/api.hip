@@ -94,6 +94,10 @@ static hipError_t zero_async(void* p, size_t bytes, hipStream_t s) {
     return hipGetLastError();
 }
 
+static inline bool fuse_sort() {   // CGS_FUSE_SORT=0 keeps the separate per-tile sort kernel (A/B measurements)
+    static const bool on = !(getenv("CGS_FUSE_SORT") && getenv("CGS_FUSE_SORT")[0] == '0');
+    return on;
+}
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace cgs
@@ -275,9 +279,17 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
             }
             BinState bin = bin_from_chunk(bchunk, (size_t)(cap * tiles));
             launch_scatter_bucket(s, P, radii, geom.rec, gx, gy, img.tile_count, bin.keys, (uint32_t)cap, cull);
-            launch_tile_sort_bucket(s, tiles, img.tile_count, img.ranges, img.total, bin.keys, bin.point_list, (uint32_t)cap);
-            if (!read_totals()) return CGS_ERR_HIP;
-            if (!render(bin.point_list)) return CGS_ERR_HIP;
+            if (render_fwd_can_sort((uint32_t)cap) && fuse_sort()) {   // depth sort fused into the compositor
+                launch_render_fwd_sorting(s, render_geo != 0, tiles, img.tile_count, bin.keys, (uint32_t)cap, img.ranges,
+                                          img.total, bin.point_list, width, height, gx, geom.rec, img.final_T,
+                                          img.n_contrib, background, out_color, out_invdepth, out_all_map);
+                if (!check_launch("render_fwd", debug, s)) return CGS_ERR_HIP;
+                if (!read_totals()) return CGS_ERR_HIP;
+            } else {
+                launch_tile_sort_bucket(s, tiles, img.tile_count, img.ranges, img.total, bin.keys, bin.point_list, (uint32_t)cap);
+                if (!read_totals()) return CGS_ERR_HIP;
+                if (!render(bin.point_list)) return CGS_ERR_HIP;
+            }
 #ifdef CGS_EXPERIMENT_NOWAIT
             if (getenv("CGS_NOWAIT")) return g_R_hint.load(std::memory_order_relaxed);
 #endif
@@ -413,9 +425,15 @@ int cgs_rasterize_forward_static(void* geometry_buffer, void* binning_buffer, si
                           width, height, tan_fovx, tan_fovy, focal_x, focal_y, radii, geom.rec, geom.rgb, gx, gy, nullptr,
                           antialiasing, 1);
     launch_scatter_bucket(s, P, radii, geom.rec, gx, gy, img.tile_count, bin.keys, (uint32_t)cap, 1);
-    launch_tile_sort_bucket(s, tiles, img.tile_count, img.ranges, img.total, bin.keys, bin.point_list, (uint32_t)cap);
-    launch_render_fwd(s, render_geo != 0, tiles, img.ranges, bin.point_list, width, height, gx, geom.rec, img.final_T,
-                      img.n_contrib, background, out_color, out_invdepth, out_all_map);
+    if (render_fwd_can_sort((uint32_t)cap) && fuse_sort()) {
+        launch_render_fwd_sorting(s, render_geo != 0, tiles, img.tile_count, bin.keys, (uint32_t)cap, img.ranges, img.total,
+                                  bin.point_list, width, height, gx, geom.rec, img.final_T, img.n_contrib, background,
+                                  out_color, out_invdepth, out_all_map);
+    } else {
+        launch_tile_sort_bucket(s, tiles, img.tile_count, img.ranges, img.total, bin.keys, bin.point_list, (uint32_t)cap);
+        launch_render_fwd(s, render_geo != 0, tiles, img.ranges, bin.point_list, width, height, gx, geom.rec, img.final_T,
+                          img.n_contrib, background, out_color, out_invdepth, out_all_map);
+    }
     if (!check_launch("rasterize_forward_static", false, s)) return CGS_ERR_HIP;
     return CGS_OK;
 }

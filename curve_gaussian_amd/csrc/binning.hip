@@ -147,7 +147,6 @@ __device__ __forceinline__ void bitonic_any_n(Ptr k, uint32_t n, uint32_t n2, ui
 // network spends its time in 36+ barrier-separated LDS round trips at 5 workgroups per CU).
 // Measured on cfg3 (mean list 225): 81 us vs 90 us for the LDS bitonic network; unrolling the broadcast loop or
 // splitting the compare into 32-bit depth/idx parts was slower (103 / 117 us).
-constexpr uint32_t RANK_MAX = 1024;
 // Bucket layout: derive this tile's range from its instance count, publish it for the compositor and fold the
 // count into the partial sums / maxima of `total` (num_rendered, longest list; longest > cap <=> overflow).
 __device__ __forceinline__ uint2 bucket_range(const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges_out,
@@ -165,43 +164,6 @@ __device__ __forceinline__ uint2 bucket_range(const uint32_t* __restrict__ tile_
         }
     }
     return make_uint2(base, base + n);
-}
-
-// rank[q] += #{ k in s[0..n) : k < mine[q] }, RANK_U broadcast keys per iteration, the next RANK_U already in flight.
-// s is padded with the maximum value up to a multiple of RANK_U.
-#ifndef CGS_RANK_U
-#define CGS_RANK_U 4
-#endif
-constexpr uint32_t RANK_U = CGS_RANK_U;
-template <int NQ, typename K>
-__device__ __forceinline__ void rank_loop(const K* s, uint32_t n, const K (&mine)[4], uint32_t (&rank)[4]) {
-    const uint32_t nu = (n + RANK_U - 1) / RANK_U * RANK_U;
-    K k[RANK_U], p[RANK_U];
-#pragma unroll
-    for (uint32_t e = 0; e < RANK_U; e++) k[e] = s[e];
-    for (uint32_t u = RANK_U; u < nu; u += RANK_U) {
-#pragma unroll
-        for (uint32_t e = 0; e < RANK_U; e++) p[e] = s[u + e];  // uniform address: LDS broadcast
-#pragma unroll
-        for (int q = 0; q < NQ; q++)
-#pragma unroll
-            for (uint32_t e = 0; e < RANK_U; e++) rank[q] += (uint32_t)(k[e] < mine[q]);
-#pragma unroll
-        for (uint32_t e = 0; e < RANK_U; e++) k[e] = p[e];
-    }
-#pragma unroll
-    for (int q = 0; q < NQ; q++)
-#pragma unroll
-        for (uint32_t e = 0; e < RANK_U; e++) rank[q] += (uint32_t)(k[e] < mine[q]);
-}
-template <typename K>
-__device__ __forceinline__ void rank_dispatch(int nq, const K* s, uint32_t n, const K (&mine)[4], uint32_t (&rank)[4]) {
-    switch (nq) {  // the compare loop is specialised: no per-key branches inside it
-        case 1: rank_loop<1>(s, n, mine, rank); break;
-        case 2: rank_loop<2>(s, n, mine, rank); break;
-        case 3: rank_loop<3>(s, n, mine, rank); break;
-        default: rank_loop<4>(s, n, mine, rank); break;
-    }
 }
 
 // ---------------------------------------------------------------------------------------- quad-walk bucket scatter

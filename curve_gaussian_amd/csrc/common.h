@@ -224,6 +224,45 @@ __device__ __forceinline__ bool tile_reach_det(float cx, float cy, float A, floa
     const float lim = __builtin_fmaf(tau2, 1.001f, 1e-3f);
     return m <= __builtin_fmaf(8e-6f, mag, lim);
 }
+// ---------------------------------------------------------------- per-tile rank sort helpers (binning.hip, render.hip)
+constexpr uint32_t RANK_MAX = 1024;  // longest list the rank sort handles (bitonic network beyond)
+// rank[q] += #{ k in s[0..n) : k < mine[q] }, RANK_U broadcast keys per iteration, the next RANK_U already in flight.
+// s is padded with the maximum value up to a multiple of RANK_U.
+#ifndef CGS_RANK_U
+#define CGS_RANK_U 4
+#endif
+constexpr uint32_t RANK_U = CGS_RANK_U;
+template <int NQ, typename K>
+__device__ __forceinline__ void rank_loop(const K* s, uint32_t n, const K (&mine)[4], uint32_t (&rank)[4]) {
+    const uint32_t nu = (n + RANK_U - 1) / RANK_U * RANK_U;
+    K k[RANK_U], p[RANK_U];
+#pragma unroll
+    for (uint32_t e = 0; e < RANK_U; e++) k[e] = s[e];
+    for (uint32_t u = RANK_U; u < nu; u += RANK_U) {
+#pragma unroll
+        for (uint32_t e = 0; e < RANK_U; e++) p[e] = s[u + e];  // uniform address: LDS broadcast
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+#pragma unroll
+            for (uint32_t e = 0; e < RANK_U; e++) rank[q] += (uint32_t)(k[e] < mine[q]);
+#pragma unroll
+        for (uint32_t e = 0; e < RANK_U; e++) k[e] = p[e];
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+#pragma unroll
+        for (uint32_t e = 0; e < RANK_U; e++) rank[q] += (uint32_t)(k[e] < mine[q]);
+}
+template <typename K>
+__device__ __forceinline__ void rank_dispatch(int nq, const K* s, uint32_t n, const K (&mine)[4], uint32_t (&rank)[4]) {
+    switch (nq) {  // the compare loop is specialised: no per-key branches inside it
+        case 1: rank_loop<1>(s, n, mine, rank); break;
+        case 2: rank_loop<2>(s, n, mine, rank); break;
+        case 3: rank_loop<3>(s, n, mine, rank); break;
+        default: rank_loop<4>(s, n, mine, rank); break;
+    }
+}
+
 __device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 #endif  // __HIPCC__
 
