@@ -256,9 +256,12 @@ def main():
         torch.cuda.synchronize()
 
     use_graphs = [view_graphs is not None]
-    if world > 1:
+    if world > 1 or os.environ.get("CGS_BENCH_FORCE_DIST"):   # (the env switch exercises RCCL with a single rank)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     def timed():
@@ -274,7 +277,7 @@ def main():
         print("bench: bucket overflow in graph mode, re-timing with eager launches", file=sys.stderr)
         use_graphs[0] = False
         elapsed = timed()
-    if world > 1:
+    if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -324,7 +327,7 @@ def main():
         R_mean = vis_mean = 0.0
 
     if rank != 0:
-        if world > 1:
+        if dist is not None:
             dist.destroy_process_group()
         return
 
@@ -480,9 +483,14 @@ def main():
                                "gpu_vs_cpu_frac_over_1e-4_of_max": {k: (v if isinstance(v, bool) else float(f"{v:.2e}")) for k, v in err.items()},
                                "sample": f"{nv} views of the same workload (raster fwd+bwd), oracle/raster_ref.c with "
                                          f"OpenMP ({threads} threads of {cores} host cores), {tc:.1f} s"}
-    print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
+    try:   # RCCL writes its banner through C stdio: flush that buffer so the JSON line is the LAST line on stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
