@@ -18,12 +18,17 @@ from .view_parallel import FlatGrads, StaticCamera as _StaticCamera
 
 class TrainStep:
     def __init__(self, gaussians, cameras, gt_images, lambda_mse=10.0, lambda_dssim=0.1, lambda_mask=0.0005,
-                 densify_until_iter=7000, mask_threshold=0.01, seed=0, rank=0, world=1, fused=True):
+                 densify_until_iter=7000, mask_threshold=0.01, seed=0, rank=0, world=1, fused=True,
+                 regularisers=False, opacity_loss_weight=0.01, lambda_curve_smo=0.1, lambda_width=0.01):
         self.g = gaussians
         self.cams = cameras
         self.gts = gt_images                      # list of [1,H,W] edge maps on the device
         self.lambda_mse, self.lambda_dssim, self.lambda_mask = lambda_mse, lambda_dssim, lambda_mask
         self.densify_until_iter, self.mask_threshold = densify_until_iter, mask_threshold
+        # train.py:113-131 (off by default: the BASELINE train-step metric excludes them)
+        self.regularisers = regularisers
+        self.opacity_loss_weight, self.lambda_curve_smo, self.lambda_width = opacity_loss_weight, lambda_curve_smo, lambda_width
+        self.reset_timestep = 0    # train.py:113: the opacity term is active after an opacity reset
         self.pipe = PipelineParams()
         self.bg = torch.zeros(3, device=gaussians.device)
         self.rng = random.Random(seed + rank)     # rank-dependent view choice
@@ -53,6 +58,17 @@ class TrainStep:
         else:
             self.flat = FlatGrads(named)
 
+    def _regulariser_terms(self, radii, opacity_gate):
+        """train.py:113-131; opacity_gate (float or device scalar) switches the opacity term (reset_timestep > 0)."""
+        from .ops import regularizers as RG
+        g = self.g
+        reg = RG.opacity_loss(g, radii, self.opacity_loss_weight) * opacity_gate
+        if self.lambda_curve_smo > 0:
+            reg = reg + RG.curve_smoothness_loss(g, radii, self.lambda_curve_smo)
+        if self.lambda_width > 0:
+            reg = reg + RG.width_loss(g, self.lambda_width)
+        return reg
+
     def _next_view(self):
         if not self.stack:
             self.stack = list(range(len(self.cams)))
@@ -77,6 +93,8 @@ class TrainStep:
             loss = self.lambda_mse * ((1.0 - self.lambda_dssim) * Ll1 + self.lambda_dssim * (1.0 - ssim_value))
         if use_mask:
             loss = loss + self.lambda_mask * torch.mean(torch.sigmoid(g._mask))
+        if self.regularisers:
+            loss = loss + self._regulariser_terms(pkg["radii"], 1.0 if self.reset_timestep > 0 else 0.0)
         loss.backward()
         self.flat.all_reduce()
         if self.fused:
@@ -119,6 +137,8 @@ class GraphedTrainStep(TrainStep):
         from .ops.losses import edge_pixel_count
         self._npos_all = [edge_pixel_count(g[:1]) for g in self.gts]
         self._npos = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._opa_gate = torch.zeros((), dtype=torch.float32, device=dev)
+        self._gates = (torch.zeros((), device=dev), torch.ones((), device=dev))
         self._graph = None
         self._cap = 0
         self._loss = None
@@ -138,6 +158,8 @@ class GraphedTrainStep(TrainStep):
         pkg = render(self._cam, g, self.pipe, self.bg, compute_visibility=False, clamp=False, compute_rend_dir=False,
                      static_bucket_cap=self._cap, status_sink=sink)
         loss = photometric_loss(pkg["render"], self._gt, self.lambda_mse, self.lambda_dssim, clamp=True, n_pos=self._npos)
+        if self.regularisers:   # sync-free torch ops; the opacity term is gated by a device scalar refreshed per step
+            loss = loss + self._regulariser_terms(pkg["radii"], self._opa_gate)
         if getattr(self, "_debug_keep", None) is not None:
             import os
             allk = dict(xyz=g._xyz, rot=g._rotation, scl=g._scaling, radii=pkg["radii"], img=pkg["render"], depth=pkg["depth"])
@@ -170,6 +192,7 @@ class GraphedTrainStep(TrainStep):
         self._cam.pack.copy_(self._cam_packs[vi], non_blocking=True)
         self._gt.copy_(self.gts[vi][:1], non_blocking=True)
         self._npos.copy_(self._npos_all[vi], non_blocking=True)
+        self._opa_gate.copy_(self._gates[1 if self.reset_timestep > 0 else 0], non_blocking=True)
 
     def _capture(self, vi):
         if self._cap == 0:

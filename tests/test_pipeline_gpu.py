@@ -268,3 +268,65 @@ def test_cfg1_plumbing_scan_on_disk_to_parametric_edges(tmp_path):
     assert np.array(saved["curves_ctl_pts"]).shape == (417, 4, 3) and saved["lines_end_pts"] == []
     assert len(pts) > 417 and os.path.getsize(tmp_path / "out" / "edge_points.ply") > 0
     np.testing.assert_allclose(np.array(saved["curves_ctl_pts"]), gm._curve_points.detach().cpu().numpy(), rtol=1e-6)
+
+
+def test_regularisers_match_the_reference_formulas():
+    """ops/regularizers.py (sync-free masked means) against train.py:113-131 written out literally with its host-side
+    conditions, values and gradients; then the eager and the graphed train step with regularisers on agree."""
+    import torch.nn.functional as F
+    from curve_gaussian_amd.ops import regularizers as RG
+    from curve_gaussian_amd.train_step import GraphedTrainStep, TrainStep
+    gm, cams, gts = _train_fixture()
+    with torch.no_grad():
+        gm._width[::3] += 0.4          # some curves above the 0.005 width threshold, some below
+    gm.prepare_scaling_rot()
+    radii = torch.zeros(gm._xyz.shape[0], dtype=torch.int32, device=DEV)
+    radii[::2] = 3
+    names = ("_curve_points", "_width", "_opacity")
+
+    def grads(loss):
+        for n in names:
+            getattr(gm, n).grad = None
+        loss.backward()
+        out = [getattr(gm, n).grad for n in names]
+        gm.prepare_scaling_rot()
+        return [None if g is None else g.detach().clone() for g in out]
+
+    # literal reference
+    vis = (radii > 0).nonzero()
+    ref = 0
+    if vis.sum() > 0:
+        opacity = gm.get_opacity[vis]
+        ref = ref + 0.01 * torch.log(1 + opacity ** 2 / 0.5).mean()
+    if vis.sum() > 0:
+        d = gm.get_rotation_matrix[..., 0].reshape(-1, 12, 3)
+        ref = ref + 0.1 * (1 - F.cosine_similarity(d[:, :-1, :], d[:, 1:, :], dim=-1).abs()).mean()
+    mask = gm.get_curve_width >= 0.005
+    assert bool(mask.any()) and not bool(mask.all())
+    ref = ref + 0.01 * (gm.get_curve_width[mask] - 0.005).mean()
+    g_ref = grads(ref)
+    mine = RG.opacity_loss(gm, radii, 0.01) + RG.curve_smoothness_loss(gm, radii, 0.1) + RG.width_loss(gm, 0.01)
+    np.testing.assert_allclose(float(mine), float(ref), rtol=1e-6)
+    for a, b in zip(grads(mine), g_ref):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-9)
+    # nothing visible / nothing above the threshold: the conditional terms vanish instead of dividing by zero
+    none = torch.zeros_like(radii)
+    assert float(RG.opacity_loss(gm, none)) == 0.0 and float(RG.curve_smoothness_loss(gm, none)) == 0.0
+    with torch.no_grad():
+        gm._width.fill_(-9.0)
+    assert float(RG.width_loss(gm)) == 0.0
+    # eager vs graphed step with the regularisers switched on
+    torch.manual_seed(0); ga, cams, gts = _train_fixture()
+    torch.manual_seed(0); gb, _, _ = _train_fixture()
+    ea = TrainStep(ga, cams, gts, seed=4, regularisers=True)
+    gs = GraphedTrainStep(gb, cams, gts, seed=4, regularisers=True)
+    for it in range(8):
+        if it == 4:
+            ea.reset_timestep = gs.reset_timestep = 1     # opacity term switches on without a re-capture
+        la = ea.step()[0]
+        lb = gs.step()[0]
+    gs.finish()
+    assert gs.recaptures == 1
+    np.testing.assert_allclose(float(lb), float(la), rtol=1e-4)
+    for n in names:
+        np.testing.assert_allclose(getattr(gb, n).detach().cpu().numpy(), getattr(ga, n).detach().cpu().numpy(), rtol=1e-3, atol=1e-5)   # 8 Adam steps amplify rounding
