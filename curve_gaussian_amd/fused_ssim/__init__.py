@@ -46,33 +46,39 @@ def fusedssim_backward(C1, C2, img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_d
     return out
 
 
+SSIM_C1, SSIM_C2 = 0.01 ** 2, 0.03 ** 2   # stabilisers of the SSIM ratio for images in [0, 1]
+_BORDER = 5                                # half width of the 11-tap window: what "valid" padding crops away
+
+
+def _crop(t, padding):
+    return t if padding == "same" else t[..., _BORDER:-_BORDER, _BORDER:-_BORDER]
+
+
 class FusedSSIMMap(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, C1, C2, img1, img2, padding="same", train=True):
-        ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12 = fusedssim(C1, C2, img1, img2, train)
-        if padding == "valid":
-            ssim_map = ssim_map[:, :, 5:-5, 5:-5]
-        ctx.save_for_backward(img1.detach(), img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12)
-        ctx.C1 = C1
-        ctx.C2 = C2
-        ctx.padding = padding
-        return ssim_map
+    """SSIM map of (img1, img2) with gradient w.r.t. img1 only; same call signature, saved state and ``None`` pattern
+    of the returned gradients as the reference's class of this name (fused_ssim/__init__.py:8-31)."""
 
     @staticmethod
-    def backward(ctx, opt_grad):
-        img1, img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12 = ctx.saved_tensors
-        C1, C2, padding = ctx.C1, ctx.C2, ctx.padding
-        dL_dmap = opt_grad
-        if padding == "valid":
-            dL_dmap = torch.zeros_like(img1)
-            dL_dmap[:, :, 5:-5, 5:-5] = opt_grad
-        grad = fusedssim_backward(C1, C2, img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12)
-        return None, None, grad, None, None, None
+    def forward(ctx, C1, C2, img1, img2, padding="same", train=True):
+        full_map, *partials = fusedssim(C1, C2, img1, img2, train)
+        ctx.save_for_backward(img1.detach(), img2, *partials)
+        ctx.consts = (C1, C2, padding)
+        return _crop(full_map, padding)
+
+    @staticmethod
+    def backward(ctx, grad_map):
+        img1, img2, d_mu1, d_var1, d_cov = ctx.saved_tensors
+        C1, C2, padding = ctx.consts
+        if padding != "same":   # the kernels work on the uncropped map: embed the cropped gradient in zeros
+            full = torch.zeros_like(img1)
+            _crop(full, padding).copy_(grad_map)
+            grad_map = full
+        g_img1 = fusedssim_backward(C1, C2, img1, img2, grad_map, d_mu1, d_var1, d_cov)
+        return (None, None, g_img1, None, None, None)
 
 
 def fused_ssim(img1, img2, padding="same", train=True):
-    C1 = 0.01 ** 2
-    C2 = 0.03 ** 2
-    assert padding in allowed_padding
-    map = FusedSSIMMap.apply(C1, C2, img1, img2, padding, train)
-    return map.mean()
+    """Mean SSIM of two [B, C, H, W] image batches (drop-in for ``fused_ssim.fused_ssim``)."""
+    if padding not in allowed_padding:
+        raise AssertionError(f"padding must be one of {allowed_padding}")
+    return FusedSSIMMap.apply(SSIM_C1, SSIM_C2, img1, img2, padding, train).mean()

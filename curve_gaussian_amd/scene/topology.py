@@ -109,27 +109,29 @@ def replace_tensor_to_optimizer(g, tensor, name):
 
 
 # ------------------------------------------------------------------------------------------------ geometry
+def _lerp(a, b, t):
+    return a + t * (b - a)
+
+
 def de_casteljau_split(g, curves, t, is_bezier):
-    """:392-425 -- split every curve at its own parameter t ([n] or [n,1]); straight segments are split linearly."""
+    """:392-425 -- split every curve at its own parameter t ([n] or [n,1]) into (left, right) control polygons.
+    Bezier curves: the three levels of de Casteljau interpolation; straight segments (is_bezier False) are cut on
+    their chord P0-P3 and get evenly spaced inner control points, as the reference does."""
     t = t.reshape(-1, 1)
-    Q0 = (1 - t) * curves[:, 0, :] + t * curves[:, 1, :]
-    Q1 = (1 - t) * curves[:, 1, :] + t * curves[:, 2, :]
-    Q2 = (1 - t) * curves[:, 2, :] + t * curves[:, 3, :]
-    R0 = (1 - t) * Q0 + t * Q1
-    R1 = (1 - t) * Q1 + t * Q2
-    S = (1 - t) * R0 + t * R1
-    left_bezier = torch.stack([curves[:, 0], Q0, R0, S], dim=1)
-    right_bezier = torch.stack([S, R1, Q2, curves[:, -1]], dim=1)
+    p0, p1, p2, p3 = curves.unbind(dim=1)
+    a0, a1, a2 = _lerp(p0, p1, t), _lerp(p1, p2, t), _lerp(p2, p3, t)     # level 1
+    b0, b1 = _lerp(a0, a1, t), _lerp(a1, a2, t)                           # level 2
+    split = _lerp(b0, b1, t)                                              # the point B(t)
+    left = torch.stack([p0, a0, b0, split], dim=1)
+    right = torch.stack([split, b1, a2, p3], dim=1)
     if bool(g.is_bezier.all()):
-        return left_bezier, right_bezier
-    S = (1 - t) * curves[:, 0] + t * curves[:, -1]
-    left_straight = torch.stack([curves[:, 0], (2 / 3) * curves[:, 0] + (1 / 3) * S,
-                                 (1 / 3) * curves[:, 0] + (2 / 3) * S, S], dim=1)
-    right_straight = torch.stack([S, (2 / 3) * S + (1 / 3) * curves[:, -1], (1 / 3) * S + (2 / 3) * curves[:, -1],
-                                  curves[:, -1]], dim=1)
-    left = torch.where(is_bezier[:, None, None], left_bezier, left_straight)
-    right = torch.where(is_bezier[:, None, None], right_bezier, right_straight)
-    return left, right
+        return left, right
+    cut = _lerp(p0, p3, t)
+    third = 1.0 / 3.0
+    left_line = torch.stack([p0, _lerp(p0, cut, third), _lerp(p0, cut, 2 * third), cut], dim=1)
+    right_line = torch.stack([cut, _lerp(cut, p3, third), _lerp(cut, p3, 2 * third), p3], dim=1)
+    sel = is_bezier[:, None, None]
+    return torch.where(sel, left, left_line), torch.where(sel, right, right_line)
 
 
 def de_casteljau_trim(g, curves, from_t, end_t, is_bezier):
