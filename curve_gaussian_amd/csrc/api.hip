@@ -279,20 +279,11 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
             }
             BinState bin = bin_from_chunk(bchunk, (size_t)(cap * tiles));
             launch_scatter_bucket(s, P, radii, geom.rec, gx, gy, img.tile_count, bin.keys, (uint32_t)cap, cull);
-            if (render_fwd_can_sort((uint32_t)cap) && fuse_sort()) {   // depth sort fused into the compositor
-                launch_render_fwd_sorting(s, render_geo != 0, tiles, img.tile_count, bin.keys, (uint32_t)cap, img.ranges,
-                                          img.total, bin.point_list, width, height, gx, geom.rec, img.final_T,
-                                          img.n_contrib, background, out_color, out_invdepth, out_all_map);
-                if (!check_launch("render_fwd", debug, s)) return CGS_ERR_HIP;
-                if (!read_totals()) return CGS_ERR_HIP;
-            } else {
-                launch_tile_sort_bucket(s, tiles, img.tile_count, img.ranges, img.total, bin.keys, bin.point_list, (uint32_t)cap);
-                if (!read_totals()) return CGS_ERR_HIP;
-                if (!render(bin.point_list)) return CGS_ERR_HIP;
-            }
-#ifdef CGS_EXPERIMENT_NOWAIT
-            if (getenv("CGS_NOWAIT")) return g_R_hint.load(std::memory_order_relaxed);
-#endif
+            // (the fused sort+composite kernel is for the sync-free forward only: here num_rendered has to come back to
+            // the host, and with the separate sort kernel that readback overlaps the compositor instead of following it)
+            launch_tile_sort_bucket(s, tiles, img.tile_count, img.ranges, img.total, bin.keys, bin.point_list, (uint32_t)cap);
+            if (!read_totals()) return CGS_ERR_HIP;
+            if (!render(bin.point_list)) return CGS_ERR_HIP;
             if (!wait_totals()) return CGS_ERR_HIP;
             int64_t Rb = 0;
             uint32_t longest = 0;

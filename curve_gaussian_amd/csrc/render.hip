@@ -260,10 +260,10 @@ __global__ void __launch_bounds__(256) k_render_fwd(const uint2* __restrict__ ra
                 const float4 b = s_b[j];
                 const float dx = a.x - pixfx, dy = a.y - pixfy;
                 const float p2 = dx * (a.z * dx + a.w * dy) + b.x * dy * dy;
-                float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(p2));
-                alpha = (p2 > 0.0f) ? 0.f : alpha;              // reference: power > 0 -> skip
+                const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(p2));
                 const float test_T = Tw - Tw * alpha;
-                const bool hit = !(alpha < ALPHA_MIN);
+                // reference: power > 0 -> skip, alpha < 1/255 -> skip (both leave the pixel untouched)
+                const bool hit = !(alpha < ALPHA_MIN) && !(p2 > 0.0f);
                 const bool blend = hit && !(test_T < 0.0001f);  // a dead pixel has Tw == test_T == 0: never blends
                 const float w = blend ? alpha * Tw : 0.f;
                 C += b.z * w;
