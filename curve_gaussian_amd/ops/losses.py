@@ -82,6 +82,11 @@ class _PhotometricLoss(torch.autograd.Function):
             key = (str(dev), H, W, stream)
             ws = _PhotometricLoss._workspaces.get(key)
             if ws is None:
+                # bounded: every hipGraph capture runs on a fresh stream and would otherwise pin one workspace (3 maps)
+                # per capture forever.  Dropping an entry is safe: a captured graph keeps using the block inside its
+                # own memory pool, eager callers simply allocate a new one.
+                while len(_PhotometricLoss._workspaces) >= 6:
+                    _PhotometricLoss._workspaces.pop(next(iter(_PhotometricLoss._workspaces)))
                 ws = _PhotometricLoss._workspaces[key] = torch.zeros(
                     int(lib.cgs_photometric_workspace_bytes(H, W)), dtype=torch.uint8, device=dev)
             grad = torch.empty_like(img)

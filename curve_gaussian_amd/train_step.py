@@ -118,7 +118,10 @@ class GraphedTrainStep(TrainStep):
     The captured forward bins into fixed-capacity tile buckets sized from an eager probe (x ``cap_margin``).  If a
     bucket still overflows, the device-side flag makes the captured Adam skip its update (gradients are cleared);
     the host sees the flag one step later, redoes that view eagerly through the exact path, enlarges the buckets and
-    re-captures.  All cameras must share the image size and field of view (they are graph constants)."""
+    re-captures.  All cameras must share the image size and field of view (they are graph constants).
+
+    ``step()`` returns the graph's static loss tensor: it is overwritten by the next step (copy or ``float()`` it
+    to keep a value).  Call ``finish()`` before reading the model from outside or editing its topology."""
 
     def __init__(self, *args, cap_margin=1.5, **kw):
         kw["fused"] = True
