@@ -677,6 +677,25 @@ int cgs_photometric_loss(int height, int width, const float* image, const float*
     return CGS_OK;
 }
 
+size_t cgs_curve_regularizers_workspace_bytes(void) { return curve_reg_workspace_bytes(); }
+int cgs_curve_regularizers(int B, int m, const float* rotation_raw, const float* opacity_logit, const float* width_log,
+                           const int* radii, float w_opacity, const float* opacity_gate, float w_smooth, float w_width,
+                           float width_threshold, void* workspace, float* loss, float* dL_drotation_raw,
+                           float* dL_dopacity_logit, float* dL_dwidth_log, void* stream_) {
+    if (B <= 0 || m < 2 || m > 32 || 256 / m < 1 || !rotation_raw || !opacity_logit || !width_log || !radii || !workspace ||
+        !loss || !dL_drotation_raw || !dL_dopacity_logit || !dL_dwidth_log || !aligned16(rotation_raw) ||
+        !aligned16(dL_drotation_raw)) {
+        set_error("cgs_curve_regularizers: invalid argument (NULL / misaligned pointer, B=%d m=%d)", B, m);
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    hipStream_t s = (hipStream_t)stream_;
+    launch_curve_regularizers(s, B, m, rotation_raw, opacity_logit, width_log, radii, w_opacity, opacity_gate, w_smooth,
+                              w_width, width_threshold, workspace, loss, dL_drotation_raw, dL_dopacity_logit,
+                              dL_dwidth_log);
+    if (!check_launch("curve_regularizers", false, s)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
+
 int cgs_adam_step_flat(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                        const void* segments, int n_segments, float beta1, float beta2, float eps, int step,
                        int zero_grads, void* stream_) {

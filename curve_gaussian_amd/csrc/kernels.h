@@ -85,6 +85,11 @@ void launch_photometric_loss(hipStream_t s, int H, int W, const float* image, co
 void launch_edge_count(hipStream_t s, int C, int HW, const float* gt, float thr, unsigned int* n_pos);
 void launch_edge_aware_loss(hipStream_t s, int C, int H, int W, const float* image, const float* gt, float thr,
                             void* scratch16, float* grad);
+size_t curve_reg_workspace_bytes();
+void launch_curve_regularizers(hipStream_t s, int B, int m, const float* rot_raw, const float* opacity_logit,
+                               const float* width, const int* radii, float w_op, const float* op_gate, float w_smo,
+                               float w_width, float width_thr, void* workspace, float* loss, float* g_rot_raw,
+                               float* g_opacity_logit, float* g_width);
 int adam_max_segments();
 size_t adam_state_bytes();
 void launch_adam_flat_dev(hipStream_t s, long long n, float* p, float* g, float* m, float* v, const void* dev_state,

@@ -79,6 +79,207 @@ void launch_edge_aware_loss(hipStream_t s, int C, int H, int W, const float* ima
     { ProfScope p("edge_loss", s); hipLaunchKernelGGL(k_edge_loss, dim3(blocks), dim3(256), 0, s, C, HW, image, gt, thr, n_pos, loss_sum, grad); }
 }
 
+// ------------------------------------------------------------------------------------------------ curve regularisers
+// The per-iteration regularisers of train.py:113-131 in three launches (value + gradients), instead of ~60 PyTorch
+// elementwise / reduction kernels over all P splats and their autograd graph (0.8 ms at P = 200 k):
+//   opacity   w_op * gate * mean_{visible splats} log(1 + sigmoid(o_b)^2 / 0.5)                     (:114-117)
+//   smooth    w_smo * [any splat visible] * mean_{b, i<m-1} (1 - |cos(d_i, d_{i+1})|),             (:119-124)
+//             d = column 0 of pytorch3d.quaternion_to_matrix(F.normalize(q))
+//   width     w_w * mean_{curves with exp(w_b) >= thr} (exp(w_b) - thr)                             (:126-131)
+// Empty selections give 0 (the reference skips those terms with host-side ifs).  Blocks hold whole curves.
+constexpr int REG_SLOTS = 32;
+struct RegArgs { float w_op, w_smo, w_width, width_thr; };
+__device__ __forceinline__ float sigmoid_reg(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ void __launch_bounds__(256) k_reg_count(int P, int B, const int* __restrict__ radii,
+                                                   const float* __restrict__ width, float width_thr,
+                                                   unsigned int* __restrict__ counts) {
+    unsigned int nv = 0, nw = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x) {
+        nv += radii[i] > 0 ? 1u : 0u;
+        if (i < B) nw += expf(width[i]) >= width_thr ? 1u : 0u;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        nv += __shfl_xor(nv, off, 64);
+        nw += __shfl_xor(nw, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        const int slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) % REG_SLOTS;
+        if (nv) atomicAdd(&counts[slot], nv);
+        if (nw) atomicAdd(&counts[REG_SLOTS + slot], nw);
+    }
+}
+
+__device__ __forceinline__ void quat_axis0(float4 q, float (&d)[3], float& nrm, float (&qn)[4]) {
+    nrm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    const float den = fmaxf(nrm, 1e-12f);                      // F.normalize
+    qn[0] = q.x / den; qn[1] = q.y / den; qn[2] = q.z / den; qn[3] = q.w / den;
+    const float r = qn[0], i = qn[1], j = qn[2], k = qn[3];
+    const float two_s = 2.0f / (r * r + i * i + j * j + k * k);  // pytorch3d quaternion_to_matrix
+    d[0] = 1.f - two_s * (j * j + k * k);
+    d[1] = two_s * (i * j + k * r);
+    d[2] = two_s * (i * k - j * r);
+}
+// d(1 - |cos(x, y)|) / dx with torch's cosine_similarity: x.y / (max(|x|, eps) max(|y|, eps)), eps = 1e-8
+__device__ __forceinline__ float smooth_pair(const float* x, const float* y, float (&gx)[3]) {
+    const float eps = 1e-8f;
+    const float nx = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]), ny = sqrtf(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
+    const float cx = fmaxf(nx, eps), cy = fmaxf(ny, eps);
+    const float c = (x[0] * y[0] + x[1] * y[1] + x[2] * y[2]) / (cx * cy);
+    const float sgn = c > 0.f ? 1.f : (c < 0.f ? -1.f : 0.f);
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        // d c / d x = y / (cx cy) - c x / (cx nx)   (the second term vanishes where the norm is clamped)
+        const float dc = y[a] / (cx * cy) - (nx > eps ? c * x[a] / (cx * nx) : 0.f);
+        gx[a] = -sgn * dc;
+    }
+    return 1.f - fabsf(c);
+}
+
+__global__ void __launch_bounds__(256) k_reg_main(int B, int m, int curves_per_block, const float* __restrict__ rot_raw,
+                                                  const float* __restrict__ opacity_logit,
+                                                  const float* __restrict__ width, const int* __restrict__ radii,
+                                                  const unsigned int* __restrict__ counts, RegArgs ra,
+                                                  const float* __restrict__ op_gate, double* __restrict__ sums,
+                                                  float* __restrict__ g_rot_raw, float* __restrict__ g_opacity_logit,
+                                                  float* __restrict__ g_width) {
+    __shared__ float s_d[256][3];
+    __shared__ float s_go[256];
+    __shared__ float s_cnt[2];
+    if (threadIdx.x < 64) {   // totals of the two selections (REG_SLOTS partial counters each)
+        unsigned int v = threadIdx.x < 2 * REG_SLOTS ? counts[threadIdx.x] : 0u;
+#pragma unroll
+        for (int off = REG_SLOTS / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (threadIdx.x == 0) s_cnt[0] = (float)v;
+        if (threadIdx.x == REG_SLOTS) s_cnt[1] = (float)v;
+    }
+    const int lc = threadIdx.x / m, i = threadIdx.x - lc * m;
+    const int b = blockIdx.x * curves_per_block + lc;
+    const bool valid = lc < curves_per_block && b < B;
+    float d[3] = {0.f, 0.f, 0.f}, qn[4] = {0.f, 0.f, 0.f, 0.f}, nrm = 1.f;
+    size_t p = 0;
+    if (valid) {
+        p = (size_t)b * m + i;
+        quat_axis0(reinterpret_cast<const float4*>(rot_raw)[p], d, nrm, qn);
+    }
+    s_d[threadIdx.x][0] = d[0]; s_d[threadIdx.x][1] = d[1]; s_d[threadIdx.x][2] = d[2];
+    __syncthreads();
+    const float n_vis = s_cnt[0], n_w = s_cnt[1];
+    const float gate = op_gate ? *op_gate : 1.f;
+    const float any_vis = n_vis > 0.f ? 1.f : 0.f;
+    const float k_smo = ra.w_smo * any_vis / ((float)B * (float)(m - 1));
+    const float k_op = ra.w_op * gate / fmaxf(n_vis, 1.f);
+    const float k_w = ra.w_width / fmaxf(n_w, 1.f);
+    float v_smo = 0.f, v_op = 0.f, v_w = 0.f, go_term = 0.f;
+    if (valid) {
+        // smoothness: this sample is x of pair (i, i+1) and y of pair (i-1, i); the function is symmetric in x, y
+        float gd[3] = {0.f, 0.f, 0.f}, gt[3];
+        if (i + 1 < m) {
+            v_smo = smooth_pair(s_d[threadIdx.x], s_d[threadIdx.x + 1], gt);
+            gd[0] += gt[0]; gd[1] += gt[1]; gd[2] += gt[2];
+        }
+        if (i > 0) {
+            (void)smooth_pair(s_d[threadIdx.x], s_d[threadIdx.x - 1], gt);
+            gd[0] += gt[0]; gd[1] += gt[1]; gd[2] += gt[2];
+        }
+        gd[0] *= k_smo; gd[1] *= k_smo; gd[2] *= k_smo;
+        // d -> normalised quaternion -> raw quaternion (same chain as k_attrs_bwd)
+        const float r = qn[0], qi = qn[1], qj = qn[2], qk = qn[3];
+        const float s2 = r * r + qi * qi + qj * qj + qk * qk, two_s = 2.0f / s2;
+        const float e0 = qj * qj + qk * qk, e1 = qi * qj + qk * r, e2 = qi * qk - qj * r;
+        const float g_two_s = -gd[0] * e0 + gd[1] * e1 + gd[2] * e2;
+        const float g_s2 = g_two_s * (-2.0f / (s2 * s2));
+        float gq[4];
+        gq[0] = two_s * (gd[1] * qk - gd[2] * qj) + g_s2 * 2.f * r;
+        gq[1] = two_s * (gd[1] * qj + gd[2] * qk) + g_s2 * 2.f * qi;
+        gq[2] = two_s * (-2.f * gd[0] * qj + gd[1] * qi - gd[2] * r) + g_s2 * 2.f * qj;
+        gq[3] = two_s * (-2.f * gd[0] * qk + gd[1] * r + gd[2] * qi) + g_s2 * 2.f * qk;
+        float4 gr;
+        if (nrm > 1e-12f) {
+            const float dq = gq[0] * r + gq[1] * qi + gq[2] * qj + gq[3] * qk;
+            gr = make_float4((gq[0] - r * dq) / nrm, (gq[1] - qi * dq) / nrm, (gq[2] - qj * dq) / nrm, (gq[3] - qk * dq) / nrm);
+        } else {
+            gr = make_float4(gq[0] / 1e-12f, gq[1] / 1e-12f, gq[2] / 1e-12f, gq[3] / 1e-12f);
+        }
+        reinterpret_cast<float4*>(g_rot_raw)[p] = gr;
+        // opacity: every visible splat of curve b contributes log(1 + o^2 / 0.5)
+        if (radii[p] > 0) {
+            const float o = sigmoid_reg(opacity_logit[b]);
+            v_op = logf(1.f + o * o / 0.5f);
+            go_term = k_op * (2.f * o / 0.5f) / (1.f + o * o / 0.5f) * o * (1.f - o);
+        }
+        if (i == 0) {   // width: one term per curve
+            const float w = expf(width[b]);
+            const bool sel = w >= ra.width_thr;
+            v_w = sel ? w - ra.width_thr : 0.f;
+            g_width[b] = sel ? k_w * w : 0.f;
+        }
+    }
+    s_go[threadIdx.x] = go_term;
+    __syncthreads();
+    if (valid && i == 0) {
+        float sum = 0.f;
+        for (int q = 0; q < m; q++) sum += s_go[threadIdx.x + q];
+        g_opacity_logit[b] = sum;
+    }
+    // block sums of the three values -> partial slots
+    float v[3] = {v_smo, v_op, v_w};
+    __shared__ float s_w[3][4];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v[t] += __shfl_xor(v[t], off, 64);
+        if ((threadIdx.x & 63) == 0) s_w[t][threadIdx.x >> 6] = v[t];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        atomicAdd(&sums[threadIdx.x * REG_SLOTS + blockIdx.x % REG_SLOTS],
+                  (double)s_w[threadIdx.x][0] + (double)s_w[threadIdx.x][1] + (double)s_w[threadIdx.x][2] + (double)s_w[threadIdx.x][3]);
+}
+
+__global__ void __launch_bounds__(64) k_reg_finish(int B, int m, unsigned int* __restrict__ counts,
+                                                   double* __restrict__ sums, RegArgs ra,
+                                                   const float* __restrict__ op_gate, float* __restrict__ loss) {
+    const int t = threadIdx.x;
+    unsigned int c = counts[t];
+    counts[t] = 0u;   // self-cleaning workspace
+#pragma unroll
+    for (int off = REG_SLOTS / 2; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+    const float n_vis = (float)__shfl((int)c, 0, 64), n_w = (float)__shfl((int)c, REG_SLOTS, 64);
+    double part[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        double s = t < REG_SLOTS ? sums[q * REG_SLOTS + t] : 0.0;
+        if (t < REG_SLOTS) sums[q * REG_SLOTS + t] = 0.0;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        part[q] = s;
+    }
+    if (t == 0) {
+        const float gate = op_gate ? *op_gate : 1.f;
+        const double smo = (double)ra.w_smo * (n_vis > 0.f ? 1.0 : 0.0) * part[0] / ((double)B * (double)(m - 1));
+        const double op = (double)ra.w_op * gate * part[1] / fmax((double)n_vis, 1.0);
+        const double wd = (double)ra.w_width * part[2] / fmax((double)n_w, 1.0);
+        *loss = (float)(smo + op + wd);
+    }
+}
+
+size_t curve_reg_workspace_bytes() { return 2 * REG_SLOTS * sizeof(unsigned int) + 3 * REG_SLOTS * sizeof(double); }
+void launch_curve_regularizers(hipStream_t s, int B, int m, const float* rot_raw, const float* opacity_logit,
+                               const float* width, const int* radii, float w_op, const float* op_gate, float w_smo,
+                               float w_width, float width_thr, void* workspace, float* loss, float* g_rot_raw,
+                               float* g_opacity_logit, float* g_width) {
+    unsigned int* counts = reinterpret_cast<unsigned int*>(workspace);
+    double* sums = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + 2 * REG_SLOTS * sizeof(unsigned int));
+    const RegArgs ra{w_op, w_smo, w_width, width_thr};
+    const int P = B * m;
+    const int cpb = 256 / m;
+    { ProfScope p("reg_count", s); hipLaunchKernelGGL(k_reg_count, dim3(std::min((P + 255) / 256, 512)), dim3(256), 0, s, P, B, radii, width, width_thr, counts); }
+    { ProfScope p("reg_main", s); hipLaunchKernelGGL(k_reg_main, dim3((B + cpb - 1) / cpb), dim3(256), 0, s, B, m, cpb, rot_raw, opacity_logit, width, radii, counts, ra, op_gate, sums, g_rot_raw, g_opacity_logit, g_width); }
+    { ProfScope p("reg_finish", s); hipLaunchKernelGGL(k_reg_finish, dim3(1), dim3(64), 0, s, B, m, counts, sums, ra, op_gate, loss); }
+}
+
 // ------------------------------------------------------------------------------------------------ flat Adam
 // torch.optim.Adam (default, non-amsgrad, no weight decay) over ONE flat parameter buffer with per-segment learning
 // rates -- the reference steps 6 parameter groups with ~8 foreach kernels each (GaussianCurveModel.training_setup,

@@ -39,3 +39,67 @@ def width_loss(gaussians, weight=0.01, width_thr=0.005):
     w = gaussians.get_curve_width
     sel = (w >= width_thr).to(w.dtype)
     return weight * ((w - width_thr) * sel).sum() / sel.sum().clamp(min=1.0)
+
+
+# ---------------------------------------------------------------------------------------------- fused HIP version
+import ctypes as _C
+
+from .. import _lib as _L
+
+
+class _CurveRegularizers(torch.autograd.Function):
+    """opacity + smoothness + width terms above from cgs_curve_regularizers: value and gradients in three launches
+    (the torch-op versions cost ~60 launches and 0.8 ms at P = 200 k)."""
+    _workspaces = {}
+
+    @staticmethod
+    def forward(ctx, rotation_raw, opacity_logit, width_log, radii, m, w_opacity, opacity_gate, w_smooth, w_width, width_thr):
+        _L.require_gpu_tensor(rotation_raw, "rotation")
+        lib = _L.load()
+        dev = rotation_raw.device
+        rot = rotation_raw.detach().float().contiguous()
+        op = opacity_logit.detach().float().contiguous()
+        wl = width_log.detach().float().contiguous()
+        rad = radii.detach().to(torch.int32).contiguous()
+        P = rot.shape[0]
+        B = P // m
+        stream = _L.raw_stream(dev)
+        key = (str(dev), stream)
+        ws = _CurveRegularizers._workspaces.get(key)
+        if ws is None:
+            while len(_CurveRegularizers._workspaces) >= 8:
+                _CurveRegularizers._workspaces.pop(next(iter(_CurveRegularizers._workspaces)))
+            ws = _CurveRegularizers._workspaces[key] = torch.zeros(
+                int(lib.cgs_curve_regularizers_workspace_bytes()), dtype=torch.uint8, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        g_rot = torch.empty_like(rot)
+        g_op = torch.empty_like(op)
+        g_w = torch.empty_like(wl)
+        gate = None
+        if torch.is_tensor(opacity_gate):
+            gate = opacity_gate.detach().float().contiguous()
+            w_op = float(w_opacity)
+        else:
+            w_op = float(w_opacity) * float(opacity_gate)
+        rc = lib.cgs_curve_regularizers(B, int(m), _L.ptr(rot), _L.ptr(op), _L.ptr(wl), _L.ptr(rad), _C.c_float(w_op),
+                                        _L.ptr(gate) if gate is not None else None, _C.c_float(w_smooth),
+                                        _C.c_float(w_width), _C.c_float(width_thr), _L.ptr(ws), _L.ptr(loss),
+                                        _L.ptr(g_rot), _L.ptr(g_op), _L.ptr(g_w), stream)
+        _L.check(rc, "cgs_curve_regularizers")
+        ctx.save_for_backward(g_rot, g_op, g_w)
+        ctx.shapes = (rotation_raw.shape, opacity_logit.shape, width_log.shape)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        g_rot, g_op, g_w = ctx.saved_tensors
+        s = ctx.shapes
+        return ((g_rot * g).view(s[0]), (g_op * g).view(s[1]), (g_w * g).view(s[2]), None, None, None, None, None,
+                None, None)
+
+
+def curve_regularizers(gaussians, radii, w_opacity=0.01, opacity_gate=1.0, w_smooth=0.1, w_width=0.01, width_thr=0.005):
+    """opacity_loss * gate + curve_smoothness_loss + width_loss (the three functions above), fused.
+    opacity_gate: float or 0-dim device tensor (train.py's ``reset_timestep > 0``)."""
+    return _CurveRegularizers.apply(gaussians._rotation, gaussians._opacity, gaussians._width, radii, gaussians.n_gaussians,
+                                    w_opacity, opacity_gate, w_smooth, w_width, width_thr)

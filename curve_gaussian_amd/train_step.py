@@ -62,6 +62,9 @@ class TrainStep:
         """train.py:113-131; opacity_gate (float or device scalar) switches the opacity term (reset_timestep > 0)."""
         from .ops import regularizers as RG
         g = self.g
+        if self.fused:   # one HIP op (three launches)
+            return RG.curve_regularizers(g, radii, self.opacity_loss_weight, opacity_gate, self.lambda_curve_smo,
+                                         self.lambda_width)
         reg = RG.opacity_loss(g, radii, self.opacity_loss_weight) * opacity_gate
         if self.lambda_curve_smo > 0:
             reg = reg + RG.curve_smoothness_loss(g, radii, self.lambda_curve_smo)

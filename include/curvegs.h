@@ -197,6 +197,23 @@ int cgs_photometric_loss(int height, int width, const float* image, const float*
                          const uint32_t* n_pos, float lambda_edge, float lambda_ssim, int clamp_input, void* workspace,
                          float* dL_dimage, float* loss, void* stream);
 
+/* The per-iteration regularisers of /root/reference/train.py:113-131 (PyTorch ops over all P splats in the reference),
+ * value and gradients in three launches:
+ *   loss = w_opacity * gate * mean_{splats with radii > 0} log(1 + sigmoid(opacity_logit[b])^2 / 0.5)
+ *        + w_smooth * [any radii > 0] * mean_{b, i < m-1} (1 - |cos(d_i, d_{i+1})|),
+ *              d = column 0 of quaternion_to_matrix(normalize(rotation_raw))  (main axis of splat b*m + i)
+ *        + w_width * mean_{curves with exp(width_log[b]) >= width_threshold} (exp(width_log[b]) - width_threshold)
+ * Empty selections contribute 0 (the reference guards them with host-side ifs).  opacity_gate: device float or NULL
+ * (= 1): train.py's `reset_timestep > 0` switch, kept on the device so a captured graph need not be re-captured.
+ * rotation_raw [B*m,4] (16-byte aligned), opacity_logit [B], width_log [B], radii [B*m] int32.  workspace:
+ * cgs_curve_regularizers_workspace_bytes() bytes, zero-filled before its FIRST use, then reusable as is.
+ * Outputs: loss [1]; dL_drotation_raw [B*m,4], dL_dopacity_logit [B], dL_dwidth_log [B] (every element written). */
+size_t cgs_curve_regularizers_workspace_bytes(void);
+int cgs_curve_regularizers(int B, int m, const float* rotation_raw, const float* opacity_logit, const float* width_log,
+                           const int* radii, float w_opacity, const float* opacity_gate, float w_smooth, float w_width,
+                           float width_threshold, void* workspace, float* loss, float* dL_drotation_raw,
+                           float* dL_dopacity_logit, float* dL_dwidth_log, void* stream);
+
 /* One-launch Adam over a flat parameter buffer (torch.optim.Adam semantics: no weight decay, no amsgrad), replacing
  * the per-group foreach step of the reference (scene/gaussian_curve_model.py:200-213, train.py:235).
  * segments: HOST array of n_segments (<= 16) x {int64 begin; float lr; float pad}, sorted by begin,

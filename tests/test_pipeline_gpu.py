@@ -309,6 +309,17 @@ def test_regularisers_match_the_reference_formulas():
     np.testing.assert_allclose(float(mine), float(ref), rtol=1e-6)
     for a, b in zip(grads(mine), g_ref):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-9)
+    # the fused HIP op (cgs_curve_regularizers) against the same reference, incl. a device-side opacity gate
+    for gate in (1.0, torch.ones((), device=DEV), 0.0):
+        fused = RG.curve_regularizers(gm, radii, 0.01, gate, 0.1, 0.01)
+        if float(gate) == 1.0:
+            np.testing.assert_allclose(float(fused), float(ref), rtol=2e-5)
+            for a, b, n in zip(grads(fused), g_ref, names):
+                np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=1e-8, err_msg="fused " + n)
+        else:
+            no_op = RG.curve_smoothness_loss(gm, radii, 0.1) + RG.width_loss(gm, 0.01)
+            np.testing.assert_allclose(float(fused), float(no_op), rtol=2e-5)
+    assert float(RG.curve_regularizers(gm, torch.zeros_like(radii), 0.01, 1.0, 0.1, 0.0)) == 0.0   # nothing visible
     # nothing visible / nothing above the threshold: the conditional terms vanish instead of dividing by zero
     none = torch.zeros_like(radii)
     assert float(RG.opacity_loss(gm, none)) == 0.0 and float(RG.curve_smoothness_loss(gm, none)) == 0.0
