@@ -427,6 +427,21 @@ def main():
         gs.finish()
         torch.cuda.synchronize()
         graph_ms = (time.perf_counter() - tt0) / n_gs * 1e3
+        # ... and with the regularisers of train.py:113-131 switched on (not part of the BASELINE metric)
+        gm3 = GaussianCurveModel(0, m, device=dev).create_from_curves(curves["curve_points"], curves["width"],
+                                                                      curves["opacity"], curves["mask"],
+                                                                      curves["is_bezier"])
+        gr = GraphedTrainStep(gm3, tcams, gts, regularisers=True)
+        for _ in range(3):
+            gr.step()
+        gr.finish()
+        torch.cuda.synchronize()
+        tt0 = time.perf_counter()
+        for _ in range(n_gs):
+            gr.step()
+        gr.finish()
+        torch.cuda.synchronize()
+        out["train_step_with_regularisers_ms"] = round((time.perf_counter() - tt0) / n_gs * 1e3, 4)
         out["train_step_ms"] = round(graph_ms, 4)
         out["train_step_eager_ms"] = round(eager_ms, 4)
         out["train_step_graph_recaptures"] = gs.recaptures
