@@ -149,6 +149,7 @@ class GraphedTrainStep(TrainStep):
         self._cap = 0
         self._loss = None
         self._status = None
+        self._use_mask = False
         self._flag_host = torch.zeros(64, dtype=torch.int32).pin_memory()
         self._inflight = []   # (event, slot, view index, iteration)
         self.recaptures = 0
@@ -161,9 +162,12 @@ class GraphedTrainStep(TrainStep):
         # prepare_scaling_rot opens the captured sequence (the reference runs it at the END of the previous iteration,
         # train.py:242-243 -- same data flow, but every replay must read the parameters, not a tensor of an older replay)
         g.prepare_scaling_rot()
-        pkg = render(self._cam, g, self.pipe, self.bg, compute_visibility=False, clamp=False, compute_rend_dir=False,
+        pkg = render(self._cam, g, self.pipe, self.bg, use_mask=self._use_mask, mask_thr=self.mask_threshold,
+                     compute_visibility=False, clamp=False, compute_rend_dir=False,
                      static_bucket_cap=self._cap, status_sink=sink)
         loss = photometric_loss(pkg["render"], self._gt, self.lambda_mse, self.lambda_dssim, clamp=True, n_pos=self._npos)
+        if self._use_mask:      # train.py:110-111 (a graph constant: the switch at densify_until_iter re-captures)
+            loss = loss + self.lambda_mask * torch.mean(torch.sigmoid(g._mask))
         if self.regularisers:   # sync-free torch ops; the opacity term is gated by a device scalar refreshed per step
             loss = loss + self._regulariser_terms(pkg["radii"], self._opa_gate)
         if getattr(self, "_debug_keep", None) is not None:
@@ -262,10 +266,11 @@ class GraphedTrainStep(TrainStep):
 
     def step(self, view_index=None):
         g = self.g
-        if self.iteration + 1 >= self.densify_until_iter:   # mask regulariser phase: not captured
-            self._check_overflow(block=True)
-            self._refresh_derived()
-            return TrainStep.step(self, view_index)
+        use_mask = self.iteration + 1 >= self.densify_until_iter
+        if use_mask != self._use_mask:                      # mask phase starts: straight-through mask + mask loss
+            self.finish()
+            self._use_mask = use_mask
+            self._graph = None
         self._check_overflow()
         self.iteration += 1
         g.update_learning_rate(self.iteration)

@@ -341,3 +341,23 @@ def test_regularisers_match_the_reference_formulas():
     np.testing.assert_allclose(float(lb), float(la), rtol=1e-4)
     for n in names:
         np.testing.assert_allclose(getattr(gb, n).detach().cpu().numpy(), getattr(ga, n).detach().cpu().numpy(), rtol=1e-3, atol=1e-5)   # 8 Adam steps amplify rounding
+
+
+def test_graphed_train_step_crosses_the_mask_phase():
+    """At densify_until_iter the iteration switches to the straight-through curve mask + mask loss (train.py:97,110-111);
+    the graphed step re-captures once and keeps following the eager trajectory."""
+    from curve_gaussian_amd.train_step import GraphedTrainStep, TrainStep
+    torch.manual_seed(0); ga, cams, gts = _train_fixture()
+    torch.manual_seed(0); gb, _, _ = _train_fixture()
+    ea = TrainStep(ga, cams, gts, seed=6, densify_until_iter=5)
+    gs = GraphedTrainStep(gb, cams, gts, seed=6, densify_until_iter=5)
+    for _ in range(10):
+        la = ea.step()[0]
+        lb = gs.step()[0]
+    gs.finish()
+    assert gs.recaptures == 2 and gs._use_mask
+    np.testing.assert_allclose(float(lb), float(la), rtol=1e-4)
+    for n in ("_curve_points", "_width", "_opacity", "_mask"):
+        np.testing.assert_allclose(getattr(gb, n).detach().cpu().numpy(), getattr(ga, n).detach().cpu().numpy(),
+                                   rtol=1e-3, atol=1e-5, err_msg=n)
+    assert float((gb._mask.detach() - 1.0).abs().max()) > 0   # the mask logits did move in the mask phase
