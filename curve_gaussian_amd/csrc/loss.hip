@@ -104,10 +104,12 @@ __global__ void __launch_bounds__(256) k_reg_count(int P, int B, const int* __re
         nv += __shfl_xor(nv, off, 64);
         nw += __shfl_xor(nw, off, 64);
     }
-    if ((threadIdx.x & 63) == 0) {
-        const int slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) % REG_SLOTS;
-        if (nv) atomicAdd(&counts[slot], nv);
-        if (nw) atomicAdd(&counts[REG_SLOTS + slot], nw);
+    __shared__ unsigned int s_n[2][4];
+    if ((threadIdx.x & 63) == 0) { s_n[0][threadIdx.x >> 6] = nv; s_n[1][threadIdx.x >> 6] = nw; }
+    __syncthreads();
+    if (threadIdx.x < 2) {   // one atomic per block and counter, spread over REG_SLOTS addresses
+        const unsigned int t = s_n[threadIdx.x][0] + s_n[threadIdx.x][1] + s_n[threadIdx.x][2] + s_n[threadIdx.x][3];
+        if (t) atomicAdd(&counts[threadIdx.x * REG_SLOTS + blockIdx.x % REG_SLOTS], t);
     }
 }
 

@@ -9,6 +9,27 @@ import torch
 from .. import _lib as L
 
 
+_UNIT = {}
+
+
+def unit_grad(device):
+    """A shared 0-dim tensor holding 1.0.  ``loss.backward(gradient=unit_grad(dev))`` (what the train steps do) lets the
+    loss ops recognise the usual d loss / d loss = 1 by its storage and hand their pre-computed gradient on without
+    the ``grad * g`` kernel; any other upstream gradient is multiplied in as autograd requires."""
+    key = str(device)
+    t = _UNIT.get(key)
+    if t is None:
+        t = _UNIT[key] = torch.ones((), dtype=torch.float32, device=device)
+    return t
+
+
+def scale_by_upstream(grad, g):
+    u = _UNIT.get(str(grad.device))
+    if u is not None and g.data_ptr() == u.data_ptr() and g.numel() == 1:
+        return grad
+    return grad * g
+
+
 class _EdgeAwareLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image, gt_image, threshold):
@@ -102,7 +123,7 @@ class _PhotometricLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
-        return grad * g, None, None, None, None, None, None
+        return scale_by_upstream(grad, g), None, None, None, None, None, None
 
 
 def edge_pixel_count(gt_image, threshold=0.1):

@@ -94,7 +94,8 @@ class _CurveRegularizers(torch.autograd.Function):
     def backward(ctx, g):
         g_rot, g_op, g_w = ctx.saved_tensors
         s = ctx.shapes
-        return ((g_rot * g).view(s[0]), (g_op * g).view(s[1]), (g_w * g).view(s[2]), None, None, None, None, None,
+        from .losses import scale_by_upstream as sc
+        return (sc(g_rot, g).view(s[0]), sc(g_op, g).view(s[1]), sc(g_w, g).view(s[2]), None, None, None, None, None,
                 None, None)
 
 

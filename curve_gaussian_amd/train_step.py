@@ -11,7 +11,7 @@ import torch
 
 from .fused_ssim import fused_ssim
 from .gaussian_renderer import PipelineParams, render
-from .ops.losses import edge_aware_loss, photometric_loss
+from .ops.losses import edge_aware_loss, photometric_loss, unit_grad
 from .ops.optim import FlatAdam
 from .view_parallel import FlatGrads, StaticCamera as _StaticCamera
 
@@ -98,7 +98,7 @@ class TrainStep:
             loss = loss + self.lambda_mask * torch.mean(torch.sigmoid(g._mask))
         if self.regularisers:
             loss = loss + self._regulariser_terms(pkg["radii"], 1.0 if self.reset_timestep > 0 else 0.0)
-        loss.backward()
+        loss.backward(gradient=unit_grad(loss.device) if self.fused else None)
         self.flat.all_reduce()
         if self.fused:
             g.optimizer.step(zero_grad=True)       # Adam + zero_grad in one launch
@@ -137,14 +137,21 @@ class GraphedTrainStep(TrainStep):
             if (c.image_height, c.image_width, c.FoVx, c.FoVy) != (c0.image_height, c0.image_width, c0.FoVx, c0.FoVy):
                 raise ValueError("GraphedTrainStep: all cameras must share image size and field of view")
         self.cap_margin = float(cap_margin)
+        # per-step inputs of the graph: ONE packed buffer per view (camera pose 35 floats | edge-pixel count as int32
+        # bits) + the gt edge map; the opacity gate only changes with reset_timestep
         self._cam = _StaticCamera(c0, dev)
-        self._cam_packs = [_StaticCamera.packed(c).to(dev) for c in self.cams]
-        self._gt = torch.empty_like(self.gts[0][:1]).contiguous()
+        self._inputs = torch.zeros(36, dtype=torch.float32, device=dev)
+        self._cam.pack = self._inputs[0:35]
+        self._cam.world_view_transform = self._cam.pack[0:16].view(4, 4)
+        self._cam.full_proj_transform = self._cam.pack[16:32].view(4, 4)
+        self._cam.camera_center = self._cam.pack[32:35]
+        self._npos = self._inputs[35:36].view(torch.int32)
         from .ops.losses import edge_pixel_count
-        self._npos_all = [edge_pixel_count(g[:1]) for g in self.gts]
-        self._npos = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._view_packs = [torch.cat([_StaticCamera.packed(c).to(dev), edge_pixel_count(g[:1]).view(torch.float32)])
+                            for c, g in zip(self.cams, self.gts)]
+        self._gt = torch.empty_like(self.gts[0][:1]).contiguous()
         self._opa_gate = torch.zeros((), dtype=torch.float32, device=dev)
-        self._gates = (torch.zeros((), device=dev), torch.ones((), device=dev))
+        self._gate_value = 0.0
         self._graph = None
         self._cap = 0
         self._loss = None
@@ -174,7 +181,7 @@ class GraphedTrainStep(TrainStep):
             import os
             allk = dict(xyz=g._xyz, rot=g._rotation, scl=g._scaling, radii=pkg["radii"], img=pkg["render"], depth=pkg["depth"])
             self._debug_keep.update({k: v for k, v in allk.items() if k in os.environ.get("CGS_DBG_KEEP", "").split(",")})
-        loss.backward()
+        loss.backward(gradient=unit_grad(loss.device))
         status = sink[0]
         g.optimizer.step_dev(zero_grad=True, skip_flag=status[2:3])
         return loss.detach(), status
@@ -199,10 +206,12 @@ class GraphedTrainStep(TrainStep):
         return cap
 
     def _load_inputs(self, vi):
-        self._cam.pack.copy_(self._cam_packs[vi], non_blocking=True)
+        self._inputs.copy_(self._view_packs[vi], non_blocking=True)
         self._gt.copy_(self.gts[vi][:1], non_blocking=True)
-        self._npos.copy_(self._npos_all[vi], non_blocking=True)
-        self._opa_gate.copy_(self._gates[1 if self.reset_timestep > 0 else 0], non_blocking=True)
+        gate = 1.0 if self.reset_timestep > 0 else 0.0
+        if gate != self._gate_value:
+            self._opa_gate.fill_(gate)
+            self._gate_value = gate
 
     def _capture(self, vi):
         if self._cap == 0:
