@@ -126,7 +126,7 @@ class GraphedTrainStep(TrainStep):
     ``step()`` returns the graph's static loss tensor: it is overwritten by the next step (copy or ``float()`` it
     to keep a value).  Call ``finish()`` before reading the model from outside or editing its topology."""
 
-    def __init__(self, *args, cap_margin=1.5, **kw):
+    def __init__(self, *args, cap_margin=1.5, direct=True, **kw):
         kw["fused"] = True
         super().__init__(*args, **kw)
         if self.world != 1:
@@ -137,6 +137,8 @@ class GraphedTrainStep(TrainStep):
             if (c.image_height, c.image_width, c.FoVx, c.FoVy) != (c0.image_height, c0.image_width, c0.FoVx, c0.FoVy):
                 raise ValueError("GraphedTrainStep: all cameras must share image size and field of view")
         self.cap_margin = float(cap_margin)
+        self.direct = bool(direct)   # True: the captured sequence calls the C ABI directly (no autograd inside the graph)
+        self._bufs = None
         # per-step inputs of the graph: ONE packed buffer per view (camera pose 35 floats | edge-pixel count as int32
         # bits) + the gt edge map; the opacity gate only changes with reset_timestep
         self._cam = _StaticCamera(c0, dev)
@@ -164,6 +166,8 @@ class GraphedTrainStep(TrainStep):
 
     # -- the captured sequence ---------------------------------------------------------------------------------
     def _body(self):
+        if self.direct:
+            return self._body_direct()
         g = self.g
         sink = []
         # prepare_scaling_rot opens the captured sequence (the reference runs it at the END of the previous iteration,
@@ -185,6 +189,121 @@ class GraphedTrainStep(TrainStep):
         status = sink[0]
         g.optimizer.step_dev(zero_grad=True, skip_flag=status[2:3])
         return loss.detach(), status
+
+    # -- the same sequence without autograd: every kernel of the iteration called through the C ABI on preallocated
+    # buffers, gradients written straight into the flat gradient buffer.  Inside a graph the autograd bookkeeping
+    # costs nothing on the host, but it does cost GPU launches (gradient accumulation adds, ones/zeros fills,
+    # grad * 1 multiplies: ~10 of 41 launches, ~45 us at cfg3).
+    def _alloc_direct(self):
+        import ctypes as C
+        from . import _lib as L
+        from .ops.curve_sampling import sample_coefficients, _bezier_mask
+        lib = L.load()
+        g = self.g
+        dev = g.device
+        m = g.n_gaussians
+        B = g._curve_points.shape[0]
+        P = B * m
+        H, W = self._cam.image_height, self._cam.image_width
+        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        u8 = lambda n: torch.empty(int(n), dtype=torch.uint8, device=dev)
+        b = dict(B=B, P=P, m=m, H=H, W=W)
+        b["coef"] = sample_coefficients(m, dev)
+        b["isb"] = _bezier_mask(g.is_bezier, dev)
+        b["norms"] = torch.empty(384, dtype=torch.float64, device=dev)
+        b["xyz"], b["rot"], b["scl"] = f(P, 3), f(P, 4), f(P, 3)
+        b["rot_n"], b["opac"], b["amap"], b["scl_m"] = f(P, 4), f(P, 1), f(P, 4), f(P, 3)
+        b["colors"] = torch.ones(P, 1, device=dev)
+        b["geom"] = u8(lib.cgs_geometry_bytes(P))
+        b["nbin"] = int(lib.cgs_binning_bytes(self._cap * tiles))
+        b["bin"] = u8(b["nbin"])
+        b["img"] = u8(lib.cgs_image_bytes(W, H))
+        off, n = int(lib.cgs_image_status_offset(W, H)), int(lib.cgs_status_words())
+        b["status"] = b["img"][off:off + 4 * n].view(torch.int32)
+        b["color"], b["invd"], b["omap"] = f(1, H, W), f(1, H, W), f(4, H, W)
+        b["radii"] = torch.empty(P, dtype=torch.int32, device=dev)
+        b["photo_ws"] = torch.zeros(int(lib.cgs_photometric_workspace_bytes(H, W)), dtype=torch.uint8, device=dev)
+        b["g_img"] = f(1, H, W)
+        b["loss"] = torch.zeros((), dtype=torch.float32, device=dev)
+        b["g_m2d"], b["g_conic"], b["g_opac"] = f(P, 3), f(P, 2, 2), f(P, 1)
+        b["g_m3d"], b["g_cov"], b["g_scl"], b["g_rotn"], b["g_amap"] = f(P, 3), f(P, 6), f(P, 3), f(P, 4), f(P, 4)
+        b["g_rot_raw"], b["g_scaling"], b["gv"] = f(P, 4), f(P, 3), f(P, 9)
+        b["reg_ws"] = torch.zeros(int(lib.cgs_curve_regularizers_workspace_bytes()), dtype=torch.uint8, device=dev)
+        b["reg_loss"] = torch.zeros((), dtype=torch.float32, device=dev)
+        b["r_rot"], b["r_op"], b["r_w"] = f(P, 4), f(B, 1), f(B, 1)
+        b["mask_loss"] = torch.zeros((), dtype=torch.float32, device=dev)
+        b["bg"] = self.bg.float().contiguous()
+        self._bufs = b
+        return b
+
+    def _body_direct(self):
+        import ctypes as C
+        import math
+        from . import _lib as L
+        lib = L.load()
+        g = self.g
+        b = self._bufs if self._bufs is not None else self._alloc_direct()
+        B, P, m, H, W = b["B"], b["P"], b["m"], b["H"], b["W"]
+        p, cf, s = L.ptr, C.c_float, L.raw_stream(g.device)
+        grads = g.optimizer.grads                       # FlatGrads: .view(name) are the parameters' .grad
+        cp, wl, ol = g._curve_points.detach(), g._width.detach(), g._opacity.detach()
+        mask = g._mask.detach() if self._use_mask else None
+        cam = self._cam
+        tanx, tany = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+        chk = L.check
+        # ---- forward: curves -> splats -> per-view attributes -> rasterizer (sync-free) -> loss
+        chk(lib.cgs_sample_curves_forward(B, m, p(cp), p(wl), p(b["isb"]), p(b["coef"]), cf(1e-8), p(b["norms"]),
+                                          p(b["xyz"]), p(b["rot"]), p(b["scl"]), s), "sample_curves_forward")
+        chk(lib.cgs_splat_attrs_forward(B, m, p(b["rot"]), p(b["xyz"]), p(ol), p(mask), cf(self.mask_threshold),
+                                        p(b["scl"]), p(cam.camera_center), p(cam.world_view_transform), p(b["rot_n"]),
+                                        p(b["opac"]), p(b["scl_m"]) if mask is not None else None, p(b["amap"]), s),
+            "splat_attrs_forward")
+        scales = b["scl_m"] if mask is not None else b["scl"]
+        chk(lib.cgs_rasterize_forward_static(
+            p(b["geom"]), p(b["bin"]), b["nbin"], p(b["img"]), self._cap, P, 0, 0, p(b["bg"]), W, H, p(b["xyz"]), None,
+            p(b["colors"]), p(b["opac"]), p(scales), 1.0, p(b["rot_n"]), None, p(b["amap"]),
+            p(cam.world_view_transform), p(cam.full_proj_transform), p(cam.camera_center), tanx, tany, p(b["color"]),
+            p(b["invd"]), p(b["omap"]), 0, 1, p(b["radii"]), s), "rasterize_forward_static")
+        a = self.lambda_mse * (1.0 - self.lambda_dssim)
+        bb = self.lambda_mse * self.lambda_dssim
+        chk(lib.cgs_photometric_loss(H, W, p(b["color"]), p(self._gt), cf(0.1), p(self._npos), cf(a), cf(bb), 1,
+                                     p(b["photo_ws"]), p(b["g_img"]), p(b["loss"]), s), "photometric_loss")
+        # ---- backward: rasterizer -> attributes -> sampling, straight into the flat gradient views
+        chk(lib.cgs_rasterize_backward(
+            P, 0, 0, 1, p(b["bg"]), W, H, p(b["xyz"]), None, p(b["colors"]), p(b["amap"]), p(b["opac"]), p(scales), 1.0,
+            p(b["rot_n"]), None, p(cam.world_view_transform), p(cam.full_proj_transform), p(cam.camera_center), tanx,
+            tany, p(b["radii"]), p(b["geom"]), p(b["bin"]), p(b["img"]), p(b["g_img"]), None, None, p(b["g_m2d"]),
+            p(b["g_conic"]), p(b["g_opac"]), None, None, p(b["g_m3d"]), p(b["g_cov"]), None, p(b["g_scl"]),
+            p(b["g_rotn"]), p(b["g_amap"]), 0, 1, 0, s), "rasterize_backward")
+        chk(lib.cgs_splat_attrs_backward(
+            B, m, p(b["rot"]), p(b["xyz"]), p(ol), p(mask), cf(self.mask_threshold), p(b["scl"]), p(cam.camera_center),
+            p(cam.world_view_transform), p(b["g_rotn"]), p(b["g_opac"]), p(b["g_scl"]) if mask is not None else None,
+            p(b["g_amap"]), p(b["g_rot_raw"]), p(grads.view("opacity")), p(grads.view("mask")) if mask is not None else None,
+            p(b["g_scaling"]) if mask is not None else None, s), "splat_attrs_backward")
+        g_scaling = b["g_scaling"] if mask is not None else b["g_scl"]
+        loss = b["loss"]
+        if self.regularisers:
+            chk(lib.cgs_curve_regularizers(B, m, p(b["rot"]), p(ol), p(wl), p(b["radii"]), cf(self.opacity_loss_weight),
+                                           p(self._opa_gate), cf(self.lambda_curve_smo), cf(self.lambda_width), cf(0.005),
+                                           p(b["reg_ws"]), p(b["reg_loss"]), p(b["r_rot"]), p(b["r_op"]), p(b["r_w"]), s),
+                "curve_regularizers")
+            b["g_rot_raw"].add_(b["r_rot"])
+            grads.view("opacity").add_(b["r_op"])
+            loss = loss + b["reg_loss"]
+        chk(lib.cgs_sample_curves_backward(B, m, p(cp), p(wl), p(b["isb"]), p(b["coef"]), cf(1e-8), p(b["norms"]),
+                                           p(b["g_m3d"]), p(b["g_rot_raw"]), p(g_scaling), p(grads.view("curve_points")),
+                                           p(grads.view("width")), p(b["gv"]), s), "sample_curves_backward")
+        if self.regularisers:
+            grads.view("width").add_(b["r_w"])
+        if self._use_mask:      # train.py:110-111: lambda_mask * mean(sigmoid(mask)), gradient added by hand
+            sg = torch.sigmoid(mask)
+            loss = loss + self.lambda_mask * sg.mean()
+            grads.view("mask").add_(sg * (1 - sg), alpha=self.lambda_mask / mask.numel())
+        status = b["status"]
+        g.optimizer.step_dev(zero_grad=True, skip_flag=status[2:3])
+        self.last = dict(radii=b["radii"], dL_dmeans2D=b["g_m2d"], render=b["color"], depth=b["invd"], all_map=b["omap"])
+        return loss, status
 
     def _probe_capacity(self):
         """Longest tile list over a few eager (exact-path) renders -> bucket capacity."""
@@ -271,6 +390,7 @@ class GraphedTrainStep(TrainStep):
             opt.step_count = self._t0 + now            # every iteration up to `now` is applied, redone or in flight
             self._cap = 0                              # re-probe and re-capture with larger buckets
             self._graph = None
+            self._bufs = None
         return len(redo)
 
     def step(self, view_index=None):
@@ -303,6 +423,7 @@ class GraphedTrainStep(TrainStep):
         TrainStep._on_topology_change(self)
         self._graph = None      # sizes are graph constants: re-probe the bucket capacity and re-capture
         self._cap = 0
+        self._bufs = None
         self._loss = self._status = None
         self._derived_stale = False
 

@@ -343,6 +343,27 @@ def test_regularisers_match_the_reference_formulas():
         np.testing.assert_allclose(getattr(gb, n).detach().cpu().numpy(), getattr(ga, n).detach().cpu().numpy(), rtol=1e-3, atol=1e-5)   # 8 Adam steps amplify rounding
 
 
+@pytest.mark.parametrize("regs", [False, True])
+def test_graphed_train_step_autograd_body_matches_direct_body(regs):
+    """GraphedTrainStep(direct=False) captures the Python-autograd sequence, direct=True (default) the same kernels
+    called through the C ABI with gradients written straight into the flat buffer: identical trajectories."""
+    from curve_gaussian_amd.train_step import GraphedTrainStep
+    torch.manual_seed(0); ga, cams, gts = _train_fixture()
+    torch.manual_seed(0); gb, _, _ = _train_fixture()
+    sa = GraphedTrainStep(ga, cams, gts, seed=8, direct=False, regularisers=regs, densify_until_iter=6)
+    sb = GraphedTrainStep(gb, cams, gts, seed=8, direct=True, regularisers=regs, densify_until_iter=6)
+    for it in range(10):
+        if it == 3:
+            sa.reset_timestep = sb.reset_timestep = 1
+        la, lb = sa.step()[0], sb.step()[0]
+    sa.finish(); sb.finish()
+    np.testing.assert_allclose(float(lb), float(la), rtol=1e-4)
+    for n in ("_curve_points", "_width", "_opacity", "_mask"):
+        np.testing.assert_allclose(getattr(gb, n).detach().cpu().numpy(), getattr(ga, n).detach().cpu().numpy(),
+                                   rtol=1e-3, atol=1e-5, err_msg=n)
+    assert sb.last["radii"].shape[0] == gb._curve_points.shape[0] * 12 and torch.isfinite(sb.last["dL_dmeans2D"]).all()
+
+
 def test_graphed_train_step_crosses_the_mask_phase():
     """At densify_until_iter the iteration switches to the straight-through curve mask + mask loss (train.py:97,110-111);
     the graphed step re-captures once and keeps following the eager trajectory."""
