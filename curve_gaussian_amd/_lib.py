@@ -100,6 +100,27 @@ def require_gpu_tensor(t, name: str):
         raise CurveGSError(f"{name} must be a GPU tensor (got device {t.device}); libcurvegs has no CPU path")
 
 
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def device_guard(dev):
+    """``torch.cuda.device(dev)`` only when `dev` is not already the current device (the context manager costs ~8 us of
+    host time per op; the reference's shim has no device guard at all)."""
+    import torch
+    idx = dev.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(dev)
+
+
 def raw_stream(dev):
     """hipStream_t of torch's current stream on `dev` as an int (one C call; torch.cuda.current_stream() builds a
     Stream object and is ~10x slower)."""

@@ -43,7 +43,7 @@ class _Ext:
         L.require_gpu_tensor(means3D, "means3D")
         dev = means3D.device
         P, H, W = means3D.size(0), int(image_height), int(image_width)
-        with torch.cuda.device(dev):
+        with L.device_guard(dev):
             means3D = _f32c(means3D, "means3D")
             colors, opacity, scales, rotations = _f32c(colors, "colors"), _f32c(opacity, "opacity"), _f32c(scales, "scales"), _f32c(rotations, "rotations")
             cov3D_precomp, all_map, sh = _f32c(cov3D_precomp, "cov3D_precomp"), _f32c(all_map, "all_map"), _f32c(sh, "sh")
@@ -65,7 +65,7 @@ class _Ext:
 
             a_geom, a_bin, a_img = make_alloc("geom"), make_alloc("bin"), make_alloc("img")
             M = sh.size(1) if (sh is not None and sh.numel() != 0) else 0
-            stream = torch.cuda.current_stream(dev).cuda_stream
+            stream = L.raw_stream(dev)
             rendered = lib.cgs_rasterize_forward(
                 a_geom, None, a_bin, None, a_img, None, P, int(degree), int(M), L.ptr(background), W, H,
                 L.ptr(means3D), L.ptr(sh), L.ptr(colors), L.ptr(opacity), L.ptr(scales), float(scale_modifier),
@@ -136,7 +136,7 @@ class _Ext:
         dev = means3D.device
         P = means3D.size(0)
         H, W = dL_dout_color.size(1), dL_dout_color.size(2)
-        with torch.cuda.device(dev):
+        with L.device_guard(dev):
             means3D = _f32c(means3D, "means3D")
             colors, opacities, scales, rotations = _f32c(colors, "colors"), _f32c(opacities, "opacities"), _f32c(scales, "scales"), _f32c(rotations, "rotations")
             cov3D_precomp, all_maps, sh = _f32c(cov3D_precomp, "cov3D_precomp"), _f32c(all_maps, "all_maps"), _f32c(sh, "sh")
@@ -177,7 +177,7 @@ class _Ext:
                 dL_drotations.zero_()
             # reference shape [P,M,3]; only the first P*M floats are written (quirk 16)
             dL_dsh = torch.zeros((P, M, 3), **fopt) if M > 0 else torch.empty((P, 0, 3), **fopt)
-            stream = torch.cuda.current_stream(dev).cuda_stream
+            stream = L.raw_stream(dev)
             if P != 0:
                 rc = lib.cgs_rasterize_backward(
                     P, int(degree), int(M), int(R), L.ptr(background), W, H, L.ptr(means3D), L.ptr(sh), L.ptr(colors),
@@ -201,13 +201,13 @@ class _Ext:
         L.require_gpu_tensor(means3D, "means3D")
         dev = means3D.device
         P = means3D.size(0)
-        with torch.cuda.device(dev):
+        with L.device_guard(dev):
             means3D = _f32c(means3D, "means3D")
             present = torch.zeros((P,), dtype=torch.bool, device=dev)
             if P != 0:
                 rc = lib.cgs_mark_visible(P, L.ptr(means3D), L.ptr(_f32c(viewmatrix, "viewmatrix")),
                                           L.ptr(_f32c(projmatrix, "projmatrix")), L.ptr(present),
-                                          torch.cuda.current_stream(dev).cuda_stream)
+                                          L.raw_stream(dev))
                 L.check(rc, "cgs_mark_visible")
         return present
 

@@ -13,7 +13,7 @@ def fusedssim(C1, C2, img1, img2, train=True):
     L.require_gpu_tensor(img1, "img1")
     lib = L.load()
     dev = img1.device
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         img1 = img1.float().contiguous()
         img2 = img2.float().contiguous()
         B, CH, H, W = img1.shape
@@ -24,7 +24,7 @@ def fusedssim(C1, C2, img1, img2, train=True):
             dm_dmu1 = dm_ds1 = dm_ds12 = torch.empty(0)
         rc = lib.cgs_ssim_forward(B, CH, H, W, C.c_float(C1), C.c_float(C2), L.ptr(img1), L.ptr(img2), L.ptr(target),
                                   L.ptr(dm_dmu1), L.ptr(dm_ds1), L.ptr(dm_ds12),
-                                  torch.cuda.current_stream(dev).cuda_stream)
+                                  L.raw_stream(dev))
         L.check(rc, "cgs_ssim_forward")
     return target, dm_dmu1, dm_ds1, dm_ds12
 
@@ -33,7 +33,7 @@ def fusedssim_backward(C1, C2, img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_d
     L.require_gpu_tensor(img1, "img1")
     lib = L.load()
     dev = img1.device
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         img1 = img1.float().contiguous()
         img2 = img2.float().contiguous()
         dL_dmap = dL_dmap.float().contiguous()
@@ -41,7 +41,7 @@ def fusedssim_backward(C1, C2, img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_d
         out = torch.empty_like(img1)
         rc = lib.cgs_ssim_backward(B, CH, H, W, C.c_float(C1), C.c_float(C2), L.ptr(img1), L.ptr(img2), L.ptr(dL_dmap),
                                    L.ptr(dm_dmu1), L.ptr(dm_dsigma1_sq), L.ptr(dm_dsigma12), L.ptr(out),
-                                   torch.cuda.current_stream(dev).cuda_stream)
+                                   L.raw_stream(dev))
         L.check(rc, "cgs_ssim_backward")
     return out
 

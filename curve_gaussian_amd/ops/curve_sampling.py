@@ -54,7 +54,7 @@ def sample_coefficients(m: int, device) -> torch.Tensor:
 
 
 def _stream(dev):
-    return torch.cuda.current_stream(dev).cuda_stream
+    return L.raw_stream(dev)
 
 
 class _SampleCurves(torch.autograd.Function):
@@ -63,7 +63,7 @@ class _SampleCurves(torch.autograd.Function):
         L.require_gpu_tensor(curve_points, "curve_points")
         lib = L.load()
         dev = curve_points.device
-        with torch.cuda.device(dev):
+        with L.device_guard(dev):
             cp = curve_points.detach().float().contiguous()
             w = width.detach().float().contiguous()
             B = cp.shape[0]
@@ -88,7 +88,7 @@ class _SampleCurves(torch.autograd.Function):
         lib = L.load()
         dev = cp.device
         B = cp.shape[0]
-        with torch.cuda.device(dev):
+        with L.device_guard(dev):
             c = lambda t: None if t is None else t.float().contiguous()
             g_xyz, g_rot, g_scl = c(g_xyz), c(g_rot), c(g_scl)
             g_cp = torch.empty_like(cp)
@@ -113,7 +113,7 @@ class _SplatAttrs(torch.autograd.Function):
         L.require_gpu_tensor(rot_raw, "rotation")
         lib = L.load()
         dev = rot_raw.device
-        with torch.cuda.device(dev):
+        with L.device_guard(dev):
             c = lambda t: None if t is None else t.detach().float().contiguous()
             rot_raw, xyz, opacity_logit, scaling, mask_logit = c(rot_raw), c(xyz), c(opacity_logit), c(scaling), c(mask_logit)
             campos, viewmatrix = c(campos), c(viewmatrix)
@@ -144,7 +144,7 @@ class _SplatAttrs(torch.autograd.Function):
         m = ctx.m
         P = rot_raw.shape[0]
         B = P // m
-        with torch.cuda.device(dev):
+        with L.device_guard(dev):
             c = lambda t: None if t is None else t.float().contiguous()
             g_rot_n, g_opac, g_scl_out, g_all_map = c(g_rot_n), c(g_opac), c(g_scl_out), c(g_all_map)
             g_rot_raw = torch.empty_like(rot_raw)

@@ -36,14 +36,14 @@ class _EdgeAwareLoss(torch.autograd.Function):
         L.require_gpu_tensor(image, "image")
         lib = L.load()
         dev = image.device
-        with torch.cuda.device(dev):
+        with L.device_guard(dev):
             img = image.detach().float().contiguous()
             gt = gt_image.detach().float().contiguous()
             Cn, H, W = img.shape[-3], img.shape[-2], img.shape[-1]
             scratch = torch.empty(2, dtype=torch.float64, device=dev)
             grad = torch.empty_like(img)
             rc = lib.cgs_edge_aware_loss(Cn, H, W, L.ptr(img), L.ptr(gt), C.c_float(threshold), L.ptr(scratch),
-                                         L.ptr(grad), torch.cuda.current_stream(dev).cuda_stream)
+                                         L.ptr(grad), L.raw_stream(dev))
             L.check(rc, "cgs_edge_aware_loss")
             loss = (scratch[1] / float(Cn * H * W)).float()
         ctx.save_for_backward(grad)
@@ -91,13 +91,13 @@ class _PhotometricLoss(torch.autograd.Function):
         L.require_gpu_tensor(image, "image")
         lib = L.load()
         dev = image.device
-        with torch.cuda.device(dev):
+        with L.device_guard(dev):
             img = image.detach().float().contiguous()
             gt = gt_image.detach().float().contiguous()
             Cn, H, W = img.shape
             if Cn != 1:
                 raise L.CurveGSError("photometric_loss: the fused path renders 1 channel (got %d)" % Cn)
-            stream = torch.cuda.current_stream(dev).cuda_stream
+            stream = L.raw_stream(dev)
             if n_pos is None:
                 n_pos = _EdgeCountCache.get(gt, threshold, stream)
             key = (str(dev), H, W, stream)

@@ -47,12 +47,12 @@ class FlatAdam:
         """One Adam step over all groups; zero_grad=True also clears the flat gradient buffer in the same kernel."""
         self.step_count += 1
         lib = L.load()
-        with torch.cuda.device(self.device):
+        with L.device_guard(self.device):
             rc = lib.cgs_adam_step_flat(self.flat.numel(), L.ptr(self.flat), L.ptr(self.grads.flat), L.ptr(self.exp_avg),
                                         L.ptr(self.exp_avg_sq), self._segments(), len(self.param_groups),
                                         C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
                                         self.step_count, 1 if zero_grad else 0,
-                                        torch.cuda.current_stream(self.device).cuda_stream)
+                                        L.raw_stream(self.device))
         L.check(rc, "cgs_adam_step_flat")
 
     # ---- topology edits (scene/topology.py): per-curve tensors change their first dimension

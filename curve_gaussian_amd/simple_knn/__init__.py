@@ -10,14 +10,14 @@ class _Ext:
         L.require_gpu_tensor(points, "points")
         lib = L.load()
         dev = points.device
-        with torch.cuda.device(dev):
+        with L.device_guard(dev):
             pts = points.float().contiguous()
             P = pts.size(0)
             means = torch.full((P,), 0.0, dtype=torch.float32, device=dev)
             if P > 0:
                 ws = torch.empty((int(lib.cgs_knn_workspace_bytes(P)),), dtype=torch.uint8, device=dev)
                 rc = lib.cgs_knn_mean_dist2(P, L.ptr(pts), L.ptr(means), L.ptr(ws),
-                                            torch.cuda.current_stream(dev).cuda_stream)
+                                            L.raw_stream(dev))
                 L.check(rc, "cgs_knn_mean_dist2")
         return means
 
