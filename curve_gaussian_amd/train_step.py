@@ -181,10 +181,6 @@ class GraphedTrainStep(TrainStep):
             loss = loss + self.lambda_mask * torch.mean(torch.sigmoid(g._mask))
         if self.regularisers:   # sync-free torch ops; the opacity term is gated by a device scalar refreshed per step
             loss = loss + self._regulariser_terms(pkg["radii"], self._opa_gate)
-        if getattr(self, "_debug_keep", None) is not None:
-            import os
-            allk = dict(xyz=g._xyz, rot=g._rotation, scl=g._scaling, radii=pkg["radii"], img=pkg["render"], depth=pkg["depth"])
-            self._debug_keep.update({k: v for k, v in allk.items() if k in os.environ.get("CGS_DBG_KEEP", "").split(",")})
         loss.backward(gradient=unit_grad(loss.device))
         status = sink[0]
         g.optimizer.step_dev(zero_grad=True, skip_flag=status[2:3])
