@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true")
     ap.add_argument("--no-train-step", action="store_true")
-    ap.add_argument("--cpu-views", type=int, default=2)
+    ap.add_argument("--cpu-views", type=int, default=6)
     ap.add_argument("--streams", type=int, default=3,
                     help="view mode: independent views kept in flight per GPU (HIP streams); 1 = strictly serial views")
     ap.add_argument("--no-graph", action="store_true",
