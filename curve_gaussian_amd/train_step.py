@@ -126,11 +126,21 @@ class GraphedTrainStep(TrainStep):
     ``step()`` returns the graph's static loss tensor: it is overwritten by the next step (copy or ``float()`` it
     to keep a value).  Call ``finish()`` before reading the model from outside or editing its topology."""
 
-    def __init__(self, *args, cap_margin=1.5, direct=True, **kw):
+    def __init__(self, *args, cap_margin=1.5, direct=True, collectives=None, **kw):
         kw["fused"] = True
         super().__init__(*args, **kw)
-        if self.world != 1:
-            raise ValueError("GraphedTrainStep: view-parallel runs use TrainStep (the all-reduce is not captured)")
+        # View-parallel runs (world > 1; `collectives=True` forces the same code path on a single-rank group): the graph
+        # ends before the optimizer; the host then all-reduces the flat gradient buffer and the overflow flag (max) and
+        # launches the Adam kernel.  Overflow handling is made deterministic across ranks by looking at the flag of
+        # iteration k - 2 (blocking, long finished) at the start of iteration k, so every rank redoes the same iteration
+        # at the same point of its collective sequence.
+        self._collective = (self.world > 1) if collectives is None else bool(collectives)
+        if self._collective:
+            import torch.distributed as dist
+            if not (dist.is_available() and dist.is_initialized()):
+                raise ValueError("GraphedTrainStep: view-parallel mode needs an initialised process group")
+            if not direct:
+                raise ValueError("GraphedTrainStep: view-parallel mode uses the direct body")
         dev = self.g.device
         c0 = self.cams[0]
         for c in self.cams:
@@ -297,7 +307,8 @@ class GraphedTrainStep(TrainStep):
             loss = loss + self.lambda_mask * sg.mean()
             grads.view("mask").add_(sg * (1 - sg), alpha=self.lambda_mask / mask.numel())
         status = b["status"]
-        g.optimizer.step_dev(zero_grad=True, skip_flag=status[2:3])
+        if not self._collective:     # view-parallel: the all-reduce sits between the backward and the optimizer
+            g.optimizer.step_dev(zero_grad=True, skip_flag=status[2:3])
         self.last = dict(radii=b["radii"], dL_dmeans2D=b["g_m2d"], render=b["color"], depth=b["invd"], all_map=b["omap"])
         return loss, status
 
@@ -367,6 +378,11 @@ class GraphedTrainStep(TrainStep):
         redo = []
         keep = []
         for ev, slot, vi, it in self._inflight:
+            if self._collective and not block:
+                if it > self.iteration - 1:       # called before iteration += 1: entries of iteration <= k - 2 ...
+                    keep.append((ev, slot, vi, it))
+                    continue
+                ev.synchronize()                  # ... are examined by every rank at the same point (long finished)
             if block:
                 ev.synchronize()
             if ev.query():
@@ -405,6 +421,11 @@ class GraphedTrainStep(TrainStep):
         self._load_inputs(vi)
         g.optimizer.stage_step()
         self._graph.replay()
+        if self._collective:
+            import torch.distributed as dist
+            dist.all_reduce(g.optimizer.grads.flat)
+            dist.all_reduce(self._status[2:3], op=dist.ReduceOp.MAX)   # any rank overflowed -> every rank skips
+            g.optimizer.step_dev(zero_grad=True, skip_flag=self._status[2:3])
         self._derived_stale = True   # g._xyz/_rotation/_scaling now hold the values of BEFORE this step's update
         slot = self.iteration % 64
         self._flag_host[slot:slot + 1].copy_(self._status[2:3], non_blocking=True)

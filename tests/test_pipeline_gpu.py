@@ -382,3 +382,36 @@ def test_graphed_train_step_crosses_the_mask_phase():
         np.testing.assert_allclose(getattr(gb, n).detach().cpu().numpy(), getattr(ga, n).detach().cpu().numpy(),
                                    rtol=1e-3, atol=1e-5, err_msg=n)
     assert float((gb._mask.detach() - 1.0).abs().max()) > 0   # the mask logits did move in the mask phase
+
+
+def test_graphed_train_step_view_parallel_mode_single_rank_group():
+    """The view-parallel code path of GraphedTrainStep (graph without optimizer -> RCCL all-reduce of the flat gradients
+    and of the overflow flag -> Adam kernel; overflow handled with a fixed two-iteration lag so that all ranks agree)
+    exercised on a single-rank RCCL group: same trajectory as the eager step, with and without forced overflow."""
+    import torch.distributed as dist
+    from curve_gaussian_amd.train_step import GraphedTrainStep, TrainStep
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        torch.manual_seed(0); ga, cams, gts = _train_fixture()
+        torch.manual_seed(0); gb, _, _ = _train_fixture()
+        torch.manual_seed(0); gc, _, _ = _train_fixture()
+        ea = TrainStep(ga, cams, gts, seed=9)
+        gs = GraphedTrainStep(gb, cams, gts, seed=9, collectives=True)
+        tiny = GraphedTrainStep(gc, cams, gts, seed=9, collectives=True)
+        tiny._cap = 64
+        tiny._probe_capacity = lambda: 64
+        for _ in range(10):
+            ea.step(); gs.step(); tiny.step()
+        gs.finish(); tiny.finish()
+        assert gs.recaptures == 1 and tiny.recaptures > 1 and gc.optimizer.step_count == 10
+        for n in ("_curve_points", "_width", "_opacity"):
+            ref = getattr(ga, n).detach().cpu().numpy()
+            np.testing.assert_allclose(getattr(gb, n).detach().cpu().numpy(), ref, rtol=2e-4, atol=2e-6, err_msg=n)
+            np.testing.assert_allclose(getattr(gc, n).detach().cpu().numpy(), ref, rtol=2e-4, atol=2e-6, err_msg="overflow " + n)
+    finally:
+        if created:
+            dist.destroy_process_group()
