@@ -243,11 +243,14 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
         if (e != hipSuccess) set_error("reading num_rendered failed: %s", hipGetErrorString(e));
         return e == hipSuccess;
     };
+    // tile_count == NULL (bucket binning): the kernel does not count, so it can clear the histogram/cursors/status words
+    // itself; with counting, they are cleared by a separate launch first.  Either way it zeroes the gradient accumulators.
     auto preprocess = [&](uint32_t* tile_count) -> bool {
         launch_preprocess_fwd(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, geom.clamped,
                               cov3D_precomp, colors_precomp, render_geo ? all_map : nullptr, viewmatrix, projmatrix,
                               cam_pos, width, height, tan_fovx, tan_fovy, focal_x, focal_y, radii, geom.rec, geom.rgb,
-                              gx, gy, tile_count, antialiasing, cull);
+                              gx, gy, tile_count, antialiasing, cull, geom.grad_acc, img.tile_count,
+                              tile_count ? 0 : clear_bytes / sizeof(uint32_t));
         return check_launch("preprocess_fwd", debug, s);
     };
     auto render = [&](const uint32_t* point_list) -> bool {
@@ -266,10 +269,6 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
     if (cull && !debug && max_hint > 0) {
         const uint64_t cap = (((uint64_t)max_hint * 5 / 4 + 64) + 63) & ~63ull;
         if (cap <= bucket_cap_limit() && cap * (uint64_t)tiles < (1ull << 31)) {
-            if (zero_async(img.tile_count, clear_bytes, s) != hipSuccess) {
-                set_error("zero_async(tile histogram) failed");
-                return CGS_ERR_HIP;
-            }
             if (!preprocess(nullptr)) return CGS_ERR_HIP;
             preprocessed = true;
             char* bchunk = (char*)binning_alloc(binning_user, cgs_binning_bytes((int64_t)(cap * tiles)));
@@ -407,14 +406,10 @@ int cgs_rasterize_forward_static(void* geometry_buffer, void* binning_buffer, si
     BinState bin = bin_from_chunk(bchunk, (size_t)(cap * tiles));
     ImageState img = image_from_chunk(ichunk, npix, (size_t)tiles);
     const size_t clear_bytes = (size_t)((char*)(img.total + TOTAL_WORDS) - (char*)img.tile_count);
-    if (zero_async(img.tile_count, clear_bytes, s) != hipSuccess) {
-        set_error("zero_async(tile histogram) failed");
-        return CGS_ERR_HIP;
-    }
     launch_preprocess_fwd(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, geom.clamped,
                           cov3D_precomp, colors_precomp, render_geo ? all_map : nullptr, viewmatrix, projmatrix, cam_pos,
                           width, height, tan_fovx, tan_fovy, focal_x, focal_y, radii, geom.rec, geom.rgb, gx, gy, nullptr,
-                          antialiasing, 1);
+                          antialiasing, 1, geom.grad_acc, img.tile_count, clear_bytes / sizeof(uint32_t));
     launch_scatter_bucket(s, P, radii, geom.rec, gx, gy, img.tile_count, bin.keys, (uint32_t)cap, 1);
     if (render_fwd_can_sort((uint32_t)cap) && fuse_sort()) {
         launch_render_fwd_sorting(s, render_geo != 0, tiles, img.tile_count, bin.keys, (uint32_t)cap, img.ranges, img.total,
@@ -486,10 +481,7 @@ int cgs_rasterize_backward(int P, int D, int M, int64_t R, const float* backgrou
     BinState bin = bin_from_chunk(bchunk, (size_t)(R > 0 ? R : 1));
     ImageState img = image_from_chunk(ichunk, npix, (size_t)tiles);
 
-    if (zero_async(geom.grad_acc, (size_t)P * ACC_STRIDE * sizeof(float), s) != hipSuccess) {
-        set_error("zero_async(gradient accumulators) failed");
-        return CGS_ERR_HIP;
-    }
+    // geom.grad_acc is zero here: the forward's preprocess kernel cleared it and k_preprocess_bwd clears it after use
     if (R > 0) {
         const bool geo = render_geo && dL_dout_all_map;
         launch_render_bwd(s, geo, dL_dout_invdepth != nullptr, dL_dcolor != nullptr, tiles, img.ranges, bin.point_list,

@@ -12,14 +12,15 @@ void launch_preprocess_fwd(hipStream_t s, int P, int D, int M, const float* mean
                            const float* all_map, const float* viewmatrix, const float* projmatrix,
                            const float* cam_pos, int W, int H, float tan_fovx, float tan_fovy, float focal_x,
                            float focal_y, int* radii, SplatRec* rec, float* rgb, int grid_x, int grid_y,
-                           uint32_t* tile_count, int antialiasing, int cull);
+                           uint32_t* tile_count, int antialiasing, int cull, float* grad_acc, uint32_t* clear_words,
+                           size_t n_clear);
 void launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* viewmatrix, uint8_t* present);
 void launch_preprocess_bwd(hipStream_t s, int P, int D, int M, const float* means3D, const int* radii,
                            const float* shs, const uint8_t* clamped, const float* opacities, const float* scales,
                            const float* rotations, float scale_modifier, const float* cov3D_precomp,
                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, float focal_x,
                            float focal_y, float tan_fovx, float tan_fovy, int W, int H, const SplatRec* rec,
-                           const float* grad_acc, float* dL_dmean2D, float* dL_dconic, float* dL_dinvdepth,
+                           float* grad_acc, float* dL_dmean2D, float* dL_dconic, float* dL_dinvdepth,
                            float* dL_dopacity, float* dL_dmean3D, float* dL_dcolor, float* dL_dall_map,
                            float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int antialiasing);
 

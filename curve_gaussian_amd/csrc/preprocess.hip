@@ -104,8 +104,19 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(
     const float* __restrict__ all_map, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
     const float* __restrict__ cam_pos, int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y,
     int* __restrict__ radii, SplatRec* __restrict__ rec, float* __restrict__ rgb, int grid_x, int grid_y,
-    uint32_t* __restrict__ tile_count, int antialiasing, int cull) {
+    uint32_t* __restrict__ tile_count, int antialiasing, int cull, float* __restrict__ grad_acc,
+    uint32_t* __restrict__ clear_words, uint32_t n_clear) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    // Folded zero fills (each was a separate ~5 us launch): this splat's gradient accumulator record for the backward
+    // compositor (k_preprocess_bwd leaves it zero again), and -- bucket binning only, where this kernel does not count --
+    // the tile histogram / cursors / status words that the scatter kernel (next launch) accumulates into.
+    if (idx < P) {
+        float4* accp = reinterpret_cast<float4*>(grad_acc + (size_t)idx * ACC_STRIDE);
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < ACC_STRIDE / 4; k++) accp[k] = z;
+    }
+    for (uint32_t i = (uint32_t)(blockIdx.x * blockDim.x + threadIdx.x); i < n_clear; i += gridDim.x * blockDim.x) clear_words[i] = 0u;
     // radius 0 == "not processed further" (forward.cu:187-190)
     int out_radius = 0;
     uint2 rmin = make_uint2(0, 0), rmax = make_uint2(0, 0);
@@ -204,15 +215,21 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(
     const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
     const float* __restrict__ projmatrix, const float* __restrict__ cam_pos, float focal_x, float focal_y,
     float tan_fovx, float tan_fovy, int W, int H, const SplatRec* __restrict__ rec,
-    const float* __restrict__ grad_acc, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
+    float* __restrict__ grad_acc, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
     float* __restrict__ dL_dinvdepth, float* __restrict__ dL_dopacity, float* __restrict__ dL_dmean3D,
     float* __restrict__ dL_dcolor, float* __restrict__ dL_dall_map, float* __restrict__ dL_dcov3D,
     float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot, int antialiasing) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= P) return;
     // ---- finish the compositor's per-splat sums: raw moments -> dL/dmean2D (NDC-scaled), dL/dconic, dL/dopacity
-    const float4* accp = reinterpret_cast<const float4*>(grad_acc + (size_t)idx * ACC_STRIDE);
-    const float4 acc0 = accp[0], acc1 = accp[1];  // {Sg,Sx,Sy,Sxx} {Sxy,Syy,col,invd}
+    // The record is handed back zeroed (the forward zeroed it the first time): a second backward over the same forward
+    // state accumulates from zero again without a separate fill launch.
+    float4* accp = reinterpret_cast<float4*>(grad_acc + (size_t)idx * ACC_STRIDE);
+    const float4 acc0 = accp[0], acc1 = accp[1], acc2 = accp[2];  // {Sg,Sx,Sy,Sxx} {Sxy,Syy,col,invd} {all_map}
+    {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        accp[0] = z; accp[1] = z; accp[2] = z;
+    }
     const bool vis = radii[idx] > 0;
     float g2x = 0.f, g2y = 0.f, dcx = 0.f, dcy = 0.f, dcz = 0.f;
     float dopac = acc0.x;
@@ -229,7 +246,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(
     if (dL_dconic) reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(dcx, dcy, 0.f, dcz);
     if (dL_dcolor) dL_dcolor[idx] = acc1.z;
     if (dL_dinvdepth) dL_dinvdepth[idx] = acc1.w;
-    if (dL_dall_map) reinterpret_cast<float4*>(dL_dall_map)[idx] = accp[2];
+    if (dL_dall_map) reinterpret_cast<float4*>(dL_dall_map)[idx] = acc2;
     float3 dmean = make_float3(0.f, 0.f, 0.f);
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float3 dscale = make_float3(0.f, 0.f, 0.f);
@@ -379,12 +396,13 @@ void launch_preprocess_fwd(hipStream_t s, int P, int D, int M, const float* mean
                            const float* all_map, const float* viewmatrix, const float* projmatrix,
                            const float* cam_pos, int W, int H, float tan_fovx, float tan_fovy, float focal_x,
                            float focal_y, int* radii, SplatRec* rec, float* rgb, int grid_x, int grid_y,
-                           uint32_t* tile_count, int antialiasing, int cull) {
+                           uint32_t* tile_count, int antialiasing, int cull, float* grad_acc, uint32_t* clear_words,
+                           size_t n_clear) {
     ProfScope p("preprocess_fwd", s);
     hipLaunchKernelGGL(k_preprocess_fwd, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, means3D, scales,
                        scale_modifier, rotations, opacities, shs, clamped, cov3D_precomp, colors_precomp, all_map,
                        viewmatrix, projmatrix, cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, radii, rec, rgb,
-                       grid_x, grid_y, tile_count, antialiasing, cull);
+                       grid_x, grid_y, tile_count, antialiasing, cull, grad_acc, clear_words, (uint32_t)n_clear);
 }
 void launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* viewmatrix, uint8_t* present) {
     ProfScope p("mark_visible", s);
@@ -395,7 +413,7 @@ void launch_preprocess_bwd(hipStream_t s, int P, int D, int M, const float* mean
                            const float* rotations, float scale_modifier, const float* cov3D_precomp,
                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, float focal_x,
                            float focal_y, float tan_fovx, float tan_fovy, int W, int H, const SplatRec* rec,
-                           const float* grad_acc, float* dL_dmean2D, float* dL_dconic, float* dL_dinvdepth,
+                           float* grad_acc, float* dL_dmean2D, float* dL_dconic, float* dL_dinvdepth,
                            float* dL_dopacity, float* dL_dmean3D, float* dL_dcolor, float* dL_dall_map,
                            float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int antialiasing) {
     ProfScope p("preprocess_bwd", s);
