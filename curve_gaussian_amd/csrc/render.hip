@@ -21,6 +21,28 @@ namespace cgs {
 
 constexpr int BATCH = 256;
 constexpr float ALPHA_MIN = 1.0f / 255.0f;
+// [x > t] as a 0/1 float with one instruction (v_fma_f32 ... clamp): scaling by 2^100 is exact and any non-zero difference
+// of two floats of these magnitudes times 2^100 exceeds 1, so the saturated product is exactly the step function.
+// [x >= thr] is [x > pred(thr)], pred = the next float below.
+// The constants live in VGPRs on purpose (opaque to the compiler): an fma with an SGPR or inline-constant operand
+// issues in ~4 cycles, with three VGPRs in ~2.9 (scratch/enc_probe.hip).
+__device__ __forceinline__ float sat01(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 1.f); }  // folds into "clamp"
+struct StepConsts {
+    float big, cA;       // [alpha >= 1/255] = sat(alpha * 2^100 - pred(1/255) * 2^100)
+    float nbig, one;     // [!(p2 > 0)]      = sat(1 - p2 * 2^127): any positive normal float times 2^127 is >= 2
+    float nbig100, cT;   // [T < 1e-4]       = sat(1e-4 * 2^100 - T * 2^100)
+};
+__device__ __forceinline__ StepConsts step_consts() {
+    StepConsts k;
+    k.big = 0x1p100f;
+    k.cA = -__uint_as_float(0x3b808080u) * 0x1p100f;   // pred(1/255f = 0x3b808081)
+    k.nbig = -0x1p127f;
+    k.one = 1.0f;
+    k.nbig100 = -0x1p100f;
+    k.cT = 0.0001f * 0x1p100f;                          // T < 1e-4  <=>  (1e-4 - T) * 2^100 >= 1
+    asm volatile("" : "+v"(k.big), "+v"(k.cA), "+v"(k.nbig), "+v"(k.one), "+v"(k.nbig100), "+v"(k.cT));
+    return k;
+}
 #ifndef CGS_SLOTS
 #define CGS_SLOTS 8
 #endif
@@ -213,12 +235,15 @@ __global__ void __launch_bounds__(256) k_render_fwd(const uint2* __restrict__ ra
     }
     const int total = (int)(range.y - range.x);
     const int rounds = (total + BATCH - 1) / BATCH;
-    // Per-lane state, branch-free: Tw is the WORKING transmittance -- equal to T while the pixel is live and forced to
-    // 0 once it terminates (reference: done = true), so a dead pixel blends nothing and can never pass the T test
-    // again; T keeps the value the reference writes to final_T.  No per-lane boolean survives an iteration, which
-    // keeps the loop free of exec-mask / SGPR-pair bookkeeping (the scalar unit was the bottleneck of the first
-    // version: ~30 SALU per splat vs ~9 now).
-    float T = 1.0f;
+    // Per-lane state, branch- and predicate-free: Tw is the WORKING transmittance -- equal to T while the pixel is live
+    // and forced to 0 once it terminates (reference: done = true), so a dead pixel blends nothing and can never pass the
+    // T test again; T_dead catches the transmittance at termination (what the reference leaves in final_T).  The
+    // reference's three tests are evaluated as 0/1 floats (step_gt) and multiplied in: v_cmp / v_cndmask issue at half
+    // the rate of fma / mul on CDNA4 (4 vs 2 cycles per wave instruction, scratch/valu_probe.hip) and the first
+    // version's 3 compares + 5 selects were 36 of its ~78 issue cycles per pair; no exec-mask or SGPR-pair bookkeeping
+    // either (the scalar unit was the bottleneck before that: ~30 SALU per splat vs ~9).
+    const StepConsts k = step_consts();
+    float T_dead = 0.0f;
     float Tw = g.inside ? 1.0f : 0.0f;
     uint32_t last_contributor = 0;
     float C = 0.f, Dacc = 0.f;
@@ -261,21 +286,28 @@ __global__ void __launch_bounds__(256) k_render_fwd(const uint2* __restrict__ ra
                 const float dx = a.x - pixfx, dy = a.y - pixfy;
                 const float p2 = dx * (a.z * dx + a.w * dy) + b.x * dy * dy;
                 const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(p2));
-                const float test_T = Tw - Tw * alpha;
                 // reference: power > 0 -> skip, alpha < 1/255 -> skip (both leave the pixel untouched)
-                const bool hit = !(alpha < ALPHA_MIN) && !(p2 > 0.0f);
-                const bool blend = hit && !(test_T < 0.0001f);  // a dead pixel has Tw == test_T == 0: never blends
-                const float w = blend ? alpha * Tw : 0.f;
-                C += b.z * w;
-                Dacc += b.w * w;
+                const float hA = sat01(fmaf(alpha, k.big, k.cA));         // [alpha >= 1/255]
+                const float hB = sat01(fmaf(p2, k.nbig, k.one));          // [!(p2 > 0)]
+                const float a_eff = (alpha * hA) * hB;                    // alpha if hit, else 0
+                const float test_T = fmaf(-Tw, a_eff, Tw);
+                // stop = 0: the pixel is live and stays above 1e-4 (then this splat is blended if it hit); stop = 1: the
+                // pixel is dead (Tw == 0) or this hit would take T below 1e-4 -- it terminates, the splat is NOT blended
+                const float stop = sat01(fmaf(test_T, k.nbig100, k.cT));  // [test_T < 1e-4]
+                const float aT = a_eff * Tw;
+                const float w = fmaf(-aT, stop, aT);
+                C = fmaf(b.z, w, C);
+                Dacc = fmaf(b.w, w, Dacc);
                 if (GEO) {
                     const float4 cc = s_c[j];
-                    A0 += cc.x * w; A1 += cc.y * w; A2 += cc.z * w; A3 += cc.w * w;
+                    A0 = fmaf(cc.x, w, A0); A1 = fmaf(cc.y, w, A1); A2 = fmaf(cc.z, w, A2); A3 = fmaf(cc.w, w, A3);
                 }
-                T = blend ? test_T : T;
-                last_contributor = blend ? base + (uint32_t)j : last_contributor;  // 1-based list position
-                // hit but not blended: T would drop below 1e-4 -> the pixel terminates and the splat is NOT blended
-                Tw = blend ? test_T : (hit ? 0.f : Tw);
+                T_dead = fmaf(stop, Tw, T_dead);        // += Tw on the terminating splat (0 while live, Tw == 0 after)
+                Tw = fmaf(-test_T, stop, test_T);
+                // 1-based list position of the last blended splat: w > 0 exactly when this one was blended, its bit
+                // pattern then exceeds any list position, and positions only grow -> the median of the three
+                const uint32_t pos1 = base + (uint32_t)j, wb = __float_as_uint(w);
+                last_contributor = max(min(last_contributor, pos1), min(max(last_contributor, pos1), wb));  // v_med3_u32
             }
             if (ballot64(Tw > 0.f) == 0ull) {  // checked once per 64-splat chunk
                 wave_done = true;
@@ -285,6 +317,7 @@ __global__ void __launch_bounds__(256) k_render_fwd(const uint2* __restrict__ ra
     }
     if (g.inside) {
         const size_t HW = (size_t)H * W;
+        const float T = Tw + T_dead;   // live: Tw (T_dead == 0); terminated: T_dead (Tw == 0)
         final_T[g.pix_id] = T;
         n_contrib[g.pix_id] = last_contributor;
         out_color[g.pix_id] = C + T * bg_color[0];
@@ -317,6 +350,24 @@ __device__ __forceinline__ float rows_sum(float v) {
     return __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
 }
 
+// Row sums of FOUR values at once: returns, in row r (r = lane >> 4), the sum over the four rows of the r-th argument
+// (column-wise).  v_permlane16_swap(X, Y) leaves X = [X0 Y0 X2 Y2], Y = [X1 Y1 X3 Y3]; v_permlane32_swap(X, Y) leaves
+// X = [Xlo Ylo], Y = [Xhi Yhi].
+__device__ __forceinline__ float rows_pair16(float a, float b) {  // -> [a0+a1, b0+b1, a2+a3, b2+b3]
+    auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+}
+__device__ __forceinline__ float rows_sum4(float a, float b, float c, float d) {
+    const float ab = rows_pair16(a, b), cd = rows_pair16(c, d);
+    auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(ab), __float_as_uint(cd), false, false);
+    return __uint_as_float(s[0]) + __uint_as_float(s[1]);   // [a, b, c, d]
+}
+__device__ __forceinline__ float rows_sum2(float a, float b) {     // -> [a, b, a, b]
+    const float ab = rows_pair16(a, b);
+    auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(ab), __float_as_uint(ab), false, false);
+    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+}
+
 // Per (pixel, splat) pair the backward needs, with g := G * dL/dalpha, the seven sums
 //   Sg = sum g, Sx = sum g dx, Sy = sum g dy, Sxx = sum g dx dx, Sxy = sum g dx dy, Syy = sum g dy dy, Sc = sum alpha T dL/dC
 // from which (reference backward.cu:655-672, linear in the sums):
@@ -335,7 +386,6 @@ __global__ void __launch_bounds__(256) k_render_bwd(
     __shared__ uint32_t s_id[BATCH];
     __shared__ float s_t[4][SLOTS][16];    // per wave: slot sums laid out [slot][field] for the transposed atomic flush
     __shared__ float s_g[4][SLOTS][SLOT_STRIDE];  // per wave: g = G dL/dalpha of the last <=16 accepted splats x 64 pixels
-    __shared__ uint32_t s_slotj[4][SLOTS];        // staged index of each slot
     __shared__ uint64_t s_qmask[4][4];
     const TileGeom g = tile_geom(W, H, grid_x);
     const int lane = g.lane;
@@ -403,6 +453,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(
         // the 16 pixels of quadrant rows 2q, 2q+1 and accumulates the six moments of g there with plain FMAs -- no
         // 64-lane reduction per field; a 4-way cross-row sum (v_permlane swaps) finishes it.
         int nslot = 0;
+        int slot_j = 0;   // lane s: staged index of the splat parked in slot s (v_writelane per pair, one bpermute per flush)
         float t_c = 0.f, t_invd = 0.f, t_m0 = 0.f, t_m1 = 0.f, t_m2 = 0.f, t_m3 = 0.f;  // extras: DPP-reduced, column = slot
         auto flush_slots = [&](int n) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -411,43 +462,62 @@ __global__ void __launch_bounds__(256) k_render_bwd(
             constexpr int QG = 64 / SLOTS;        // lane groups per slot (4 or 8)
             constexpr int RPL = 8 / QG;           // quadrant rows per lane (2 or 1)
             const int sl = lane & (SLOTS - 1), q = lane / SLOTS;
-            const int j = (int)s_slotj[g.wave][sl < n ? sl : 0];
+            const int j = __builtin_amdgcn_ds_bpermute(4 * (sl < n ? sl : 0), slot_j);
             const float4 sa = s_a[j];
             const float dx0 = sa.x - (float)(g.tx * TILE + ((g.wave & 1) << 3));             // minus column c
             const float dy0 = sa.y - (float)(g.ty * TILE + ((g.wave >> 1) << 3) + RPL * q);  // minus row r
-            float Sg = 0.f, Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f;
-            float dxc[8], dxc2[8];
-#pragma unroll
-            for (int c = 0; c < 8; c++) { dxc[c] = dx0 - (float)c; dxc2[c] = dxc[c] * dxc[c]; }
+            // Moments of the row's 8 values about the row's first pixel (weights 0..7 and 0,1,4,..49 are instruction
+            // constants), then shifted to the splat centre: sum g (d-c) = d M0 - M1, sum g (d-c)^2 = d (d M0 - 2 M1) + M2.
+            // 19 + 3 instructions per row instead of 16 (the d-c, (d-c)^2 tables) + 24.
+            float Sg, Sx, Sy, Sxx, Sxy, Syy;
             const float* gp = &s_g[g.wave][sl][8 * RPL * q];
 #pragma unroll
             for (int r = 0; r < RPL; r++) {
                 const float dyr = dy0 - (float)r;
-                float R = 0.f, Rx = 0.f, Rxx = 0.f;
+                float M0 = gp[8 * r], M1 = gp[8 * r + 1], M2 = M1;
+                M0 += M1;
 #pragma unroll
-                for (int c = 0; c < 8; c++) {
+                for (int c = 2; c < 8; c++) {
                     const float gv = gp[8 * r + c];
-                    R += gv; Rx += gv * dxc[c]; Rxx += gv * dxc2[c];
+                    M0 += gv; M1 = fmaf(gv, (float)c, M1); M2 = fmaf(gv, (float)(c * c), M2);
                 }
-                Sg += R; Sx += Rx; Sxx += Rxx;
-                Sy += dyr * R; Sxy += dyr * Rx; Syy += (dyr * dyr) * R;
+                const float Rx = fmaf(dx0, M0, -M1);
+                const float Rxx = fmaf(dx0, Rx - M1, M2);
+                if (r == 0) {
+                    Sg = M0; Sx = Rx; Sxx = Rxx;
+                    Sy = dyr * M0; Sxy = dyr * Rx; Syy = (dyr * dyr) * M0;
+                } else {
+                    Sg += M0; Sx += Rx; Sxx += Rxx;
+                    Sy = fmaf(dyr, M0, Sy); Sxy = fmaf(dyr, Rx, Sxy); Syy = fmaf(dyr * dyr, M0, Syy);
+                }
             }
             if (SLOTS == 8) {  // lanes l and l^8 hold the two half-row groups of the same slot: fold them first
                 Sg += dpp_row_ror8(Sg); Sx += dpp_row_ror8(Sx); Sy += dpp_row_ror8(Sy);
                 Sxx += dpp_row_ror8(Sxx); Sxy += dpp_row_ror8(Sxy); Syy += dpp_row_ror8(Syy);
             }
-            Sg = rows_sum(Sg); Sx = rows_sum(Sx); Sy = rows_sum(Sy);
-            Sxx = rows_sum(Sxx); Sxy = rows_sum(Sxy); Syy = rows_sum(Syy);
+            // Sum over the four 16-lane rows, TRANSPOSING on the way: one v_permlane16_swap + add halves the rows of two
+            // quantities at once, one v_permlane32_swap + add finishes four -- row r of U ends up holding field r
+            // (Sg, Sx, Sy, Sxx) and rows 0/1 of V fields 4/5 (Sxy, Syy): 5 swaps + 5 adds for the six moments instead
+            // of 12 + 12 (+ the register copies a swap of a value with itself needs).
+            const float U = rows_sum4(Sg, Sx, Sy, Sxx);
+            const float V = rows_sum2(Sxy, Syy);
             if (COLG) t_c = rows_sum(t_c);
             if (INVD) t_invd = rows_sum(t_invd);
             if (GEO) { t_m0 = rows_sum(t_m0); t_m1 = rows_sum(t_m1); t_m2 = rows_sum(t_m2); t_m3 = rows_sum(t_m3); }
-            // Transposed flush: lanes 0..n-1 hold the sums of slot `lane`; lay them out [slot][field] in LDS and let
-            // lane (slot = lane >> 3, field = lane & 7) issue the global f32 atomic, so the 6-8 atomics of one splat
-            // hit 8 consecutive floats of its 64-byte accumulator record and coalesce into ONE L2 request
-            // (measured 7x the rate of one-field-per-instruction; scratch/xcc_probe.hip).
+            // Transposed flush: the sums are laid out [slot][field] in LDS and lane (slot = lane >> 3, field = lane & 7)
+            // issues the global f32 atomic, so the 6-8 atomics of one splat hit 8 consecutive floats of its 64-byte
+            // accumulator record and coalesce into ONE L2 request (measured 7x the rate of one-field-per-instruction;
+            // scratch/xcc_probe.hip).
+            {
+                const int row = lane >> 4;
+                if ((lane & 15) < SLOTS && sl < n) {
+                    float* tp = &s_t[g.wave][sl][0];
+                    tp[row] = U;
+                    if (row < 2) tp[4 + row] = V;
+                }
+            }
             if (lane < n) {
                 float* tp = &s_t[g.wave][lane][0];
-                tp[0] = Sg; tp[1] = Sx; tp[2] = Sy; tp[3] = Sxx; tp[4] = Sxy; tp[5] = Syy;
                 tp[ACC_COL] = COLG ? t_c : 0.f;
                 tp[ACC_INVD] = INVD ? t_invd : 0.f;
                 if (GEO) { tp[ACC_MAP + 0] = t_m0; tp[ACC_MAP + 1] = t_m1; tp[ACC_MAP + 2] = t_m2; tp[ACC_MAP + 3] = t_m3; }
@@ -530,7 +600,9 @@ __global__ void __launch_bounds__(256) k_render_bwd(
                     v_g = G * dL_dalpha;
                 }
                 s_g[g.wave][nslot][lane] = v_g;
-                if (lane == 0) s_slotj[g.wave][nslot] = (uint32_t)j;
+                // (no clang builtin for v_writelane; gfx9 allows one SGPR per VALU instruction, so the lane select goes
+                // through m0 -- nothing else in this kernel uses m0, and clang rejects it as a clobber: "reserved")
+                asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(slot_j) : "s"(j), "s"(nslot));
                 if (COLG || INVD || GEO) {
                     const bool mine = col == nslot;
                     if (COLG) { v_c = row16_sum(v_c); t_c = mine ? v_c : t_c; }
