@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true",
                     help="view mode: launch every view eagerly (Python autograd + ctypes) instead of replaying one "
                          "captured hipGraph per stream")
+    ap.add_argument("--no-pingpong", action="store_true",
+                    help="view mode: one set of per-stream gradient buffers (the streams drain at every step boundary) "
+                         "instead of two used by alternate steps")
     ap.add_argument("--views-per-step", type=int, default=8,
                     help="view mode: views per rank whose gradients are summed before the all-reduce (one optimizer "
                          "step's view batch per rank)")
@@ -175,8 +178,16 @@ def main():
     G = max(1, args.views_per_step) if args.mode == "view" else 1
     # every stream accumulates into its own flat buffer through its own leaf aliases (a shared .grad would make
     # autograd funnel all accumulation through one stream and serialise the views); slot 0 is the exchanged buffer
-    stream_flats = [flat_grads] + [torch.zeros_like(flat_grads) for _ in range(max(args.streams, 1) - 1)]
-    stream_leaves = [make_leaves(f) for f in stream_flats]
+    # Two such sets, used by alternate steps: the streams start step s+1 (other set) while the main stream is still
+    # summing / all-reducing step s, so neither the per-step reduction nor the collective drains the view pipeline;
+    # a set is reused at step s+2, ordered after its reduction by an event.  (--no-pingpong: one set, join per step.)
+    n_sets = 2 if (args.mode == "view" and args.streams > 1 and not args.no_pingpong) else 1
+    flat_sets = [[flat_grads if (q == 0 and i == 0) else torch.zeros_like(flat_grads)
+                  for i in range(max(args.streams, 1))] for q in range(n_sets)]
+    leaf_sets = [[make_leaves(f) for f in flats] for flats in flat_sets]
+    stream_flats, stream_leaves = flat_sets[0], leaf_sets[0]
+    reduced = [None] * n_sets      # event: this set's gradients have been reduced (it may be zeroed and refilled)
+    step_no = [0]
 
     # ---- hipGraph mode: one captured per-view pipeline per stream (sync-free forward with fixed-capacity buckets),
     # replayed for any view after a 140-byte camera copy; the host cost per view drops from ~0.4 ms to ~0.02 ms
@@ -197,32 +208,33 @@ def main():
                 raise RuntimeError(f'tile lists of {longest} entries exceed the bucket limit')
             packs = {id(c): StaticCamera.packed(c) for c in my_cams}
             overflow_acc = torch.zeros(1, dtype=torch.int32, device=dev)
-            view_graphs = []
-            for si in range(vstreams.n):
-                scam = StaticCamera(my_cams[0], dev)
-                scam.load(packs[id(my_cams[0])])
-                sink = []
+            view_graphs = []      # [set][stream] -> (graph, its static camera, its stream)
+            for q in range(n_sets):
+                view_graphs.append([])
+                for si in range(vstreams.n):
+                    scam = StaticCamera(my_cams[0], dev)
+                    scam.load(packs[id(my_cams[0])])
+                    sink = []
 
-                def body(scam=scam, si=si, sink=sink):
-                    del sink[:]
-                    step_view(scam, stream_leaves[si], False, cap, sink)
-                    overflow_acc.add_(sink[0][2:3])   # sticky bucket-overflow flag, checked after the timed region
+                    def body(scam=scam, leaves=leaf_sets[q][si], sink=sink):
+                        del sink[:]
+                        step_view(scam, leaves, False, cap, sink)
+                        overflow_acc.add_(sink[0][2:3])   # sticky bucket-overflow flag, checked after the timed region
 
-                st = vstreams.streams[si] if vstreams.streams else torch.cuda.Stream()
-                for f in stream_flats:
+                    st = vstreams.streams[si] if vstreams.streams else torch.cuda.Stream()
+                    graph, _ = capture_graph(body, st)
+                    view_graphs[q].append((graph, scam, st))
+            for flats in flat_sets:
+                for f in flats:
                     f.zero_()
-                graph, _ = capture_graph(body, st)
-                view_graphs.append((graph, scam, st))
-            for f in stream_flats:
-                f.zero_()
             overflow_acc.zero_()
             torch.cuda.synchronize()
         except Exception as e:   # capture is an optimisation: fall back to eager launches
             print(f"bench: hipGraph capture unavailable ({e}); using eager launches", file=sys.stderr)
             view_graphs = None
 
-    def replay_view(j, cam):
-        graph, scam, st = view_graphs[j % min(len(view_graphs), vstreams.n)]
+    def replay_view(j, cam, q=0):
+        graph, scam, st = view_graphs[q][j % min(len(view_graphs[q]), vstreams.n)]
         if vstreams.streams:
             with torch.cuda.stream(st):
                 scam.load(packs[id(cam)])
@@ -236,19 +248,35 @@ def main():
             if args.mode == "raster":
                 step_raster(view_list[g0], collect)
                 continue
-            for f in stream_flats[:vstreams.n]:
-                f.zero_()
-            vstreams.fork()
+            q = step_no[0] % n_sets if vstreams.streams else 0
+            step_no[0] += 1
+            flats, leaves = flat_sets[q], leaf_sets[q]
+            cur = torch.cuda.current_stream()
+            if n_sets == 1 or not vstreams.streams:
+                for f in flats[:vstreams.n]:
+                    f.zero_()
+                vstreams.fork()
+            else:   # each stream clears its own buffer of this set, once the set's previous use has been reduced
+                for i, st in enumerate(vstreams.streams):
+                    if reduced[q] is not None:
+                        st.wait_event(reduced[q])
+                    else:
+                        st.wait_stream(cur)
+                    with torch.cuda.stream(st):
+                        flats[i].zero_()
             for j, cam in enumerate(view_list[g0:g0 + G]):
                 if use_graphs[0] and not collect:
-                    replay_view(j, cam)
+                    replay_view(j, cam, q)
                 else:
-                    vstreams.run(j, step_view, cam, stream_leaves[j % vstreams.n], collect)
-            vstreams.join()
-            for f in stream_flats[1:vstreams.n]:
-                flat_grads.add_(f)
+                    vstreams.run(j, step_view, cam, leaves[j % vstreams.n], collect)
+            vstreams.join()     # (events only: the main stream waits, the view streams run on into the next step)
+            for f in flats[1:vstreams.n]:
+                flats[0].add_(f)
             if dist is not None:
-                dist.all_reduce(flat_grads)
+                dist.all_reduce(flats[0])
+            if n_sets > 1 and vstreams.streams:
+                reduced[q] = torch.cuda.Event()
+                reduced[q].record(cur)
 
     def barrier():
         if dist is not None:
@@ -281,6 +309,25 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+
+    # the step's summed gradient under the timed schedule (streams, graphs, double-buffered sets) against the same views
+    # run one at a time, eagerly, on one stream: the overlap machinery must not change what is computed
+    grad_check = None
+    if args.mode == "view" and (vstreams.n > 1 or use_graphs[0]) and dist is None:
+        barrier()
+        for _ in range(3):     # several consecutive steps: both sets, and a reuse of the first
+            run_views(my_cams[:G])
+        barrier()
+        got = flat_sets[(step_no[0] - 1) % n_sets if vstreams.streams else 0][0].clone()
+        keep_s, keep_u = vstreams, use_graphs[0]
+        vstreams, use_graphs[0] = ViewStreams(1), False
+        run_views(my_cams[:G])
+        barrier()
+        ref = flat_sets[0][0].clone()
+        vstreams, use_graphs[0] = keep_s, keep_u
+        grad_check = float((got - ref).norm() / ref.norm().clamp_min(1e-30))
+        if not grad_check < 1e-3:
+            raise RuntimeError(f"bench: overlapped schedule changed the step gradient (relative L2 error {grad_check:.3e})")
 
     # the reference's schedule for comparison: one view at a time, one stream (latency of a single view's hot path)
     serial_ms = serial_graph_ms = None
@@ -345,8 +392,12 @@ def main():
                    "instances_per_view_R": round(R_mean, 1), "visible_per_view": round(vis_mean, 1),
                    "views_per_rank": K, "views_per_step_per_rank": G, "views_in_flight_per_gpu": vstreams.n,
                    "launch": "hipGraph replay per view" if use_graphs[0] else "eager",
+                   "step_boundary": "double-buffered gradient sets (reduction/all-reduce of step s overlaps the views of "
+                                    "step s+1)" if n_sets > 1 else "join per step",
                    "parallelism": f"view-parallel x{world}"},
     }
+    if grad_check is not None:
+        out["step_gradient_rel_l2_vs_serial_eager"] = float(f"{grad_check:.3e}")
     if serial_ms is not None:
         out["serial_view_ms"] = round(serial_ms, 4)   # one view in flight, eager launches, all-reduce after every view
         if serial_graph_ms is not None:

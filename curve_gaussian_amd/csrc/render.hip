@@ -157,11 +157,17 @@ __global__ void __launch_bounds__(256) k_render_fwd(const uint2* __restrict__ ra
                                                     uint32_t* __restrict__ n_contrib, const float* __restrict__ bg_color,
                                                     float* __restrict__ out_color, float* __restrict__ out_invdepth,
                                                     float* __restrict__ out_all_map, BucketSort bs) {
-    __shared__ float4 s_a[BATCH];
-    __shared__ float4 s_b[BATCH];
-    __shared__ float4 s_c[GEO ? BATCH : 1];
+    __shared__ float4 s_a[BATCH + 1];   // entry BATCH: all zeros (opacity 0), the partner of an odd tail
+    __shared__ float4 s_b[BATCH + 1];
+    __shared__ float4 s_c[GEO ? BATCH + 1 : 1];
     __shared__ uint64_t s_qmask[4][4];  // [quadrant][64-splat chunk]
     __shared__ uint32_t s_ord[SORT ? RANK_MAX + RANK_U : 1];  // depths -> claim array -> ordered splat indices
+    if (threadIdx.x == 0) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_a[BATCH] = z;
+        s_b[BATCH] = z;
+        if (GEO) s_c[GEO ? BATCH : 0] = z;
+    }
     const TileGeom g = tile_geom(W, H, grid_x);
     const float pixfx = (float)g.px, pixfy = (float)g.py;
     const float X0 = (float)(g.tx * TILE), Y0 = (float)(g.ty * TILE);
@@ -274,40 +280,57 @@ __global__ void __launch_bounds__(256) k_render_fwd(const uint2* __restrict__ ra
         __syncthreads();
         if (wave_done) continue;
         const uint32_t base = (uint32_t)(i * BATCH) + 1u;
+        // Two splats per trip: everything up to a_eff (loads, quadratic form, exp, the two skip tests) is independent of
+        // the pixel's state, only the three-fma transmittance update is sequential -- the loop is bound by the latency of
+        // one wave's dependent chain (instruction-count reductions alone did not move it), so the second splat's chain
+        // runs in the shadow of the first.  An odd tail pairs with the all-zero entry BATCH (alpha = 0: never a hit).
+        struct Eval { float a_eff; float col, invd; float4 cc; uint32_t pos1; };
+        auto eval = [&](int j) {
+            Eval e;
+            const float4 a = s_a[j];
+            const float4 b = s_b[j];
+            const float dx = a.x - pixfx, dy = a.y - pixfy;
+            const float p2 = dx * (a.z * dx + a.w * dy) + b.x * dy * dy;
+            const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(p2));
+            // reference: power > 0 -> skip, alpha < 1/255 -> skip (both leave the pixel untouched)
+            const float hA = sat01(fmaf(alpha, k.big, k.cA));         // [alpha >= 1/255]
+            const float hB = sat01(fmaf(p2, k.nbig, k.one));          // [!(p2 > 0)]
+            e.a_eff = (alpha * hA) * hB;                              // alpha if hit, else 0
+            e.col = b.z;
+            e.invd = b.w;
+            if (GEO) e.cc = s_c[j];
+            e.pos1 = base + (uint32_t)j;
+            return e;
+        };
+        auto blend = [&](const Eval& e) {
+            const float test_T = fmaf(-Tw, e.a_eff, Tw);
+            // stop = 0: the pixel is live and stays above 1e-4 (then this splat is blended if it hit); stop = 1: the
+            // pixel is dead (Tw == 0) or this hit would take T below 1e-4 -- it terminates, the splat is NOT blended
+            const float stop = sat01(fmaf(test_T, k.nbig100, k.cT));  // [test_T < 1e-4]
+            const float aT = e.a_eff * Tw;
+            const float w = fmaf(-aT, stop, aT);
+            C = fmaf(e.col, w, C);
+            Dacc = fmaf(e.invd, w, Dacc);
+            if (GEO) { A0 = fmaf(e.cc.x, w, A0); A1 = fmaf(e.cc.y, w, A1); A2 = fmaf(e.cc.z, w, A2); A3 = fmaf(e.cc.w, w, A3); }
+            T_dead = fmaf(stop, Tw, T_dead);        // += Tw on the terminating splat (0 while live, Tw == 0 after)
+            Tw = fmaf(-test_T, stop, test_T);
+            // 1-based list position of the last blended splat: w > 0 exactly when this one was blended, its bit
+            // pattern then exceeds any list position, and positions only grow -> the median of the three
+            const uint32_t wb = __float_as_uint(w);
+            last_contributor = max(min(last_contributor, e.pos1), min(max(last_contributor, e.pos1), wb));  // v_med3_u32
+        };
 #pragma unroll 1
         for (int c = 0; c < 4; c++) {
             uint64_t m = uniform64(s_qmask[g.wave][c]);
             while (m) {
-                const int bit = __builtin_ctzll(m);
+                const int j0 = c * 64 + __builtin_ctzll(m);
                 m &= m - 1;
-                const int j = c * 64 + bit;
-                const float4 a = s_a[j];
-                const float4 b = s_b[j];
-                const float dx = a.x - pixfx, dy = a.y - pixfy;
-                const float p2 = dx * (a.z * dx + a.w * dy) + b.x * dy * dy;
-                const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(p2));
-                // reference: power > 0 -> skip, alpha < 1/255 -> skip (both leave the pixel untouched)
-                const float hA = sat01(fmaf(alpha, k.big, k.cA));         // [alpha >= 1/255]
-                const float hB = sat01(fmaf(p2, k.nbig, k.one));          // [!(p2 > 0)]
-                const float a_eff = (alpha * hA) * hB;                    // alpha if hit, else 0
-                const float test_T = fmaf(-Tw, a_eff, Tw);
-                // stop = 0: the pixel is live and stays above 1e-4 (then this splat is blended if it hit); stop = 1: the
-                // pixel is dead (Tw == 0) or this hit would take T below 1e-4 -- it terminates, the splat is NOT blended
-                const float stop = sat01(fmaf(test_T, k.nbig100, k.cT));  // [test_T < 1e-4]
-                const float aT = a_eff * Tw;
-                const float w = fmaf(-aT, stop, aT);
-                C = fmaf(b.z, w, C);
-                Dacc = fmaf(b.w, w, Dacc);
-                if (GEO) {
-                    const float4 cc = s_c[j];
-                    A0 = fmaf(cc.x, w, A0); A1 = fmaf(cc.y, w, A1); A2 = fmaf(cc.z, w, A2); A3 = fmaf(cc.w, w, A3);
-                }
-                T_dead = fmaf(stop, Tw, T_dead);        // += Tw on the terminating splat (0 while live, Tw == 0 after)
-                Tw = fmaf(-test_T, stop, test_T);
-                // 1-based list position of the last blended splat: w > 0 exactly when this one was blended, its bit
-                // pattern then exceeds any list position, and positions only grow -> the median of the three
-                const uint32_t pos1 = base + (uint32_t)j, wb = __float_as_uint(w);
-                last_contributor = max(min(last_contributor, pos1), min(max(last_contributor, pos1), wb));  // v_med3_u32
+                const int j1 = m ? c * 64 + __builtin_ctzll(m) : BATCH;
+                m &= m - 1;    // (0 & anything = 0)
+                const Eval e0 = eval(j0);
+                const Eval e1 = eval(j1);
+                blend(e0);
+                blend(e1);
             }
             if (ballot64(Tw > 0.f) == 0ull) {  // checked once per 64-splat chunk
                 wave_done = true;
@@ -418,8 +441,8 @@ __global__ void __launch_bounds__(256) k_render_bwd(
             dm3 = dL_dout_all_map[3 * HW + g.pix_id];
         }
     }
-    float last_alpha = 0.f, last_color = 0.f, last_invd = 0.f, lm0 = 0.f, lm1 = 0.f, lm2 = 0.f, lm3 = 0.f;
     const float nTf_bg = -T_final * (bg_color[0] * dL_dpixel);             // backward.cu:649-652
+    float Tp = T_final * dL_dpixel;                                        // T dL/dpixel (single-channel configurations)
     const int col = lane & 15;
 
     for (int i = 0; i < rounds; i++) {
@@ -564,39 +587,42 @@ __global__ void __launch_bounds__(256) k_render_bwd(
                 if (ballot64(active) == 0ull) continue;
                 float v_g = 0.f, v_c = 0.f, v_invd = 0.f, v_m0 = 0.f, v_m1 = 0.f, v_m2 = 0.f, v_m3 = 0.f;
                 if (active) {
+                    // The reference keeps (last_alpha, last_colour) and folds them into the "colour behind" accumulator at
+                    // the start of the next step (backward.cu:605,620,631); folding right after use is the same
+                    // recurrence -- acc' = alpha c + (1 - alpha) acc = acc + alpha (c - acc) -- with one fma per channel
+                    // on the difference the gradient needs anyway, and no register copies (v_mov issues at half rate).
                     const float rcp_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-                    T = T * rcp_1ma;
-                    const float dchannel_dcolor = alpha * T;
                     float dL_dalpha;
-                    {
-                        const float cval = b.z;
-                        accum_rec = last_alpha * last_color + (1.f - last_alpha) * accum_rec;
-                        last_color = cval;
-                        dL_dalpha = (cval - accum_rec) * dL_dpixel;
+                    if (!INVD && !GEO) {   // one channel: carry Tp = T dL/dpixel instead of T
+                        Tp = Tp * rcp_1ma;
+                        const float d_c = b.z - accum_rec;
+                        accum_rec = fmaf(alpha, d_c, accum_rec);
+                        if (COLG) v_c = alpha * Tp;
+                        dL_dalpha = fmaf(nTf_bg, rcp_1ma, d_c * Tp);
+                    } else {
+                        T = T * rcp_1ma;
+                        const float dchannel_dcolor = alpha * T;
+                        const float d_c = b.z - accum_rec;
+                        accum_rec = fmaf(alpha, d_c, accum_rec);
+                        float sum = d_c * dL_dpixel;
                         if (COLG) v_c = dchannel_dcolor * dL_dpixel;
+                        if (INVD) {
+                            const float d_i = b.w - accum_invd;
+                            accum_invd = fmaf(alpha, d_i, accum_invd);
+                            sum = fmaf(d_i, dL_invd, sum);
+                            v_invd = dchannel_dcolor * dL_invd;
+                        }
+                        if (GEO) {
+                            const float4 cm = s_c[j];
+                            const float d0 = cm.x - accum_m0, d1 = cm.y - accum_m1, d2 = cm.z - accum_m2, d3 = cm.w - accum_m3;
+                            accum_m0 = fmaf(alpha, d0, accum_m0); accum_m1 = fmaf(alpha, d1, accum_m1);
+                            accum_m2 = fmaf(alpha, d2, accum_m2); accum_m3 = fmaf(alpha, d3, accum_m3);
+                            sum = fmaf(d0, dm0, sum); sum = fmaf(d1, dm1, sum); sum = fmaf(d2, dm2, sum); sum = fmaf(d3, dm3, sum);
+                            v_m0 = dchannel_dcolor * dm0; v_m1 = dchannel_dcolor * dm1;
+                            v_m2 = dchannel_dcolor * dm2; v_m3 = dchannel_dcolor * dm3;
+                        }
+                        dL_dalpha = fmaf(nTf_bg, rcp_1ma, sum * T);
                     }
-                    if (INVD) {
-                        const float invd = b.w;
-                        accum_invd = last_alpha * last_invd + (1.f - last_alpha) * accum_invd;
-                        last_invd = invd;
-                        dL_dalpha += (invd - accum_invd) * dL_invd;
-                        v_invd = dchannel_dcolor * dL_invd;
-                    }
-                    if (GEO) {
-                        const float4 cm = s_c[j];
-                        accum_m0 = last_alpha * lm0 + (1.f - last_alpha) * accum_m0; lm0 = cm.x;
-                        accum_m1 = last_alpha * lm1 + (1.f - last_alpha) * accum_m1; lm1 = cm.y;
-                        accum_m2 = last_alpha * lm2 + (1.f - last_alpha) * accum_m2; lm2 = cm.z;
-                        accum_m3 = last_alpha * lm3 + (1.f - last_alpha) * accum_m3; lm3 = cm.w;
-                        dL_dalpha += (cm.x - accum_m0) * dm0;
-                        dL_dalpha += (cm.y - accum_m1) * dm1;
-                        dL_dalpha += (cm.z - accum_m2) * dm2;
-                        dL_dalpha += (cm.w - accum_m3) * dm3;
-                        v_m0 = dchannel_dcolor * dm0; v_m1 = dchannel_dcolor * dm1;
-                        v_m2 = dchannel_dcolor * dm2; v_m3 = dchannel_dcolor * dm3;
-                    }
-                    dL_dalpha = dL_dalpha * T + nTf_bg * rcp_1ma;
-                    last_alpha = alpha;
                     v_g = G * dL_dalpha;
                 }
                 s_g[g.wave][nslot][lane] = v_g;
