@@ -25,7 +25,7 @@ constexpr float ALPHA_MIN = 1.0f / 255.0f;
 // of two floats of these magnitudes times 2^100 exceeds 1, so the saturated product is exactly the step function.
 // [x >= thr] is [x > pred(thr)], pred = the next float below.
 // The constants live in VGPRs on purpose (opaque to the compiler): an fma with an SGPR or inline-constant operand
-// issues in ~4 cycles, with three VGPRs in ~2.9 (scratch/enc_probe.hip).
+// issues in ~4 cycles, with three VGPRs in ~2.9 (profiles/probes/enc_probe.hip).
 __device__ __forceinline__ float sat01(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 1.f); }  // folds into "clamp"
 struct StepConsts {
     float big, cA;       // [alpha >= 1/255] = sat(alpha * 2^100 - pred(1/255) * 2^100)
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(256) k_render_fwd(const uint2* __restrict__ ra
     // and forced to 0 once it terminates (reference: done = true), so a dead pixel blends nothing and can never pass the
     // T test again; T_dead catches the transmittance at termination (what the reference leaves in final_T).  The
     // reference's three tests are evaluated as 0/1 floats (step_gt) and multiplied in: v_cmp / v_cndmask issue at half
-    // the rate of fma / mul on CDNA4 (4 vs 2 cycles per wave instruction, scratch/valu_probe.hip) and the first
+    // the rate of fma / mul on CDNA4 (4 vs 2 cycles per wave instruction, profiles/probes/valu_probe.hip) and the first
     // version's 3 compares + 5 selects were 36 of its ~78 issue cycles per pair; no exec-mask or SGPR-pair bookkeeping
     // either (the scalar unit was the bottleneck before that: ~30 SALU per splat vs ~9).
     const StepConsts k = step_consts();
@@ -530,7 +530,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(
             // Transposed flush: the sums are laid out [slot][field] in LDS and lane (slot = lane >> 3, field = lane & 7)
             // issues the global f32 atomic, so the 6-8 atomics of one splat hit 8 consecutive floats of its 64-byte
             // accumulator record and coalesce into ONE L2 request (measured 7x the rate of one-field-per-instruction;
-            // scratch/xcc_probe.hip).
+            // profiles/probes/xcc_probe.hip).
             {
                 const int row = lane >> 4;
                 if ((lane & 15) < SLOTS && sl < n) {
