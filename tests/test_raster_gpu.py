@@ -406,6 +406,40 @@ def test_forward_is_deterministic_and_backward_linear():
         assert_close("linearity " + k, c["g"][k], 2.0 * a["g"][k], rel=2e-5, outlier_frac=0.0, abs_floor=1e-6)
 
 
+def test_backward_twice_over_one_forward_state():
+    """retain_graph: the gradient accumulators inside the geometry buffer are zeroed by the forward and handed back
+    zeroed by the backward (no separate fill launch), so a second backward over the same forward state must reproduce
+    the first one, and a different upstream gradient must not see leftovers."""
+    from curve_gaussian_amd.diff_cur_rasterization import _C
+    dev = torch.device(DEV)
+    H, W = 96, 144
+    sp = S.random_splats(4000, 75)
+    cam = S.make_camera(*CAMS[2], H, W)
+    rs = hip_settings(cam, torch.zeros(3), dev)
+    d = {k: v.to(dev) for k, v in sp.items()}
+    empty = torch.empty(0, device=dev)
+    (R, color, radii, gB, bB, iB, invd, om) = _C.rasterize_gaussians(
+        rs.bg, d["means3D"], d["colors"], d["opacities"], d["scales"], d["rotations"], 1.0, empty, d["all_map"],
+        rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, empty, 0, rs.campos, False, False, True, False)
+
+    def bwd(gc, gi, gm):
+        out = _C.rasterize_gaussians_backward(
+            rs.bg, empty, d["means3D"], radii, d["colors"], d["all_map"], d["opacities"], d["scales"], d["rotations"], 1.0,
+            empty, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, gc, gi, gm, empty, 0, rs.campos, gB, R, bB, iB,
+            False, True, False)
+        torch.cuda.synchronize()
+        return [t.clone() for t in out]
+    g = [t.to(dev) for t in rand_grads(H, W, 5)]
+    first = bwd(*g)
+    other = bwd(*[3.0 * t for t in g])      # would pick up leftovers of `first` if the accumulators were not clean
+    again = bwd(*g)
+    for a, b, c in zip(first, again, other):
+        if a.numel() == 0:
+            continue
+        assert_close("second backward", b.cpu().numpy(), a.cpu().numpy(), rel=2e-5, outlier_frac=0.0, abs_floor=1e-7)
+        assert_close("scaled backward", c.cpu().numpy(), 3.0 * a.cpu().numpy(), rel=2e-5, outlier_frac=0.0, abs_floor=1e-6)
+
+
 def test_mark_visible_matches_reference_semantics():
     from curve_gaussian_amd.diff_cur_rasterization import GaussianRasterizer
     dev = torch.device(DEV)
