@@ -423,7 +423,7 @@ def main():
             insts = {}
             for line in open(os.path.join(ROOT, "profiles", "r01_pmc.csv")):
                 f = line.strip().split(",")
-                if len(f) == 3 and f[0] == dom and f[1] in ("SQ_INSTS_VALU", "SQ_INSTS_SALU"):
+                if len(f) == 3 and f[0] == dom:
                     insts[f[1]] = float(f[2])
             if "SQ_INSTS_VALU" in insts:
                 rate = insts["SQ_INSTS_VALU"] / (kernel_ms[dom] * 1e-3) / 1e9
@@ -433,6 +433,16 @@ def main():
                                          "salu_instr_per_launch": int(insts.get("SQ_INSTS_SALU", 0)),
                                          "achieved": round(rate, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
                                          "frac": round(rate / peak, 4)}
+                # busy fractions of the other two issue-limited units in the profiled run (PMC ratios; SQ_BUSY_CYCLES is
+                # summed over the 32 shader engines): the scalar ALU issues one instruction per cycle per CU, the LDS
+                # pipeline reports its active cycles directly
+                if insts.get("SQ_BUSY_CYCLES"):
+                    cyc = insts["SQ_BUSY_CYCLES"] / 32.0
+                    out["issue_roofline"]["scalar_alu_busy_frac"] = round(insts.get("SQ_INSTS_SALU", 0) / (256 * cyc), 3)
+                    if "SQ_LDS_IDX_ACTIVE" in insts:
+                        out["issue_roofline"]["lds_busy_frac"] = round(insts["SQ_LDS_IDX_ACTIVE"] / (256 * cyc), 3)
+                    out["issue_roofline"]["note"] = ("vector pipes ~3 cycles per instruction on this mix (profiles/probes): "
+                                                     "no single unit is saturated, see DESIGN.md section 4")
         except Exception:
             pass
         out["kernel_ms_per_view"] = {k: round(v, 5) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])}
