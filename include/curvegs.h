@@ -89,7 +89,9 @@ int64_t cgs_rasterize_forward(
  *   Every gradient output is fully WRITTEN for all P splats (zeros for culled ones); unlike the reference's shim
  *   (rasterize_points.cu:173-193) the caller does not have to zero-fill anything, except dL_dsh [P,M], which is
  *   written for visible splats only when shs != NULL (zero it on entry).  The per-splat accumulation scratch lives
- *   in the geometry buffer, which is therefore written by the backward.
+ *   in the geometry buffer, which is therefore written by the backward: the forward's preprocess kernel zeroes it and
+ *   the backward hands it back zeroed, so any number of backward calls may follow one forward (no fill launch); the
+ *   buffer must be the one the forward of the same splats wrote.
  *   dL_dmean2D [P,3] (.z = 0, NDC-scaled, quirk 9), dL_dconic [P,4] (.x,.y,.w; scratch in the reference, may be
  *   NULL), dL_dopacity [P], dL_dcolor [P,1], dL_dinvdepth [P] (NULL together with dL_dout_invdepth),
  *   dL_dall_map [P,4], dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dscale [P,3], dL_drot [P,4].
