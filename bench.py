@@ -79,11 +79,17 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Control-flow rehearsal of the multi-rank path on a box with ONE GPU (tests only): every rank uses device 0 and the
+    # collectives go through gloo (RCCL refuses two ranks on one device).  Never set for a measurement.
+    rehearsal = os.environ.get("CGS_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None   # the process group is created after the hipGraph captures (below): no RCCL thread runs during capture
+    exchange = [True]   # False for the rank-0-only sections after the timed region (per-kernel times): no collectives there
 
     from curve_gaussian_amd import _lib as L
     from curve_gaussian_amd import synthetic as S
@@ -130,7 +136,7 @@ def main():
             bg, empty, xyz, radii, colors, amaps[id(cam)], opac, scl, rotn, 1.0, empty, cam.world_view_transform,
             cam.full_proj_transform, tanx, tany, dL_dcolor, empty, empty, empty, 0, cam.camera_center, gB, R, bB, iB,
             False, True, False)
-        if dist is not None:
+        if dist is not None and exchange[0]:
             dist.all_reduce(flat_grads)
         if collect:
             stats["R"] += R
@@ -272,7 +278,7 @@ def main():
             vstreams.join()     # (events only: the main stream waits, the view streams run on into the next step)
             for f in flats[1:vstreams.n]:
                 flats[0].add_(f)
-            if dist is not None:
+            if dist is not None and exchange[0]:
                 dist.all_reduce(flats[0])
             if n_sets > 1 and vstreams.streams:
                 reduced[q] = torch.cuda.Event()
@@ -290,7 +296,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     def timed():
         run_views(my_cams[:Wm])
@@ -351,6 +360,7 @@ def main():
     # ---------------------------------------------------------------- per-kernel times (HIP events on the launch stream)
     kernel_ms = {}
     if not args.no_kernel_times and rank == 0:
+        exchange[0] = False     # the other ranks are past their last collective
         lib.cgs_prof_reset()
         lib.cgs_prof_enable(1)
         n_prof = min(K, 16)
