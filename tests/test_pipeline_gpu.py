@@ -415,3 +415,29 @@ def test_graphed_train_step_view_parallel_mode_single_rank_group():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_bench_two_rank_control_flow_rehearsal():
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank), as a
+    rehearsal on ONE GPU: both ranks on device 0, collectives through gloo (CGS_BENCH_REHEARSAL).  Guards the control
+    flow of the multi-rank path -- every rank reaches every collective, rank 0 finishes its rank-0-only sections
+    without one, exactly one JSON line comes out -- not its performance."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, CGS_BENCH_REHEARSAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "8",
+           "--warmup", "2", "--config", "cfg1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 8 and out["value"] > 0
+    assert "roofline" in out and out["config"]["parallelism"] == "view-parallel x2"
