@@ -198,6 +198,7 @@ def main():
     # ---- hipGraph mode: one captured per-view pipeline per stream (sync-free forward with fixed-capacity buckets),
     # replayed for any view after a 140-byte camera copy; the host cost per view drops from ~0.4 ms to ~0.02 ms
     view_graphs = None
+    overflow_acc = torch.zeros(1, dtype=torch.int32, device=dev)
     if args.mode == "view" and not args.no_graph:
         import ctypes
         from curve_gaussian_amd.view_parallel import StaticCamera, capture_graph
@@ -213,7 +214,6 @@ def main():
             if cap > int(lib.cgs_bucket_capacity_limit()):
                 raise RuntimeError(f'tile lists of {longest} entries exceed the bucket limit')
             packs = {id(c): StaticCamera.packed(c) for c in my_cams}
-            overflow_acc = torch.zeros(1, dtype=torch.int32, device=dev)
             view_graphs = []      # [set][stream] -> (graph, its static camera, its stream)
             for q in range(n_sets):
                 view_graphs.append([])
@@ -300,6 +300,11 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        # graph replay only if EVERY rank captured its graphs: the schedules below contain collectives, and ranks on
+        # different schedules would wait for each other forever
+        flag = torch.tensor([1 if use_graphs[0] else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        use_graphs[0] = bool(int(flag.item()))
 
     def timed():
         run_views(my_cams[:Wm])
@@ -310,7 +315,9 @@ def main():
         return time.perf_counter() - t0
 
     elapsed = timed()
-    if use_graphs[0] and int(overflow_acc.item()) != 0:   # a tile list outgrew its bucket: graph results invalid
+    if dist is not None:   # every rank takes the same decision (the re-timing below contains collectives)
+        dist.all_reduce(overflow_acc, op=dist.ReduceOp.MAX)
+    if int(overflow_acc.item()) != 0:   # a tile list outgrew its bucket on some rank: graph results invalid
         print("bench: bucket overflow in graph mode, re-timing with eager launches", file=sys.stderr)
         use_graphs[0] = False
         elapsed = timed()
