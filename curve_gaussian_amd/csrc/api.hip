@@ -663,9 +663,23 @@ int cgs_photometric_loss(int height, int width, const float* image, const float*
         return CGS_ERR_INVALID_ARGUMENT;
     }
     hipStream_t s = (hipStream_t)stream_;
-    launch_photometric_loss(s, height, width, image, gt, threshold, n_pos, lambda_edge, lambda_ssim, clamp_input, workspace,
-                            dL_dimage, loss);
+    launch_photometric_loss(s, height, width, image, gt, nullptr, threshold, n_pos, lambda_edge, lambda_ssim, clamp_input,
+                            workspace, dL_dimage, loss);
     if (!check_launch("photometric_loss", false, s)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
+int cgs_photometric_loss_indexed(int height, int width, const float* image, const float* gt_stack, const int* view_index,
+                                 float threshold, const uint32_t* n_pos_table, float lambda_edge, float lambda_ssim,
+                                 int clamp_input, void* workspace, float* dL_dimage, float* loss, void* stream_) {
+    if (height <= 0 || width <= 0 || !image || !gt_stack || !view_index || !n_pos_table || !workspace || !dL_dimage ||
+        !loss) {
+        set_error("cgs_photometric_loss_indexed: invalid argument");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    hipStream_t s = (hipStream_t)stream_;
+    launch_photometric_loss(s, height, width, image, gt_stack, view_index, threshold, n_pos_table, lambda_edge, lambda_ssim,
+                            clamp_input, workspace, dL_dimage, loss);
+    if (!check_launch("photometric_loss_indexed", false, s)) return CGS_ERR_HIP;
     return CGS_OK;
 }
 

@@ -80,9 +80,9 @@ void launch_ssim_bwd(hipStream_t s, int planes, int H, int W, const float* img1,
                      float* dL_dimg1);
 // loss.hip  (scratch16: 16 zeroed bytes = {u32 n_pos, pad, f64 loss_sum})
 size_t photometric_workspace_bytes(int H, int W);
-void launch_photometric_loss(hipStream_t s, int H, int W, const float* image, const float* gt, float thr,
-                             const unsigned int* n_pos, float lambda_a, float lambda_b, int clamp, void* workspace,
-                             float* grad, float* loss);
+void launch_photometric_loss(hipStream_t s, int H, int W, const float* image, const float* gt, const int* view_index,
+                             float thr, const unsigned int* n_pos, float lambda_a, float lambda_b, int clamp,
+                             void* workspace, float* grad, float* loss);
 void launch_edge_count(hipStream_t s, int C, int HW, const float* gt, float thr, unsigned int* n_pos);
 void launch_edge_aware_loss(hipStream_t s, int C, int H, int W, const float* image, const float* gt, float thr,
                             void* scratch16, float* grad);

@@ -33,7 +33,8 @@ struct PhotoArgs {
     float dmap_const;          // d loss / d ssim_map (constant): -lambda_b / N
     float edge_scale;          // lambda_a * 2 / N
     float thr;                 // edge threshold on gt
-    const unsigned int* n_pos; // #{gt > thr} (device scalar, cached per gt image)
+    const unsigned int* n_pos; // #{gt > thr} (device scalar, cached per gt image; a table when view_index is set)
+    const int* view_index;     // optional device scalar v: img2 is a stack of images and n_pos a table, use entry v
     double* ssim_slots;        // [PHOTO_SLOTS]
     double* edge_slots;        // [PHOTO_SLOTS]
 };
@@ -60,8 +61,9 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(int H, int W, float C1, float 
     float (*s2)[SSX + 1] = reinterpret_cast<float (*)[SSX + 1]>(smem + SSY * (SSX + 1));
     float (*hq)[SSY][STX + 1] = reinterpret_cast<float (*)[SSY][STX + 1]>(smem);
     const size_t plane = (size_t)blockIdx.z * H * W;
+    const size_t view = (FUSED && pa.view_index) ? (size_t)pa.view_index[0] : 0;
     const float* p1 = img1 + plane;
-    const float* p2 = img2 + plane;
+    const float* p2 = img2 + plane + view * ((size_t)H * W);
     const int x0 = blockIdx.x * STX, y0 = blockIdx.y * STY;
     const int tid = threadIdx.x;
     for (int t = tid; t < SSY * SSX; t += 256) {
@@ -205,6 +207,7 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(int H, int W, const float* __r
     }
     __syncthreads();
     const int tx = tid & 31, rg = tid >> 5;
+    const size_t gt_view = (FUSED && pa.view_index) ? (size_t)pa.view_index[0] * ((size_t)H * W) : 0;
     float win[3][14];
 #pragma unroll
     for (int q = 0; q < 3; q++)
@@ -212,7 +215,7 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(int H, int W, const float* __r
         for (int k = 0; k < 14; k++) win[q][k] = hq[q][4 * rg + k][tx];
     float w_pos = 0.f, w_neg = 0.f, edge_acc = 0.f;
     if (FUSED) {  // loss_utils.py:100-108 (weights from the class balance of the gt edge mask)
-        const float n_pos = (float)(*pa.n_pos), n_neg = (float)H * (float)W - n_pos;
+        const float n_pos = (float)pa.n_pos[pa.view_index ? pa.view_index[0] : 0], n_neg = (float)H * (float)W - n_pos;
         w_pos = 5.f * (n_neg + 1.f) / (n_pos + n_neg);
         w_neg = 1.0f * (n_pos + 1.f) / (n_pos + n_neg);
     }
@@ -228,7 +231,7 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(int H, int W, const float* __r
         const int px = x0 + tx, py = y0 + oy;
         if (px < W && py < H) {
             const size_t o = plane + (size_t)py * W + px;
-            const float x = img1[o], y = img2[o];
+            const float x = img1[o], y = img2[o + gt_view];
             const float xc = (FUSED && pa.clamp) ? clamp01(x) : x;
             float dL = a;
             dL += xc * 2.0f * b;
@@ -278,9 +281,9 @@ void launch_ssim_bwd(hipStream_t s, int planes, int H, int W, const float* img1,
 size_t photometric_workspace_bytes(int H, int W) {
     return (((size_t)3 * H * W * sizeof(float) + 127) & ~(size_t)127) + 2 * PHOTO_SLOTS * sizeof(double);
 }
-void launch_photometric_loss(hipStream_t s, int H, int W, const float* image, const float* gt, float thr,
-                             const unsigned int* n_pos, float lambda_a, float lambda_b, int clamp, void* workspace,
-                             float* grad, float* loss) {
+void launch_photometric_loss(hipStream_t s, int H, int W, const float* image, const float* gt, const int* view_index,
+                             float thr, const unsigned int* n_pos, float lambda_a, float lambda_b, int clamp,
+                             void* workspace, float* grad, float* loss) {
     const size_t N = (size_t)H * W;
     float* dm1 = reinterpret_cast<float*>(workspace);
     float* dm2 = dm1 + N;
@@ -292,6 +295,7 @@ void launch_photometric_loss(hipStream_t s, int H, int W, const float* image, co
     pa.edge_scale = lambda_a * 2.f / (float)N;
     pa.thr = thr;
     pa.n_pos = n_pos;
+    pa.view_index = view_index;
     pa.ssim_slots = slots;
     pa.edge_slots = slots + PHOTO_SLOTS;
     const dim3 grid((W + STX - 1) / STX, (H + STY - 1) / STY, 1);

@@ -95,26 +95,39 @@ class FlatAdam:
         return out
 
     # ---- graph-replayable variant: per-step scalars in device memory, optional device-side skip flag
-    def device_state(self):
-        """(device uint8 tensor, pinned host mirror) holding {segments, 1 - b1^t, sqrt(1 - b2^t)} for cgs_adam_step_flat_dev."""
-        if getattr(self, "_state_dev", None) is None:
-            n = int(L.load().cgs_adam_state_bytes())
-            self._state_dev = torch.zeros(n, dtype=torch.uint8, device=self.device)
+    def device_state(self, extra_bytes=None):
+        """(device uint8 tensor, pinned host mirror) holding {segments, 1 - b1^t, sqrt(1 - b2^t)} for
+        cgs_adam_step_flat_dev, followed by `extra_bytes` of caller data that ride in the same per-step copy
+        (``stage_step(extra=...)``; ``state_extra()`` is the device view of that tail)."""
+        n = int(L.load().cgs_adam_state_bytes())
+        have = getattr(self, "_state_dev", None)
+        if have is None or (extra_bytes is not None and have.numel() != n + int(extra_bytes)):
+            total = n + int(extra_bytes or 0)
+            self._state_dev = torch.zeros(total, dtype=torch.uint8, device=self.device)
             # ring of pinned staging slots: the host-to-device copy is asynchronous, so the slot of step t must not be
             # rewritten before that copy has run (callers keep fewer than STATE_RING steps in flight)
-            self._state_host = torch.zeros(self.STATE_RING, n, dtype=torch.uint8).pin_memory()
+            self._state_host = torch.zeros(self.STATE_RING, total, dtype=torch.uint8).pin_memory()
         return self._state_dev, self._state_host
 
-    def stage_step(self):
-        """Advance the step count and enqueue (stream-ordered, non-blocking) the scalars of that step."""
+    def state_extra(self):
+        dev, _ = self.device_state()
+        return dev[int(L.load().cgs_adam_state_bytes()):]
+
+    def stage_step(self, extra=None):
+        """Advance the step count and enqueue (stream-ordered, non-blocking) the scalars of that step -- ONE copy from a
+        pinned slot; `extra` (bytes, at most the size reserved by device_state) lands behind the Adam scalars."""
         dev, host = self.device_state()
         self.step_count += 1
         b1, b2 = self.betas
         segs = self._segments()
         blob = segs + b"\0" * (16 * 16 - len(segs)) + struct.pack("<ffff", 1.0 - b1 ** self.step_count,
                                                                   (1.0 - b2 ** self.step_count) ** 0.5, 0.0, 0.0)
+        if extra is not None:
+            blob = blob + extra
+        if len(blob) > dev.numel():
+            raise ValueError("FlatAdam.stage_step: extra bytes exceed the reserved tail")
         slot = host[self.step_count % self.STATE_RING]
-        slot.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+        slot[:len(blob)].copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
         dev.copy_(slot, non_blocking=True)
 
     def step_dev(self, zero_grad=True, skip_flag=None):

@@ -115,8 +115,9 @@ class GraphedTrainStep(TrainStep):
     An eager iteration costs ~30 kernel launches through Python autograd, ctypes and the HIP runtime (~0.4 ms of host
     time); small scenes are bound by that, large ones leave the GPU idle between kernels.  Here the whole sequence
     (render with the sync-free forward -> fused photometric loss -> backward -> Adam -> prepare_scaling_rot) is captured
-    once; per step the host refreshes four small static buffers (camera pose, gt edge map, edge-pixel count, Adam
-    scalars) with stream-ordered copies and replays the graph.
+    once; per step the host sends ONE 432-byte pinned staging slot (Adam scalars, camera pose, edge-pixel count, view
+    index) with a stream-ordered copy and replays the graph; the gt edge map of the step is picked on the device from
+    a [V,H,W] stack (the autograd body, ``direct=False``, still copies it into a staging image).
 
     The captured forward bins into fixed-capacity tile buckets sized from an eager probe (x ``cap_margin``).  If a
     bucket still overflows, the device-side flag makes the captured Adam skip its update (gradients are cleared);
@@ -149,19 +150,25 @@ class GraphedTrainStep(TrainStep):
         self.cap_margin = float(cap_margin)
         self.direct = bool(direct)   # True: the captured sequence calls the C ABI directly (no autograd inside the graph)
         self._bufs = None
-        # per-step inputs of the graph: ONE packed buffer per view (camera pose 35 floats | edge-pixel count as int32
-        # bits) + the gt edge map; the opacity gate only changes with reset_timestep
-        self._cam = _StaticCamera(c0, dev)
-        self._inputs = torch.zeros(36, dtype=torch.float32, device=dev)
-        self._cam.pack = self._inputs[0:35]
-        self._cam.world_view_transform = self._cam.pack[0:16].view(4, 4)
-        self._cam.full_proj_transform = self._cam.pack[16:32].view(4, 4)
-        self._cam.camera_center = self._cam.pack[32:35]
-        self._npos = self._inputs[35:36].view(torch.int32)
+        # per-step inputs of the graph: camera pose (35 floats) | edge-pixel count (int32 bits) | view index (int32),
+        # 160 bytes per view kept as host bytes; they travel behind the Adam scalars in the optimizer's ONE pinned
+        # staging copy per step (FlatAdam.stage_step(extra=...)) and land in the tail of its device state, which the
+        # captured kernels read.  The gt edge maps live in one [V,H,W] stack and the direct body picks the step's map
+        # on the device (cgs_photometric_loss_indexed): no per-step 4*H*W-byte copy.
+        import struct
         from .ops.losses import edge_pixel_count
-        self._view_packs = [torch.cat([_StaticCamera.packed(c).to(dev), edge_pixel_count(g[:1]).view(torch.float32)])
-                            for c, g in zip(self.cams, self.gts)]
-        self._gt = torch.empty_like(self.gts[0][:1]).contiguous()
+        self._cam = _StaticCamera(c0, dev)
+        H, W = int(c0.image_height), int(c0.image_width)
+        self._gt_stack = torch.stack([g[:1].reshape(H, W).float() for g in self.gts]).contiguous()
+        self.gts = [self._gt_stack[v:v + 1] for v in range(len(self.gts))]          # same storage, eager path
+        self._npos_table = torch.cat([edge_pixel_count(g) for g in self.gts]).to(torch.int32).contiguous()
+        npos_host = self._npos_table.cpu().tolist()
+        self._host_packs = []
+        for v, c in enumerate(self.cams):
+            pose = _StaticCamera.packed(c).cpu().numpy().astype("<f4").tobytes()
+            self._host_packs.append(pose + struct.pack("<ii", int(npos_host[v]), v) + b"\0" * (self.INPUT_BYTES - 148))
+        self._bind_inputs()
+        self._gt = torch.empty_like(self.gts[0][:1]).contiguous()      # staging copy, autograd body (direct=False) only
         self._opa_gate = torch.zeros((), dtype=torch.float32, device=dev)
         self._gate_value = 0.0
         self._graph = None
@@ -273,8 +280,9 @@ class GraphedTrainStep(TrainStep):
             p(b["invd"]), p(b["omap"]), 0, 1, p(b["radii"]), s), "rasterize_forward_static")
         a = self.lambda_mse * (1.0 - self.lambda_dssim)
         bb = self.lambda_mse * self.lambda_dssim
-        chk(lib.cgs_photometric_loss(H, W, p(b["color"]), p(self._gt), cf(0.1), p(self._npos), cf(a), cf(bb), 1,
-                                     p(b["photo_ws"]), p(b["g_img"]), p(b["loss"]), s), "photometric_loss")
+        chk(lib.cgs_photometric_loss_indexed(H, W, p(b["color"]), p(self._gt_stack), p(self._view_idx), cf(0.1),
+                                             p(self._npos_table), cf(a), cf(bb), 1, p(b["photo_ws"]), p(b["g_img"]),
+                                             p(b["loss"]), s), "photometric_loss_indexed")
         # ---- backward: rasterizer -> attributes -> sampling, straight into the flat gradient views
         chk(lib.cgs_rasterize_backward(
             P, 0, 0, 1, p(b["bg"]), W, H, p(b["xyz"]), None, p(b["colors"]), p(b["amap"]), p(b["opac"]), p(scales), 1.0,
@@ -331,9 +339,27 @@ class GraphedTrainStep(TrainStep):
                                f"({limit}); use TrainStep for this scene")
         return cap
 
-    def _load_inputs(self, vi):
-        self._inputs.copy_(self._view_packs[vi], non_blocking=True)
-        self._gt.copy_(self.gts[vi][:1], non_blocking=True)
+    INPUT_BYTES = 160
+
+    def _bind_inputs(self):
+        """(Re)derive the views of the per-step input block from the current optimizer's device state."""
+        opt = self.g.optimizer
+        opt.device_state(extra_bytes=self.INPUT_BYTES)
+        tail = opt.state_extra()
+        self._inputs = tail[:144].view(torch.float32)
+        self._cam.pack = self._inputs[0:35]
+        self._cam.world_view_transform = self._cam.pack[0:16].view(4, 4)
+        self._cam.full_proj_transform = self._cam.pack[16:32].view(4, 4)
+        self._cam.camera_center = self._cam.pack[32:35]
+        self._npos = self._inputs[35:36].view(torch.int32)
+        self._view_idx = tail[144:148].view(torch.int32)
+        self._bound_state = opt._state_dev
+
+    def _stage(self, vi):
+        """Everything the replay of view `vi` needs, stream-ordered: ONE host-to-device copy (Adam scalars + inputs)."""
+        self.g.optimizer.stage_step(extra=self._host_packs[vi])
+        if not self.direct:
+            self._gt.copy_(self.gts[vi][:1], non_blocking=True)
         gate = 1.0 if self.reset_timestep > 0 else 0.0
         if gate != self._gate_value:
             self._opa_gate.fill_(gate)
@@ -343,6 +369,8 @@ class GraphedTrainStep(TrainStep):
         if self._cap == 0:
             self._cap = self._probe_capacity()
         opt = self.g.optimizer
+        if getattr(opt, "_state_dev", None) is not self._bound_state:   # optimizer (re)built since the last capture
+            self._bind_inputs()
         # warm-up replicas of the body must not change the model: snapshot, run on a side stream, restore
         snap = (opt.flat.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.step_count)
         # The gradient accumulators of the parameters live as long as an autograd graph references them, and they keep
@@ -352,8 +380,7 @@ class GraphedTrainStep(TrainStep):
         g = self.g
         g._xyz, g._rotation, g._scaling = g._xyz.detach(), g._rotation.detach(), g._scaling.detach()
         self._loss = self._status = None
-        self._load_inputs(vi)
-        opt.stage_step()
+        self._stage(vi)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -418,8 +445,7 @@ class GraphedTrainStep(TrainStep):
         vi = self._next_view() if view_index is None else view_index
         if self._graph is None:
             self._capture(vi)
-        self._load_inputs(vi)
-        g.optimizer.stage_step()
+        self._stage(vi)
         self._graph.replay()
         if self._collective:
             import torch.distributed as dist

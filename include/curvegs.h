@@ -198,6 +198,12 @@ int cgs_edge_count(int channels, int height, int width, const float* gt, float t
 int cgs_photometric_loss(int height, int width, const float* image, const float* gt, float threshold,
                          const uint32_t* n_pos, float lambda_edge, float lambda_ssim, int clamp_input, void* workspace,
                          float* dL_dimage, float* loss, void* stream);
+/* Same, with the target picked on the device: gt_stack [V,H,W], n_pos_table [V], *view_index (device int) selects the
+ * entry.  For stream-captured training iterations (train.py:95 picks a random view per iteration): the captured launch
+ * is the same for every view, no 4*H*W-byte copy of the step's edge map into a staging buffer. */
+int cgs_photometric_loss_indexed(int height, int width, const float* image, const float* gt_stack, const int* view_index,
+                                 float threshold, const uint32_t* n_pos_table, float lambda_edge, float lambda_ssim,
+                                 int clamp_input, void* workspace, float* dL_dimage, float* loss, void* stream);
 
 /* The per-iteration regularisers of /root/reference/train.py:113-131 (PyTorch ops over all P splats in the reference),
  * value and gradients in three launches:

@@ -204,6 +204,37 @@ def test_flat_adam_matches_torch_adam():
         assert hp[k].data_ptr() >= opt.flat.data_ptr()  # parameters are views of the flat buffer
 
 
+def test_photometric_loss_indexed_picks_the_view_on_the_device():
+    """cgs_photometric_loss_indexed(gt_stack, n_pos_table, *view_index) == cgs_photometric_loss(gt_stack[v], n_pos[v]),
+    bit for bit, for every v, with the index changed between calls through device memory only."""
+    import ctypes as C
+    from curve_gaussian_amd import _lib as L
+    lib = L.load()
+    H, W, V = 70, 93, 3
+    g = torch.Generator().manual_seed(9)
+    img = (torch.rand(1, H, W, generator=g) * 1.4 - 0.2).to(DEV)
+    stack = ((torch.rand(V, H, W, generator=g) > 0.9).float() * torch.rand(V, H, W, generator=g)).to(DEV).contiguous()
+    table = torch.zeros(V, dtype=torch.int32, device=DEV)
+    s = L.raw_stream(torch.device(DEV))
+    for v in range(V):
+        L.check(lib.cgs_edge_count(1, H, W, L.ptr(stack[v]), C.c_float(0.1), L.ptr(table[v:v + 1]), s), "edge_count")
+    ws = torch.zeros(int(lib.cgs_photometric_workspace_bytes(H, W)), dtype=torch.uint8, device=DEV)
+    idx = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for v in (2, 0, 1):
+        idx.fill_(v)
+        g_i, l_i = torch.empty(1, H, W, device=DEV), torch.zeros((), device=DEV)
+        g_p, l_p = torch.empty(1, H, W, device=DEV), torch.zeros((), device=DEV)
+        L.check(lib.cgs_photometric_loss_indexed(H, W, L.ptr(img), L.ptr(stack), L.ptr(idx), C.c_float(0.1), L.ptr(table),
+                                                 C.c_float(9.0), C.c_float(1.0), 1, L.ptr(ws), L.ptr(g_i), L.ptr(l_i), s),
+                "photometric_loss_indexed")
+        L.check(lib.cgs_photometric_loss(H, W, L.ptr(img), L.ptr(stack[v]), C.c_float(0.1), L.ptr(table[v:v + 1]),
+                                         C.c_float(9.0), C.c_float(1.0), 1, L.ptr(ws), L.ptr(g_p), L.ptr(l_p), s),
+                "photometric_loss")
+        torch.cuda.synchronize()
+        assert torch.equal(g_i, g_p), v
+        assert float(l_i) == float(l_p) and float(l_i) > 0, v
+
+
 @pytest.mark.parametrize("clamp", [False, True])
 def test_photometric_loss_equals_composition(clamp):
     """cgs_photometric_loss == lambda_mse ((1-l) edge_aware_loss + l (1 - fused_ssim)) composed from the drop-in ops
