@@ -66,11 +66,30 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(int H, int W, float C1, float 
     const float* p2 = img2 + plane + view * ((size_t)H * W);
     const int x0 = blockIdx.x * STX, y0 = blockIdx.y * STY;
     const int tid = threadIdx.x;
-    for (int t = tid; t < SSY * SSX; t += 256) {
+    // halo staging in two phases -- all global loads first (addresses clamped into the image, out-of-image values zeroed
+    // afterwards), then the LDS stores: a rolled loop waited for its loads every trip, 7 dependent memory round trips per
+    // workgroup, which was most of the kernel's time
+    constexpr int NST = (SSY * SSX + 255) / 256;
+    float g1[NST], g2[NST];
+#pragma unroll
+    for (int e = 0; e < NST; e++) {
+        const int t = tid + 256 * e;
         const int ly = t / SSX, lx = t - ly * SSX;
-        const float v1 = pix_or_zero(p1, y0 + ly - SR, x0 + lx - SR, H, W);
-        s1[ly][lx] = (FUSED && pa.clamp) ? clamp01(v1) : v1;
-        s2[ly][lx] = pix_or_zero(p2, y0 + ly - SR, x0 + lx - SR, H, W);
+        const int y = y0 + ly - SR, x = x0 + lx - SR;
+        const bool inb = t < SSY * SSX && x >= 0 && y >= 0 && x < W && y < H;
+        const size_t o = (size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
+        const float v1 = p1[o], v2 = p2[o];
+        g1[e] = inb ? v1 : 0.f;    // ssim.cu:36-42: zero padding
+        g2[e] = inb ? v2 : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < NST; e++) {
+        const int t = tid + 256 * e;
+        if (t < SSY * SSX) {
+            const int ly = t / SSX, lx = t - ly * SSX;
+            s1[ly][lx] = (FUSED && pa.clamp) ? clamp01(g1[e]) : g1[e];
+            s2[ly][lx] = g2[e];
+        }
     }
     __syncthreads();
     // Both passes are register-blocked along the filter direction: a thread produces 4 neighbouring outputs from a
@@ -161,16 +180,37 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(int H, int W, const float* __r
     const size_t plane = (size_t)blockIdx.z * H * W;
     const int x0 = blockIdx.x * STX, y0 = blockIdx.y * STY;
     const int tid = threadIdx.x;
-    for (int t = tid; t < SSY * SSX; t += 256) {
+    // (two-phase halo staging, see k_ssim_fwd)
+    constexpr int NST = (SSY * SSX + 255) / 256;
+    float ga[NST], gb[NST], gc[NST];
+#pragma unroll
+    for (int e = 0; e < NST; e++) {
+        const int t = tid + 256 * e;
         const int ly = t / SSX, lx = t - ly * SSX;
         const int y = y0 + ly - SR, x = x0 + lx - SR;
-        float a = 0.f, b = 0.f, c = 0.f;
-        if (x >= 0 && y >= 0 && x < W && y < H) {
-            const size_t o = plane + (size_t)y * W + x;
-            const float g = FUSED ? pa.dmap_const : dL_dmap[o];
-            a = dm_dmu1[o] * g; b = dm_dsigma1_sq[o] * g; c = dm_dsigma12[o] * g;
+        const bool inb = t < SSY * SSX && x >= 0 && y >= 0 && x < W && y < H;
+        const size_t o = plane + (size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
+        const float g = !inb ? 0.f : (FUSED ? pa.dmap_const : dL_dmap[o]);
+        ga[e] = dm_dmu1[o] * g; gb[e] = dm_dsigma1_sq[o] * g; gc[e] = dm_dsigma12[o] * g;
+    }
+#pragma unroll
+    for (int e = 0; e < NST; e++) {
+        const int t = tid + 256 * e;
+        if (t < SSY * SSX) {
+            const int ly = t / SSX, lx = t - ly * SSX;
+            s[0][ly][lx] = ga[e]; s[1][ly][lx] = gb[e]; s[2][ly][lx] = gc[e];
         }
-        s[0][ly][lx] = a; s[1][ly][lx] = b; s[2][ly][lx] = c;
+    }
+    // the epilogue's image values, requested now: their latency hides behind the two filter passes
+    const int tx = tid & 31, rg = tid >> 5;
+    const size_t gt_view = (FUSED && pa.view_index) ? (size_t)pa.view_index[0] * ((size_t)H * W) : 0;
+    float xs[4], ys[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int px = min(x0 + tx, W - 1), py = min(y0 + 4 * rg + j, H - 1);
+        const size_t o = plane + (size_t)py * W + px;
+        xs[j] = img1[o];
+        ys[j] = img2[o + gt_view];
     }
     __syncthreads();
     // register-blocked passes (see k_ssim_fwd): 4 neighbouring outputs per thread from a 14-value window
@@ -206,8 +246,6 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(int H, int W, const float* __r
         }
     }
     __syncthreads();
-    const int tx = tid & 31, rg = tid >> 5;
-    const size_t gt_view = (FUSED && pa.view_index) ? (size_t)pa.view_index[0] * ((size_t)H * W) : 0;
     float win[3][14];
 #pragma unroll
     for (int q = 0; q < 3; q++)
@@ -231,7 +269,7 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(int H, int W, const float* __r
         const int px = x0 + tx, py = y0 + oy;
         if (px < W && py < H) {
             const size_t o = plane + (size_t)py * W + px;
-            const float x = img1[o], y = img2[o + gt_view];
+            const float x = xs[j], y = ys[j];
             const float xc = (FUSED && pa.clamp) ? clamp01(x) : x;
             float dL = a;
             dL += xc * 2.0f * b;
