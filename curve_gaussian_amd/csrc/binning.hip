@@ -114,31 +114,48 @@ __global__ void __launch_bounds__(256) k_scatter(int P, const int* __restrict__ 
 
 // Ascending bitonic network in its "flip + disperse" form: every compare-exchange puts the smaller key at the
 // lower index, so indices >= n can be treated as +inf and simply skipped -- any n works without padding.
-template <typename Ptr>
+// WAVE_LOCAL (LDS only, 256 threads, t = tid + 256 k): the 64 pairs a wave handles in one trip of a pass cover one
+// aligned run of 128 elements whenever the pass spans <= 128 elements (flip) or has stride <= 64 (disperse), and it is
+// the same run in every such pass -- so between two such passes a wave only has to order its own LDS accesses, no
+// workgroup barrier: 6 instead of 55 barriers for 1024 keys.
+template <bool WAVE_LOCAL, typename Ptr>
 __device__ __forceinline__ void bitonic_any_n(Ptr k, uint32_t n, uint32_t n2, uint32_t tid, uint32_t nthreads) {
-    for (uint32_t size = 2; size <= n2; size <<= 1) {
+    auto sync = [&](bool done_local, bool next_local) {
+        if (WAVE_LOCAL && done_local && next_local) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            __syncthreads();
+        }
+    };
+    // (strides are powers of two: shifts and masks, no integer division in the index arithmetic)
+    for (uint32_t lsize = 1; (1u << lsize) <= n2; lsize++) {
+        const uint32_t size = 1u << lsize;
         // flip: i <-> (block_end - 1 - i)
         for (uint32_t t = tid; t < n2 / 2; t += nthreads) {
-            const uint32_t half = size >> 1;
-            const uint32_t blk = t / half, j = t % half;
-            const uint32_t lo = blk * size + j, hi = blk * size + size - 1 - j;
+            const uint32_t base = (t >> (lsize - 1)) << lsize, j = t & ((size >> 1) - 1);
+            const uint32_t lo = base + j, hi = base + size - 1 - j;
             if (hi < n) {
                 const uint64_t a = k[lo], b = k[hi];
                 if (a > b) { k[lo] = b; k[hi] = a; }
             }
         }
-        __syncthreads();
-        for (uint32_t d = size >> 2; d >= 1; d >>= 1) {
+        // next pass: the first disperse (stride size/4) if there is one, else the flip of the next size
+        sync(size <= 128, size >= 4 ? (size >> 2) <= 64 : 2 * size <= 128);
+        for (int ld = (int)lsize - 2; ld >= 0; ld--) {
+            const uint32_t d = 1u << ld;
             for (uint32_t t = tid; t < n2 / 2; t += nthreads) {
-                const uint32_t lo = 2 * d * (t / d) + (t % d), hi = lo + d;
+                const uint32_t lo = ((t >> ld) << (ld + 1)) + (t & (d - 1)), hi = lo + d;
                 if (hi < n) {
                     const uint64_t a = k[lo], b = k[hi];
                     if (a > b) { k[lo] = b; k[hi] = a; }
                 }
             }
-            __syncthreads();
+            sync(d <= 64, d > 1 ? (d >> 1) <= 64 : 2 * size <= 128);
         }
     }
+    if (WAVE_LOCAL) __syncthreads();   // (the last pass may have ended on a wave-level fence)
 }
 
 // Small buckets (n <= 1024, i.e. every tile of the BASELINE configs): counting rank sort.  Keys are unique, so
@@ -342,63 +359,37 @@ __global__ void __launch_bounds__(256) k_scatter_grouped(int P, const int* __res
     }
 }
 
-// Fast path: rank on the 32-bit depth alone (a full-rate v_cmp_lt_u32 + add-with-carry per compare; the 64-bit compare
-// of the full (depth, idx) key is several times slower).  Distinct depths give distinct ranks; if two splats of the
-// tile share a depth, two keys collide on a rank -- detected through a claim array in LDS -- and the whole tile is
-// redone with the full 64-bit keys, which reproduces the reference's stable (depth, then index) order.
+// Lists longer than this go to the bitonic network instead of the rank sort: ranking is O(n^2) compares (the kernel is
+// VALU-bound on them for long lists: 0.45 ms at cfg5's mean list of 686), the network O(n log^2 n) with a barrier per pass
+#ifndef CGS_RANK_SPLIT
+#define CGS_RANK_SPLIT 1024
+#endif
+constexpr uint32_t RANK_SPLIT = CGS_RANK_SPLIT;
+// Lists up to RANK_SPLIT entries: the shared rank sort (common.h, tile_rank_sort).  Bucket layout: the range is derived
+// from the tile's instance count and published, with the partial totals, for the compositor.
 template <bool BUCKET>
 __global__ void __launch_bounds__(256) k_tile_rank_sort(const uint2* __restrict__ ranges,
                                                         const uint64_t* __restrict__ keys,
                                                         uint32_t* __restrict__ point_list, uint32_t cap,
                                                         const uint32_t* __restrict__ tile_count,
                                                         uint2* __restrict__ ranges_out, uint32_t* __restrict__ total) {
-    __shared__ uint64_t sk[RANK_MAX + RANK_U];
-    __shared__ uint32_t sd[RANK_MAX + RANK_U];   // depth bits, then reused as the claim array
+    __shared__ uint32_t sd[RANK_MAX + RANK_U];
+    __shared__ uint32_t si[RANK_MAX];
+    __shared__ uint32_t s_hist[RANK_NB], s_start[RANK_NB + 1], s_mm[8];
     const uint2 rg = BUCKET ? bucket_range(tile_count, ranges_out, total, cap, true) : ranges[blockIdx.x];
     const uint32_t n = rg.y - rg.x;
-    if (n == 0 || n > RANK_MAX || (!BUCKET && rg.y > cap)) return;
+    if (n == 0 || n > RANK_SPLIT || (!BUCKET && rg.y > cap)) return;
     const uint32_t tid = threadIdx.x;
     // a wave that owns no key leaves at once (the hardware drops finished waves from the workgroup barriers): its
     // slot goes to the next tile's workgroup -- the kernel is bound by dependent-load latency, i.e. by tiles in flight
     if ((tid & ~63u) >= n) return;
-    const uint64_t* gk = keys + rg.x;
+    uint32_t rank[4], idx[4];
+    tile_rank_sort(keys + rg.x, n, RankScratch{sd, si, s_hist, s_start, s_mm}, rank, idx);
     uint32_t* out = point_list + rg.x;
-    uint64_t mine[4];
-    uint32_t mine_d[4];
-    uint32_t rank[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const uint32_t i = tid + 256u * q;
-        mine[q] = i < n ? gk[i] : ~0ull;
-        mine_d[q] = (uint32_t)(mine[q] >> 32);
-        if (i < n) { sk[i] = mine[q]; sd[i] = mine_d[q]; }
-    }
-    if (tid < RANK_U) { sk[n + tid] = ~0ull; sd[n + tid] = ~0u; }  // +inf padding: never "less than" a real key
-    __syncthreads();
-    const int nq = (n + 255) / 256;  // keys per thread actually in use (block-uniform)
-    rank_dispatch(nq, sd, n, mine_d, rank);
-    __syncthreads();                 // everyone is done reading the depths: sd becomes the claim array
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const uint32_t i = tid + 256u * q;
-        if (i < n) sd[rank[q]] = i;
-    }
-    __syncthreads();
-    bool lost = false;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const uint32_t i = tid + 256u * q;
-        if (i < n) lost |= sd[rank[q]] != i;
-    }
-    if (__syncthreads_or(lost)) {    // equal depths in this tile: full-key ranking (block-uniform branch)
-#pragma unroll
-        for (int q = 0; q < 4; q++) rank[q] = 0;
-        rank_dispatch(nq, sk, n, mine, rank);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const uint32_t i = tid + 256u * q;
-        if (i < n) out[rank[q]] = (uint32_t)mine[q];
+        if (i < n) out[rank[q]] = idx[q];
     }
 }
 
@@ -424,11 +415,11 @@ __global__ void __launch_bounds__(256) k_tile_sort(const uint2* __restrict__ ran
     if (n <= SORT_LDS_KEYS) {
         for (uint32_t i = tid; i < n; i += 256) sk[i] = gk[i];
         __syncthreads();
-        bitonic_any_n(sk, n, n2, tid, 256u);
+        bitonic_any_n<true>(sk, n, n2, tid, 256u);
         for (uint32_t i = tid; i < n; i += 256) out[i] = (uint32_t)sk[i];
     } else {
         // rare oversized bucket: same network directly on global memory (one workgroup => __syncthreads orders it)
-        bitonic_any_n(gk, n, n2, tid, 256u);
+        bitonic_any_n<false>(gk, n, n2, tid, 256u);
         for (uint32_t i = tid; i < n; i += 256) out[i] = (uint32_t)gk[i];
     }
 }
@@ -453,9 +444,9 @@ void launch_tile_sort_small(hipStream_t s, int tiles, const uint2* ranges, uint6
 }
 void launch_tile_sort_big(hipStream_t s, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* point_list,
                           uint32_t max_count) {
-    if (max_count <= RANK_MAX) return;  // rare: some tile list is longer than 1024 -> bitonic network (LDS or global)
+    if (max_count <= RANK_SPLIT) return;  // some tile list is longer than that -> bitonic network (LDS or global)
     ProfScope p("tile_sort_big", s);
-    hipLaunchKernelGGL(k_tile_sort<false>, dim3(tiles), dim3(256), 0, s, ranges, keys, point_list, RANK_MAX, 0u,
+    hipLaunchKernelGGL(k_tile_sort<false>, dim3(tiles), dim3(256), 0, s, ranges, keys, point_list, RANK_SPLIT, 0u,
                        nullptr);
 }
 // Single-pass bucket binning: scatter straight into fixed-capacity tile buckets, then sort each bucket and publish
@@ -480,9 +471,9 @@ void launch_tile_sort_bucket(hipStream_t s, int tiles, const uint32_t* tile_coun
         hipLaunchKernelGGL(k_tile_rank_sort<true>, dim3(tiles), dim3(256), 0, s, nullptr, keys, point_list, cap,
                            tile_count, ranges, total);
     }
-    if (cap > RANK_MAX) {
+    if (cap > RANK_SPLIT) {
         ProfScope p("tile_sort_big", s);
-        hipLaunchKernelGGL(k_tile_sort<true>, dim3(tiles), dim3(256), 0, s, nullptr, keys, point_list, RANK_MAX, cap,
+        hipLaunchKernelGGL(k_tile_sort<true>, dim3(tiles), dim3(256), 0, s, nullptr, keys, point_list, RANK_SPLIT, cap,
                            tile_count);
     }
 }

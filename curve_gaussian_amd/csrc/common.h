@@ -263,6 +263,156 @@ __device__ __forceinline__ void rank_dispatch(int nq, const K* s, uint32_t n, co
     }
 }
 
+// ---- sort of one tile's (<= RANK_MAX) keys by one 256-thread workgroup, shared by k_tile_rank_sort and the fused
+// sort of k_render_fwd<.., SORT>.  Keys are (depth_bits << 32 | splat_idx), unique; on return thread t knows, for each of
+// its slots q (element i = t + 256 q < n of the order it ended up holding), the splat index idx[q] and its final position
+// rank[q] in the reference's stable (depth, then index) order.
+//
+// Ranking is done on the 32-bit depth alone (a v_cmp_lt_u32 + add-with-carry per compare; the 64-bit compare of the full
+// key is several times slower).  Distinct depths give distinct ranks; if two splats of the tile share a depth, two keys
+// collide on a rank -- detected through a claim array in LDS -- and the tile is redone with the full keys.  Lists longer than RANK_PARTITION_MIN are first partitioned into RANK_NB depth buckets (a monotonic map
+// of the depth bits, so bucket order is depth order) laid out bucket by bucket in LDS; thread i then takes the i-th key
+// of that layout and a wave only ranks against the buckets its own 64 keys fall into -- everything before is smaller,
+// everything after larger: O(n^2 / RANK_NB) instead of O(n^2) compares (cfg5, mean list 686: 0.45 -> 0.14 ms).
+#ifndef CGS_RANK_PARTITION_MIN
+#define CGS_RANK_PARTITION_MIN 256
+#endif
+constexpr uint32_t RANK_PARTITION_MIN = CGS_RANK_PARTITION_MIN;
+constexpr uint32_t RANK_NB = 32;   // depth buckets (<= 64: their prefix sum is one wave)
+struct RankScratch {               // LDS
+    uint32_t* sd;                  // [RANK_MAX + RANK_U] depths, then the claim array
+    uint32_t* si;                  // [RANK_MAX] splat indices in the order the threads hold them (partition, tie fallback)
+    uint32_t* hist;                // [RANK_NB]
+    uint32_t* start;               // [RANK_NB + 1]
+    uint32_t* mm;                  // [8] per-wave min / max depth
+};
+// Every thread of the workgroup calls this (waves that hold no key just pass the barriers), n > 0 block-uniform.
+__device__ __forceinline__ void tile_rank_sort(const uint64_t* __restrict__ gk, uint32_t n, const RankScratch S,
+                                               uint32_t (&rank)[4], uint32_t (&idx)[4]) {
+    const uint32_t tid = threadIdx.x;
+    const int lane = (int)(tid & 63u), wave = (int)(tid >> 6);
+    const bool has_keys = ((uint32_t)__builtin_amdgcn_readfirstlane((int)tid) & ~63u) < n;   // wave-uniform, in an SGPR
+    const int nq = (int)((n + 255u) / 256u);         // keys per thread actually in use (block-uniform)
+    uint32_t mine_d[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t i = tid + 256u * q;
+        const uint64_t k = i < n ? gk[i] : ~0ull;
+        mine_d[q] = (uint32_t)(k >> 32);
+        idx[q] = (uint32_t)k;
+        rank[q] = 0u;
+    }
+    if (n <= RANK_PARTITION_MIN) {   // block-uniform
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t i = tid + 256u * q;
+            if (i < n) S.sd[i] = mine_d[q];
+        }
+        if (tid < RANK_U) S.sd[n + tid] = ~0u;       // +inf padding: never "less than" a real key
+        __syncthreads();
+        if (has_keys) rank_dispatch(nq, S.sd, n, mine_d, rank);
+    } else {                         // (n > 256: all four waves hold keys)
+        uint32_t lo = ~0u, hi = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (tid + 256u * q < n) { lo = min(lo, mine_d[q]); hi = max(hi, mine_d[q]); }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
+            hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
+        }
+        if (lane == 0) { S.mm[wave] = lo; S.mm[4 + wave] = hi; }
+        if (tid < RANK_NB) S.hist[tid] = 0u;
+        __syncthreads();
+        const uint32_t dmin = min(min(S.mm[0], S.mm[1]), min(S.mm[2], S.mm[3]));
+        const uint32_t dmax = max(max(S.mm[4], S.mm[5]), max(S.mm[6], S.mm[7]));
+        const float scale = (float)RANK_NB / ((float)(dmax - dmin) + 1.0f);
+        auto bucket_of = [&](uint32_t d) {   // conversion, product and truncation are all monotonic in d
+            return min(RANK_NB - 1u, (uint32_t)((float)(d - dmin) * scale));
+        };
+        uint32_t bq[4] = {0, 0, 0, 0}, pq[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (tid + 256u * q < n) { bq[q] = bucket_of(mine_d[q]); pq[q] = atomicAdd(&S.hist[bq[q]], 1u); }
+        __syncthreads();
+        if (tid < 64) {              // exclusive prefix of the bucket counts
+            uint32_t v = tid < RANK_NB ? S.hist[tid] : 0u;
+#pragma unroll
+            for (int off = 1; off < (int)RANK_NB; off <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)v, off, 64);
+                if (lane >= off) v += t;
+            }
+            if (tid < RANK_NB) S.start[tid + 1] = v;
+            if (tid == 0) S.start[0] = 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (tid + 256u * q < n) {
+                const uint32_t slot = S.start[bq[q]] + pq[q];
+                S.sd[slot] = mine_d[q];
+                S.si[slot] = idx[q];
+            }
+        if (tid < RANK_U) S.sd[n + tid] = ~0u;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t i = tid + 256u * q;
+            mine_d[q] = i < n ? S.sd[i] : ~0u;
+            idx[q] = i < n ? S.si[i] : ~0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t i0 = ((uint32_t)__builtin_amdgcn_readfirstlane((int)tid) & ~63u) + 256u * q;   // wave-uniform
+            if (i0 < n) {
+                const uint32_t i1 = min(n - 1u, i0 + 63u);
+                const uint32_t b0 = bucket_of(S.sd[i0]), b1 = bucket_of(S.sd[i1]);
+                const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(S.start[b0] & ~(RANK_U - 1u)));
+                const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.start[b1 + 1]) - base;
+                const uint32_t m1[4] = {mine_d[q], 0u, 0u, 0u};
+                uint32_t r[4] = {0u, 0u, 0u, 0u};
+                rank_loop<1>(S.sd + base, len, m1, r);     // keys before `base` are all smaller, keys after all larger
+                rank[q] = base + r[0];
+            }
+        }
+    }
+    __syncthreads();                 // everyone is done reading the depths: sd becomes the claim array
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t i = tid + 256u * q;
+        if (i < n) S.sd[rank[q]] = i;
+    }
+    __syncthreads();
+    bool lost = false;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t i = tid + 256u * q;
+        if (i < n) lost |= S.sd[rank[q]] != i;
+    }
+    if (__syncthreads_or(lost)) {    // equal depths in this tile: rank on the full keys (block-uniform branch)
+        // Not rare enough to be slow: with ~160 float depths per tile about one tile in 600 has a pair of equal ones
+        // (a dozen tiles per cfg3 view), and a workgroup that re-read its keys from global memory one by one sat in the
+        // kernel's tail.  The claim array overwrote the depths: restage (depth, index) from registers and rank in LDS.
+        uint64_t mine[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t i = tid + 256u * q;
+            mine[q] = ((uint64_t)mine_d[q] << 32) | idx[q];
+            rank[q] = 0u;
+            if (i < n) { S.sd[i] = mine_d[q]; S.si[i] = idx[q]; }
+        }
+        __syncthreads();
+        if (has_keys) {
+            for (uint32_t u = 0; u < n; u++) {
+                const uint64_t k = ((uint64_t)S.sd[u] << 32) | S.si[u];   // uniform address: LDS broadcast
+#pragma unroll
+                for (int q = 0; q < 4; q++) rank[q] += (uint32_t)(k < mine[q]);
+            }
+        }
+        __syncthreads();             // the caller may overwrite sd / si now
+    }
+}
+
 __device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 #endif  // __HIPCC__
 

@@ -162,6 +162,8 @@ __global__ void __launch_bounds__(256) k_render_fwd(const uint2* __restrict__ ra
     __shared__ float4 s_c[GEO ? BATCH + 1 : 1];
     __shared__ uint64_t s_qmask[4][4];  // [quadrant][64-splat chunk]
     __shared__ uint32_t s_ord[SORT ? RANK_MAX + RANK_U : 1];  // depths -> claim array -> ordered splat indices
+    __shared__ uint32_t s_si[SORT ? RANK_MAX : 1];            // (scratch of tile_rank_sort, common.h)
+    __shared__ uint32_t s_hist[SORT ? RANK_NB : 1], s_start[SORT ? RANK_NB + 1 : 1], s_mm[8];
     if (threadIdx.x == 0) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         s_a[BATCH] = z;
@@ -188,50 +190,14 @@ __global__ void __launch_bounds__(256) k_render_fwd(const uint2* __restrict__ ra
             }
         }
         if (n > 0) {   // block-uniform
-            const uint64_t* gk = bs.keys + base;
-            uint64_t mine[4];
-            uint32_t mine_d[4], rank[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t i = tid + 256u * q;
-                mine[q] = i < n ? gk[i] : ~0ull;
-                mine_d[q] = (uint32_t)(mine[q] >> 32);
-                if (i < n) s_ord[i] = mine_d[q];
-            }
-            if (tid < RANK_U) s_ord[n + tid] = ~0u;
-            __syncthreads();
-            const int nq = (int)((n + 255) / 256);
-            if ((tid & ~63u) < n) rank_dispatch(nq, s_ord, n, mine_d, rank);   // waves without keys skip the loop
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t i = tid + 256u * q;
-                if (i < n) s_ord[rank[q]] = i;
-            }
-            __syncthreads();
-            bool lost = false;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t i = tid + 256u * q;
-                if (i < n) lost |= s_ord[rank[q]] != i;
-            }
-            if (__syncthreads_or(lost)) {   // equal depths in this tile: rank on the full keys, read from global memory
-#pragma unroll
-                for (int q = 0; q < 4; q++) rank[q] = 0;
-                if ((tid & ~63u) < n) {
-                    for (uint32_t u = 0; u < n; u++) {
-                        const uint64_t k = gk[u];
-#pragma unroll
-                        for (int q = 0; q < 4; q++) rank[q] += (uint32_t)(k < mine[q]);
-                    }
-                }
-            }
+            uint32_t rank[4], idx[4];
+            tile_rank_sort(bs.keys + base, n, RankScratch{s_ord, s_si, s_hist, s_start, s_mm}, rank, idx);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const uint32_t i = tid + 256u * q;
                 if (i < n) {
-                    s_ord[rank[q]] = (uint32_t)mine[q];
-                    bs.point_list[base + rank[q]] = (uint32_t)mine[q];
+                    s_ord[rank[q]] = idx[q];
+                    bs.point_list[base + rank[q]] = idx[q];
                 }
             }
             __syncthreads();
