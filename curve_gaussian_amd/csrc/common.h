@@ -275,10 +275,13 @@ __device__ __forceinline__ void rank_dispatch(int nq, const K* s, uint32_t n, co
 // of that layout and a wave only ranks against the buckets its own 64 keys fall into -- everything before is smaller,
 // everything after larger: O(n^2 / RANK_NB) instead of O(n^2) compares (cfg5, mean list 686: 0.45 -> 0.14 ms).
 #ifndef CGS_RANK_PARTITION_MIN
-#define CGS_RANK_PARTITION_MIN 256
+#define CGS_RANK_PARTITION_MIN 192
 #endif
 constexpr uint32_t RANK_PARTITION_MIN = CGS_RANK_PARTITION_MIN;
-constexpr uint32_t RANK_NB = 32;   // depth buckets (<= 64: their prefix sum is one wave)
+#ifndef CGS_RANK_NB
+#define CGS_RANK_NB 64
+#endif
+constexpr uint32_t RANK_NB = CGS_RANK_NB;   // depth buckets (<= 64: their prefix sum is one wave)
 struct RankScratch {               // LDS
     uint32_t* sd;                  // [RANK_MAX + RANK_U] depths, then the claim array
     uint32_t* si;                  // [RANK_MAX] splat indices in the order the threads hold them (partition, tie fallback)
@@ -311,7 +314,7 @@ __device__ __forceinline__ void tile_rank_sort(const uint64_t* __restrict__ gk, 
         if (tid < RANK_U) S.sd[n + tid] = ~0u;       // +inf padding: never "less than" a real key
         __syncthreads();
         if (has_keys) rank_dispatch(nq, S.sd, n, mine_d, rank);
-    } else {                         // (n > 256: all four waves hold keys)
+    } else {
         uint32_t lo = ~0u, hi = 0u;
 #pragma unroll
         for (int q = 0; q < 4; q++)
@@ -324,8 +327,9 @@ __device__ __forceinline__ void tile_rank_sort(const uint64_t* __restrict__ gk, 
         if (lane == 0) { S.mm[wave] = lo; S.mm[4 + wave] = hi; }
         if (tid < RANK_NB) S.hist[tid] = 0u;
         __syncthreads();
-        const uint32_t dmin = min(min(S.mm[0], S.mm[1]), min(S.mm[2], S.mm[3]));
-        const uint32_t dmax = max(max(S.mm[4], S.mm[5]), max(S.mm[6], S.mm[7]));
+        uint32_t dmin = S.mm[0], dmax = S.mm[4];
+        const int nwaves = (int)min(4u, (n + 63u) / 64u);   // waves that hold keys (the others may have left the kernel)
+        for (int w = 1; w < nwaves; w++) { dmin = min(dmin, S.mm[w]); dmax = max(dmax, S.mm[4 + w]); }
         const float scale = (float)RANK_NB / ((float)(dmax - dmin) + 1.0f);
         auto bucket_of = [&](uint32_t d) {   // conversion, product and truncation are all monotonic in d
             return min(RANK_NB - 1u, (uint32_t)((float)(d - dmin) * scale));
