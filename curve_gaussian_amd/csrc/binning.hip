@@ -365,29 +365,33 @@ __global__ void __launch_bounds__(256) k_scatter_grouped(int P, const int* __res
 #define CGS_RANK_SPLIT 1024
 #endif
 constexpr uint32_t RANK_SPLIT = CGS_RANK_SPLIT;
-// Lists up to RANK_SPLIT entries: the shared rank sort (common.h, tile_rank_sort).  Bucket layout: the range is derived
-// from the tile's instance count and published, with the partial totals, for the compositor.
-template <bool BUCKET>
+// The shared rank sort (common.h, tile_rank_sort) for lists of (min_n, 256 * KPT] entries: KPT = 4 covers every list of
+// the 200k-splat configs, a second launch with KPT = 8 the 1025..2048-entry lists of denser scenes (cfg5), the bitonic
+// network below the rest.  Bucket layout: the first launch (PUBLISH) derives each tile's range from its instance count
+// and publishes it, with the partial totals, for the compositor.
+constexpr uint32_t RANK_MAX2 = 2048;
+template <bool BUCKET, int KPT, bool PUBLISH>
 __global__ void __launch_bounds__(256) k_tile_rank_sort(const uint2* __restrict__ ranges,
                                                         const uint64_t* __restrict__ keys,
                                                         uint32_t* __restrict__ point_list, uint32_t cap,
                                                         const uint32_t* __restrict__ tile_count,
-                                                        uint2* __restrict__ ranges_out, uint32_t* __restrict__ total) {
-    __shared__ uint32_t sd[RANK_MAX + RANK_U];
-    __shared__ uint32_t si[RANK_MAX];
+                                                        uint2* __restrict__ ranges_out, uint32_t* __restrict__ total,
+                                                        uint32_t min_n) {
+    __shared__ uint32_t sd[256 * KPT + RANK_U];
+    __shared__ uint32_t si[256 * KPT];
     __shared__ uint32_t s_hist[RANK_NB], s_start[RANK_NB + 1], s_mm[8];
-    const uint2 rg = BUCKET ? bucket_range(tile_count, ranges_out, total, cap, true) : ranges[blockIdx.x];
+    const uint2 rg = BUCKET ? bucket_range(tile_count, ranges_out, total, cap, PUBLISH) : ranges[blockIdx.x];
     const uint32_t n = rg.y - rg.x;
-    if (n == 0 || n > RANK_SPLIT || (!BUCKET && rg.y > cap)) return;
+    if (n <= min_n || n > 256u * KPT || n > (KPT == 4 ? RANK_SPLIT : ~0u) || (!BUCKET && rg.y > cap)) return;
     const uint32_t tid = threadIdx.x;
     // a wave that owns no key leaves at once (the hardware drops finished waves from the workgroup barriers): its
     // slot goes to the next tile's workgroup -- the kernel is bound by dependent-load latency, i.e. by tiles in flight
     if ((tid & ~63u) >= n) return;
-    uint32_t rank[4], idx[4];
-    tile_rank_sort(keys + rg.x, n, RankScratch{sd, si, s_hist, s_start, s_mm}, rank, idx);
+    uint32_t rank[KPT], idx[KPT];
+    tile_rank_sort<KPT>(keys + rg.x, n, RankScratch{sd, si, s_hist, s_start, s_mm}, rank, idx);
     uint32_t* out = point_list + rg.x;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < KPT; q++) {
         const uint32_t i = tid + 256u * q;
         if (i < n) out[rank[q]] = idx[q];
     }
@@ -439,15 +443,22 @@ void launch_scatter(hipStream_t s, int P, const int* radii, const SplatRec* rec,
 void launch_tile_sort_small(hipStream_t s, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* point_list,
                             uint32_t cap) {
     ProfScope p("tile_sort", s);
-    hipLaunchKernelGGL(k_tile_rank_sort<false>, dim3(tiles), dim3(256), 0, s, ranges, keys, point_list, cap, nullptr,
-                       nullptr, nullptr);
+    hipLaunchKernelGGL((k_tile_rank_sort<false, 4, false>), dim3(tiles), dim3(256), 0, s, ranges, keys, point_list, cap,
+                       nullptr, nullptr, nullptr, 0u);
 }
 void launch_tile_sort_big(hipStream_t s, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* point_list,
                           uint32_t max_count) {
-    if (max_count <= RANK_SPLIT) return;  // some tile list is longer than that -> bitonic network (LDS or global)
+    if (max_count <= RANK_SPLIT) return;  // some tile list is longer than that
+    uint32_t done = RANK_SPLIT;
+    if (RANK_SPLIT == RANK_MAX) {         // 1025..2048 entries: rank sort with 8 keys per thread
+        ProfScope p("tile_sort_mid", s);
+        hipLaunchKernelGGL((k_tile_rank_sort<false, 8, false>), dim3(tiles), dim3(256), 0, s, ranges, keys, point_list,
+                           ~0u, nullptr, nullptr, nullptr, RANK_MAX);
+        done = RANK_MAX2;
+    }
     ProfScope p("tile_sort_big", s);
-    hipLaunchKernelGGL(k_tile_sort<false>, dim3(tiles), dim3(256), 0, s, ranges, keys, point_list, RANK_SPLIT, 0u,
-                       nullptr);
+    if (max_count > done)                 // beyond: bitonic network (LDS or global)
+        hipLaunchKernelGGL(k_tile_sort<false>, dim3(tiles), dim3(256), 0, s, ranges, keys, point_list, done, 0u, nullptr);
 }
 // Single-pass bucket binning: scatter straight into fixed-capacity tile buckets, then sort each bucket and publish
 // ranges / num_rendered / longest list / overflow flag from the sort kernel.
@@ -468,13 +479,21 @@ void launch_tile_sort_bucket(hipStream_t s, int tiles, const uint32_t* tile_coun
                              uint64_t* keys, uint32_t* point_list, uint32_t cap) {
     {
         ProfScope p("tile_sort", s);
-        hipLaunchKernelGGL(k_tile_rank_sort<true>, dim3(tiles), dim3(256), 0, s, nullptr, keys, point_list, cap,
-                           tile_count, ranges, total);
+        hipLaunchKernelGGL((k_tile_rank_sort<true, 4, true>), dim3(tiles), dim3(256), 0, s, nullptr, keys, point_list, cap,
+                           tile_count, ranges, total, 0u);
     }
     if (cap > RANK_SPLIT) {
+        uint32_t done = RANK_SPLIT;
+        if (RANK_SPLIT == RANK_MAX) {
+            ProfScope p("tile_sort_mid", s);
+            hipLaunchKernelGGL((k_tile_rank_sort<true, 8, false>), dim3(tiles), dim3(256), 0, s, nullptr, keys, point_list,
+                               cap, tile_count, nullptr, nullptr, RANK_MAX);
+            done = RANK_MAX2;
+        }
         ProfScope p("tile_sort_big", s);
-        hipLaunchKernelGGL(k_tile_sort<true>, dim3(tiles), dim3(256), 0, s, nullptr, keys, point_list, RANK_SPLIT, cap,
-                           tile_count);
+        if (cap > done)
+            hipLaunchKernelGGL(k_tile_sort<true>, dim3(tiles), dim3(256), 0, s, nullptr, keys, point_list, done, cap,
+                               tile_count);
     }
 }
 uint32_t bucket_cap_limit() { return SORT_LDS_KEYS; }

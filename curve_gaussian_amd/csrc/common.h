@@ -290,34 +290,42 @@ struct RankScratch {               // LDS
     uint32_t* mm;                  // [8] per-wave min / max depth
 };
 // Every thread of the workgroup calls this (waves that hold no key just pass the barriers), n > 0 block-uniform.
+// KPT = keys per thread: lists of up to 256 * KPT entries (the scratch arrays are sized accordingly by the caller).
+template <int KPT>
 __device__ __forceinline__ void tile_rank_sort(const uint64_t* __restrict__ gk, uint32_t n, const RankScratch S,
-                                               uint32_t (&rank)[4], uint32_t (&idx)[4]) {
+                                               uint32_t (&rank)[KPT], uint32_t (&idx)[KPT]) {
     const uint32_t tid = threadIdx.x;
     const int lane = (int)(tid & 63u), wave = (int)(tid >> 6);
     const bool has_keys = ((uint32_t)__builtin_amdgcn_readfirstlane((int)tid) & ~63u) < n;   // wave-uniform, in an SGPR
     const int nq = (int)((n + 255u) / 256u);         // keys per thread actually in use (block-uniform)
-    uint32_t mine_d[4];
+    (void)nq;
+    uint32_t mine_d[KPT];
+    uint32_t rbase[KPT], rlen[KPT];   // wave-uniform: the slice of the LDS order each of this wave's key rounds ranks against
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < KPT; q++) {
+        rbase[q] = 0u;
+        rlen[q] = n;
         const uint32_t i = tid + 256u * q;
         const uint64_t k = i < n ? gk[i] : ~0ull;
         mine_d[q] = (uint32_t)(k >> 32);
         idx[q] = (uint32_t)k;
         rank[q] = 0u;
     }
-    if (n <= RANK_PARTITION_MIN) {   // block-uniform
+    if (KPT == 4 && n <= RANK_PARTITION_MIN) {   // block-uniform (longer per-thread key sets always partition)
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < KPT; q++) {
             const uint32_t i = tid + 256u * q;
             if (i < n) S.sd[i] = mine_d[q];
         }
         if (tid < RANK_U) S.sd[n + tid] = ~0u;       // +inf padding: never "less than" a real key
         __syncthreads();
-        if (has_keys) rank_dispatch(nq, S.sd, n, mine_d, rank);
+        if constexpr (KPT == 4) {
+            if (has_keys) rank_dispatch(nq, S.sd, n, mine_d, rank);
+        }
     } else {
         uint32_t lo = ~0u, hi = 0u;
 #pragma unroll
-        for (int q = 0; q < 4; q++)
+        for (int q = 0; q < KPT; q++)
             if (tid + 256u * q < n) { lo = min(lo, mine_d[q]); hi = max(hi, mine_d[q]); }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
@@ -334,9 +342,9 @@ __device__ __forceinline__ void tile_rank_sort(const uint64_t* __restrict__ gk, 
         auto bucket_of = [&](uint32_t d) {   // conversion, product and truncation are all monotonic in d
             return min(RANK_NB - 1u, (uint32_t)((float)(d - dmin) * scale));
         };
-        uint32_t bq[4] = {0, 0, 0, 0}, pq[4] = {0, 0, 0, 0};
+        uint32_t bq[KPT], pq[KPT];
 #pragma unroll
-        for (int q = 0; q < 4; q++)
+        for (int q = 0; q < KPT; q++)
             if (tid + 256u * q < n) { bq[q] = bucket_of(mine_d[q]); pq[q] = atomicAdd(&S.hist[bq[q]], 1u); }
         __syncthreads();
         if (tid < 64) {              // exclusive prefix of the bucket counts
@@ -351,7 +359,7 @@ __device__ __forceinline__ void tile_rank_sort(const uint64_t* __restrict__ gk, 
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; q++)
+        for (int q = 0; q < KPT; q++)
             if (tid + 256u * q < n) {
                 const uint32_t slot = S.start[bq[q]] + pq[q];
                 S.sd[slot] = mine_d[q];
@@ -360,13 +368,13 @@ __device__ __forceinline__ void tile_rank_sort(const uint64_t* __restrict__ gk, 
         if (tid < RANK_U) S.sd[n + tid] = ~0u;
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < KPT; q++) {
             const uint32_t i = tid + 256u * q;
             mine_d[q] = i < n ? S.sd[i] : ~0u;
             idx[q] = i < n ? S.si[i] : ~0u;
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < KPT; q++) {
             const uint32_t i0 = ((uint32_t)__builtin_amdgcn_readfirstlane((int)tid) & ~63u) + 256u * q;   // wave-uniform
             if (i0 < n) {
                 const uint32_t i1 = min(n - 1u, i0 + 63u);
@@ -377,19 +385,21 @@ __device__ __forceinline__ void tile_rank_sort(const uint64_t* __restrict__ gk, 
                 uint32_t r[4] = {0u, 0u, 0u, 0u};
                 rank_loop<1>(S.sd + base, len, m1, r);     // keys before `base` are all smaller, keys after all larger
                 rank[q] = base + r[0];
+                rbase[q] = base;
+                rlen[q] = len;
             }
         }
     }
     __syncthreads();                 // everyone is done reading the depths: sd becomes the claim array
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < KPT; q++) {
         const uint32_t i = tid + 256u * q;
         if (i < n) S.sd[rank[q]] = i;
     }
     __syncthreads();
     bool lost = false;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < KPT; q++) {
         const uint32_t i = tid + 256u * q;
         if (i < n) lost |= S.sd[rank[q]] != i;
     }
@@ -397,20 +407,26 @@ __device__ __forceinline__ void tile_rank_sort(const uint64_t* __restrict__ gk, 
         // Not rare enough to be slow: with ~160 float depths per tile about one tile in 600 has a pair of equal ones
         // (a dozen tiles per cfg3 view), and a workgroup that re-read its keys from global memory one by one sat in the
         // kernel's tail.  The claim array overwrote the depths: restage (depth, index) from registers and rank in LDS.
-        uint64_t mine[4];
+        uint64_t mine[KPT];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < KPT; q++) {
             const uint32_t i = tid + 256u * q;
             mine[q] = ((uint64_t)mine_d[q] << 32) | idx[q];
             rank[q] = 0u;
             if (i < n) { S.sd[i] = mine_d[q]; S.si[i] = idx[q]; }
         }
         __syncthreads();
-        if (has_keys) {
-            for (uint32_t u = 0; u < n; u++) {
-                const uint64_t k = ((uint64_t)S.sd[u] << 32) | S.si[u];   // uniform address: LDS broadcast
+        if (has_keys) {              // same slices as the first pass (ties share a bucket), full (depth, index) compare
 #pragma unroll
-                for (int q = 0; q < 4; q++) rank[q] += (uint32_t)(k < mine[q]);
+            for (int q = 0; q < KPT; q++) {
+                if (((uint32_t)__builtin_amdgcn_readfirstlane((int)tid) & ~63u) + 256u * q >= n) continue;
+                const uint32_t u1 = min(n, rbase[q] + rlen[q]);
+                uint32_t r = rbase[q];
+                for (uint32_t u = rbase[q]; u < u1; u++) {
+                    const uint64_t k = ((uint64_t)S.sd[u] << 32) | S.si[u];   // uniform address: LDS broadcast
+                    r += (uint32_t)(k < mine[q]);
+                }
+                rank[q] = r;
             }
         }
         __syncthreads();             // the caller may overwrite sd / si now

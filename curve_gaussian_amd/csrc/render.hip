@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(256) k_render_fwd(const uint2* __restrict__ ra
         }
         if (n > 0) {   // block-uniform
             uint32_t rank[4], idx[4];
-            tile_rank_sort(bs.keys + base, n, RankScratch{s_ord, s_si, s_hist, s_start, s_mm}, rank, idx);
+            tile_rank_sort<4>(bs.keys + base, n, RankScratch{s_ord, s_si, s_hist, s_start, s_mm}, rank, idx);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const uint32_t i = tid + 256u * q;
