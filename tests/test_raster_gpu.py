@@ -201,6 +201,10 @@ def _binning_case(case):
         H, W, P = 64, 64, 3000
         sp = S.random_splats(P, 61)
         sp["means3D"] = sp["means3D"][torch.arange(P) % 40]  # 75 coincident copies of 40 positions => depth ties
+    elif case == "ties_mid":                                     # 4 tiles x 1025..2048 instances, with depth ties:
+        H, W, P = 32, 32, 1700                                   # the 8-keys-per-thread rank sort and its tie pass
+        sp = S.random_splats(P, 65, scale_range=(0.05, 0.2))
+        sp["means3D"] = sp["means3D"][torch.arange(P) % 300]
     elif case == "oversized_bucket":
         H, W, P = 32, 32, 9000                                   # 4 tiles x ~9000 instances > 4096-key LDS capacity
         sp = S.random_splats(P, 62, scale_range=(0.05, 0.2))
@@ -237,7 +241,7 @@ def _raster_raw(sp, cam, H, W, dev, reset_hints=False):
     return out
 
 
-@pytest.mark.parametrize("case", ["ties", "oversized_bucket", "screen_filling", "elongated"])
+@pytest.mark.parametrize("case", ["ties", "ties_mid", "oversized_bucket", "screen_filling", "elongated"])
 def test_tile_culling_drops_only_invisible_instances(case):
     """Default mode (cgs_set_tile_culling(1)): every tile list is a SUBSEQUENCE of the reference's stable-sorted list
     (same relative order), every dropped (splat, tile) instance stays below alpha 1/255 at all 256 pixels of its tile
@@ -295,7 +299,7 @@ def test_tile_culling_drops_only_invisible_instances(case):
     fw.free()
 
 
-@pytest.mark.parametrize("case", ["ties", "oversized_bucket", "screen_filling", "elongated"])
+@pytest.mark.parametrize("case", ["ties", "ties_mid", "oversized_bucket", "screen_filling", "elongated"])
 def test_binning_bit_exact(case, no_tile_culling):
     """Integer work with tile culling off: num_rendered, tile ranges and the per-tile (depth, idx) order equal the
     reference's stable radix sort exactly -- including depth ties and buckets larger than the LDS sort capacity."""
@@ -316,10 +320,13 @@ def test_binning_bit_exact(case, no_tile_culling):
     ranges, point_list, n_contrib, final_T = _decode_state(geomB, binB, imgB, P, H, W, R)
     ref_ranges = fw.ranges
     nonempty = ref_ranges[:, 1] > ref_ranges[:, 0]
+    if case == "ties_mid":   # the case exists for the 1025..2048-entry sort path: make sure it is what it exercises
+        longest = int((ref_ranges[:, 1] - ref_ranges[:, 0]).max())
+        assert 1024 < longest <= 2048, longest
     assert (ranges[nonempty] == ref_ranges[nonempty]).all()
     assert ((ranges[~nonempty, 1] - ranges[~nonempty, 0]) == 0).all()
     assert (point_list == fw.point_list).all(), "per-tile compositing order must match the reference's stable sort"
-    if case != "ties":  # identical order + identical arithmetic up to expf rounding: n_contrib may flip only at thresholds
+    if case not in ("ties", "ties_mid"):  # identical order + identical arithmetic up to expf rounding: n_contrib may flip only at thresholds
         mism = (n_contrib.reshape(H, W) != fw.n_contrib).mean()
         assert mism <= 2e-3, mism
     assert_close("color", color.cpu().numpy(), fw.color)
