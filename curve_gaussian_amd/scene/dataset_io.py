@@ -12,6 +12,7 @@
   (edge_extraction/extract_para_edge.py:60-129, 252-256): curves as 4x3 control points, lines as 6 floats, and the
   edge point cloud sampled every 5 mm of Simpson-rule arc length (edge_extraction/extract_uitl.py:291-330).
   ``merge_endpoints`` (opt.merge_endpoints_flag) and the visibility check are not reproduced.
+* ``point_cloud.ply`` splat snapshot -- ``save_ply`` (scene/gaussian_model.py:267-280, 383-400; scene/__init__.py:96).
 
 Parity: the camera arithmetic is pinned by tests/golden/emap_camera.npz (reference graphics_utils imported by
 tests/golden/make_golden.py); the edge_extraction modules cannot be imported here (cv2 / point_cloud_utils missing), so
@@ -200,3 +201,53 @@ def write_parametric_edges(gaussians, model_path):
         for p in pts:
             f.write("%.10g %.10g %.10g\n" % (p[0], p[1], p[2]))
     return edge_dict, pts
+
+
+# ------------------------------------------------------------------------------------------ splat snapshot (PLY)
+def ply_attribute_names(n_dc, n_rest, n_scale=3, n_rot=4):
+    """scene/gaussian_model.py:267-280 (construct_list_of_attributes)."""
+    names = ["x", "y", "z", "nx", "ny", "nz"]
+    names += [f"f_dc_{i}" for i in range(n_dc)] + [f"f_rest_{i}" for i in range(n_rest)]
+    names += ["opacity"] + [f"scale_{i}" for i in range(n_scale)] + [f"rot_{i}" for i in range(n_rot)]
+    return names
+
+
+def save_ply(gaussians, path):
+    """Splat snapshot in the 3DGS point_cloud.ply layout the reference writes (scene/gaussian_model.py:383-400, called
+    from scene/__init__.py:96): one vertex per splat with float32 properties x y z | nx ny nz (zeros) | f_dc_* |
+    f_rest_* | opacity (logit) | scale_* | rot_* (raw, un-normalised), binary little-endian -- written directly (plyfile
+    is not a dependency here).  The curve model keeps opacity per curve: it is expanded to its m splats, and `_scaling`
+    holds (segment length, exp(width), exp(width)) as sampled, exactly what the reference's tensors of these names hold."""
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    xyz = gaussians._xyz.detach().float().cpu().numpy()
+    P = xyz.shape[0]
+    feats = gaussians.get_features.detach().float().cpu().numpy().reshape(P, -1)      # [P, (D+1)^2] (one channel)
+    f_dc, f_rest = feats[:, :1], feats[:, 1:]
+    op = gaussians.get_opacity.detach().float().cpu().numpy().reshape(P, 1)
+    op = np.clip(op, 1e-12, 1.0 - 1e-7)
+    logit = np.log(op / (1.0 - op))                                                     # inverse_sigmoid
+    scale = gaussians._scaling.detach().float().cpu().numpy().reshape(P, -1)
+    rot = gaussians._rotation.detach().float().cpu().numpy().reshape(P, -1)
+    cols = np.concatenate([xyz, np.zeros_like(xyz), f_dc, f_rest, logit, scale, rot], axis=1).astype("<f4")
+    names = ply_attribute_names(f_dc.shape[1], f_rest.shape[1], scale.shape[1], rot.shape[1])
+    assert cols.shape[1] == len(names)
+    header = "ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % P
+    header += "".join(f"property float {n}\n" for n in names) + "end_header\n"
+    with open(path, "wb") as f:
+        f.write(header.encode("ascii"))
+        f.write(np.ascontiguousarray(cols).tobytes())
+    return names
+
+
+def read_ply_vertices(path):
+    """Minimal reader of the float32 binary little-endian vertex table save_ply writes -> dict name -> [P] array."""
+    with open(path, "rb") as f:
+        blob = f.read()
+    head, body = blob.split(b"end_header\n", 1)
+    lines = head.decode("ascii").splitlines()
+    if lines[0] != "ply" or "format binary_little_endian 1.0" not in lines:
+        raise ValueError("read_ply_vertices: not a binary little-endian PLY")
+    n = int([ln for ln in lines if ln.startswith("element vertex")][0].split()[-1])
+    names = [ln.split()[-1] for ln in lines if ln.startswith("property float")]
+    table = np.frombuffer(body, dtype="<f4", count=n * len(names)).reshape(n, len(names))
+    return {nm: table[:, i] for i, nm in enumerate(names)}

@@ -79,3 +79,32 @@ def test_parametric_edges_writer(tmp_path):
     assert len(pts) == n_expected
     head = open(tmp_path / "edge_points.ply").read().split("end_header")[0]
     assert "format ascii 1.0" in head and f"element vertex {n_expected}" in head
+
+
+def test_splat_snapshot_ply_round_trip(tmp_path):
+    """save_ply: the reference's point_cloud.ply vertex layout (gaussian_model.py:267-280, 383-400) -- attribute names
+    and order, float32 little-endian, opacity stored as its logit -- read back value for value."""
+    class G:
+        pass
+    g = G()
+    P = 24
+    gen = torch.Generator().manual_seed(3)
+    g._xyz = torch.randn(P, 3, generator=gen)
+    g._scaling = torch.rand(P, 3, generator=gen) * 0.01
+    g._rotation = torch.randn(P, 4, generator=gen)
+    g.get_features = torch.randn(P, 4, 1, generator=gen)          # sh degree 1: 1 dc + 3 rest coefficients, one channel
+    g.get_opacity = torch.rand(P, 1, generator=gen) * 0.98 + 0.01
+    path = tmp_path / "point_cloud" / "iteration_7" / "point_cloud.ply"
+    names = IO.save_ply(g, str(path))
+    assert names == ["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_rest_0", "f_rest_1", "f_rest_2", "opacity",
+                     "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"]
+    head = open(path, "rb").read(400).decode("ascii", "ignore")
+    assert head.startswith("ply\nformat binary_little_endian 1.0\nelement vertex 24\nproperty float x\n")
+    v = IO.read_ply_vertices(str(path))
+    np.testing.assert_array_equal(np.stack([v["x"], v["y"], v["z"]], 1), g._xyz.numpy())
+    assert not np.any(v["nx"]) and not np.any(v["nz"])
+    np.testing.assert_array_equal(v["f_dc_0"], g.get_features[:, 0, 0].numpy())
+    np.testing.assert_array_equal(v["f_rest_2"], g.get_features[:, 3, 0].numpy())
+    np.testing.assert_allclose(1.0 / (1.0 + np.exp(-v["opacity"].astype(np.float64))), g.get_opacity[:, 0].numpy(), rtol=1e-5)
+    np.testing.assert_array_equal(np.stack([v[f"scale_{i}"] for i in range(3)], 1), g._scaling.numpy())
+    np.testing.assert_array_equal(np.stack([v[f"rot_{i}"] for i in range(4)], 1), g._rotation.numpy())
