@@ -47,6 +47,8 @@ SIGNATURES = {
     "cgs_photometric_workspace_bytes": (C.c_size_t, [_i, _i]),
     "cgs_edge_count": (_i, [_i, _i, _i, _vp, _f, _vp, _vp]),
     "cgs_photometric_loss": (_i, [_i, _i, _vp, _vp, _f, _vp, _f, _f, _i, _vp, _vp, _vp, _vp]),
+    "cgs_endpoint_connection_workspace_bytes": (C.c_size_t, [_i]),
+    "cgs_endpoint_connection_loss": (_i, [_i, _vp, _f, _f, _vp, _vp, _vp, _i, _vp]),
     "cgs_photometric_loss_indexed": (_i, [_i, _i, _vp, _vp, _vp, _f, _vp, _f, _f, _i, _vp, _vp, _vp, _vp]),
     "cgs_curve_regularizers_workspace_bytes": (C.c_size_t, []),
     "cgs_curve_regularizers": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),

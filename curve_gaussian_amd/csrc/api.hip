@@ -733,6 +733,19 @@ int cgs_adam_step_flat_dev(int64_t n, float* params, float* grads, float* exp_av
     if (!check_launch("adam_step_flat_dev", false, (hipStream_t)stream_)) return CGS_ERR_HIP;
     return CGS_OK;
 }
+size_t cgs_endpoint_connection_workspace_bytes(int B) { return endpoint_connection_workspace_bytes(B > 0 ? B : 1); }
+int cgs_endpoint_connection_loss(int B, const float* curve_points, float distance_threshold, float weight, void* workspace,
+                                 float* loss, float* dL_dcurve_points, int accumulate, void* stream_) {
+    if (B <= 0 || !curve_points || !workspace || !loss || !dL_dcurve_points || !(distance_threshold > 0.f)) {
+        set_error("cgs_endpoint_connection_loss: invalid argument (NULL pointer, B=%d or threshold <= 0)", B);
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    hipStream_t s = (hipStream_t)stream_;
+    launch_endpoint_connection(s, B, curve_points, distance_threshold, weight, workspace, loss, dL_dcurve_points, accumulate);
+    if (!check_launch("endpoint_connection_loss", false, s)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
+
 size_t cgs_adam_state_bytes(void) { return adam_state_bytes(); }
 
 size_t cgs_knn_workspace_bytes(int P) { return knn_workspace_bytes(P); }

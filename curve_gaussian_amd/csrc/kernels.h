@@ -87,6 +87,9 @@ void launch_edge_count(hipStream_t s, int C, int HW, const float* gt, float thr,
 void launch_edge_aware_loss(hipStream_t s, int C, int H, int W, const float* image, const float* gt, float thr,
                             void* scratch16, float* grad);
 size_t curve_reg_workspace_bytes();
+size_t endpoint_connection_workspace_bytes(int B);
+void launch_endpoint_connection(hipStream_t s, int B, const float* cp, float thr, float weight, void* workspace, float* loss,
+                                float* dL_dcp, int accumulate);
 void launch_curve_regularizers(hipStream_t s, int B, int m, const float* rot_raw, const float* opacity_logit,
                                const float* width, const int* radii, float w_op, const float* op_gate, float w_smo,
                                float w_width, float width_thr, void* workspace, float* loss, float* g_rot_raw,

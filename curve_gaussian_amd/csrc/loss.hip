@@ -282,6 +282,121 @@ void launch_curve_regularizers(hipStream_t s, int B, int m, const float* rot_raw
     { ProfScope p("reg_finish", s); hipLaunchKernelGGL(k_reg_finish, dim3(1), dim3(64), 0, s, B, m, counts, sums, ra, op_gate, loss); }
 }
 
+// ------------------------------------------------------------------------------------------------ end-point connection loss
+// train.py:133-146: the 2B curve end points (B starts, then B ends), every ordered pair (i, j) of DIFFERENT curves closer
+// than dis_thr; loss = weight * mean of those distances.  The reference materialises the full (2B)^2 cdist matrix and
+// its masks (O(B^2) memory: 111 GB at B = 83 k); here every thread owns one point, sweeps all others through LDS tiles
+// and keeps count, distance sum and the direction sum  g_i = sum_j (p_i - p_j) / d_ij  in registers.  The mean's
+// denominator is only known at the end: a finish kernel scales, dL/dp_i = weight * 2 g_i / count (each unordered pair
+// appears twice in the mean; a zero distance has zero gradient, as in torch.cdist).  O(B) memory, O(B^2) distance tests
+// (a squared-distance prefilter keeps the square root and the division out of the common path).
+constexpr int CONN_SLOTS = 64;
+constexpr int CONN_JSPLIT = 8;    // the sweep over the other points is split over this many workgroups per point block
+__global__ void __launch_bounds__(256) k_conn_zero(int n_floats, float* __restrict__ g_pt,
+                                                   unsigned long long* __restrict__ cnt_slots, double* __restrict__ sum_slots) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_floats) g_pt[i] = 0.f;
+    if (i < CONN_SLOTS) { cnt_slots[i] = 0ull; sum_slots[i] = 0.0; }
+}
+__global__ void __launch_bounds__(256) k_conn_main(int B, const float* __restrict__ cp, float thr, float* __restrict__ g_pt,
+                                                   unsigned long long* __restrict__ cnt_slots, double* __restrict__ sum_slots) {
+    __shared__ float4 tile[256];
+    const int N = 2 * B;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    auto point = [&](int k) {   // k < B: first control point of curve k; else last control point of curve k - B
+        const float* q = cp + (size_t)(k < B ? k : k - B) * 12 + (k < B ? 0 : 9);
+        return make_float4(q[0], q[1], q[2], 0.f);
+    };
+    const float4 pi = i < N ? point(i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int ci = i < B ? i : i - B;
+    const float thr2 = thr * thr * 1.000001f;   // cheap prefilter on the squared distance (exact test below)
+    unsigned int cnt = 0;
+    float sum = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+    const int ntiles = (N + 255) / 256;
+    for (int tl = blockIdx.y; tl < ntiles; tl += CONN_JSPLIT) {
+        const int j0 = tl * 256;
+        const int jl = j0 + threadIdx.x;
+        __syncthreads();
+        tile[threadIdx.x] = jl < N ? point(jl) : make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+        const int jn = min(256, N - j0);
+        if (i < N) {
+            for (int t = 0; t < jn; t++) {
+                const float4 pj = tile[t];          // uniform address: LDS broadcast
+                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                const float d2 = dx * dx + dy * dy + dz * dz;
+                if (d2 < thr2) {
+                    const int j = j0 + t;
+                    const float d = sqrtf(d2);
+                    if (d < thr && (j < B ? j : j - B) != ci) {
+                        cnt++;
+                        sum += d;
+                        if (d > 0.f) {
+                            const float r = 1.0f / d;
+                            gx += dx * r; gy += dy * r; gz += dz * r;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (i < N && cnt) {   // (a pair contributes to g only if it was counted)
+        atomicAdd(&g_pt[3 * i], gx); atomicAdd(&g_pt[3 * i + 1], gy); atomicAdd(&g_pt[3 * i + 2], gz);
+    }
+    // block totals -> partial slots
+    __shared__ unsigned int s_c[4];
+    __shared__ float s_s[4];
+    unsigned int c = cnt;
+    float v = sum;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { c += __shfl_xor(c, off, 64); v += __shfl_xor(v, off, 64); }
+    if ((threadIdx.x & 63) == 0) { s_c[threadIdx.x >> 6] = c; s_s[threadIdx.x >> 6] = v; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int ct = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+        if (ct) {
+            const int slot = (blockIdx.x * CONN_JSPLIT + blockIdx.y) % CONN_SLOTS;
+            atomicAdd(&cnt_slots[slot], (unsigned long long)ct);
+            atomicAdd(&sum_slots[slot], (double)s_s[0] + (double)s_s[1] + (double)s_s[2] + (double)s_s[3]);
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_conn_finish(int B, float weight, const float* __restrict__ g_pt,
+                                                     const unsigned long long* __restrict__ cnt_slots,
+                                                     const double* __restrict__ sum_slots, float* __restrict__ loss,
+                                                     float* __restrict__ dL_dcp, int accumulate) {
+    unsigned long long c = cnt_slots[threadIdx.x & (CONN_SLOTS - 1)];
+    double s = sum_slots[threadIdx.x & (CONN_SLOTS - 1)];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { c += __shfl_xor(c, off, 64); s += __shfl_xor(s, off, 64); }
+    const double count = (double)c;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *loss = c ? (float)((double)weight * s / count) : 0.f;   // `if valid_mask.any()`
+    const float scale = c ? (float)(2.0 * (double)weight / count) : 0.f;
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    float* row = dL_dcp + (size_t)b * 12;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float gs = scale * g_pt[3 * b + k], ge = scale * g_pt[3 * (B + b) + k];
+        if (accumulate) { row[k] += gs; row[9 + k] += ge; }
+        else { row[k] = gs; row[3 + k] = 0.f; row[6 + k] = 0.f; row[9 + k] = ge; }
+    }
+}
+size_t endpoint_connection_workspace_bytes(int B) {
+    return (((size_t)6 * B * sizeof(float) + 127) & ~(size_t)127) + CONN_SLOTS * (sizeof(unsigned long long) + sizeof(double));
+}
+void launch_endpoint_connection(hipStream_t s, int B, const float* cp, float thr, float weight, void* workspace, float* loss,
+                                float* dL_dcp, int accumulate) {
+    float* g_pt = reinterpret_cast<float*>(workspace);
+    char* tail = reinterpret_cast<char*>(workspace) + (((size_t)6 * B * sizeof(float) + 127) & ~(size_t)127);
+    unsigned long long* cnt_slots = reinterpret_cast<unsigned long long*>(tail);
+    double* sum_slots = reinterpret_cast<double*>(tail + CONN_SLOTS * sizeof(unsigned long long));
+    const int N = 2 * B;
+    { ProfScope p("conn_zero", s); hipLaunchKernelGGL(k_conn_zero, dim3((3 * N + 255) / 256), dim3(256), 0, s, 3 * N, g_pt, cnt_slots, sum_slots); }
+    { ProfScope p("conn_main", s); hipLaunchKernelGGL(k_conn_main, dim3((N + 255) / 256, CONN_JSPLIT), dim3(256), 0, s, B, cp, thr, g_pt, cnt_slots, sum_slots); }
+    { ProfScope p("conn_finish", s); hipLaunchKernelGGL(k_conn_finish, dim3((B + 255) / 256), dim3(256), 0, s, B, weight, g_pt, cnt_slots, sum_slots, loss, dL_dcp, accumulate); }
+}
+
 // ------------------------------------------------------------------------------------------------ flat Adam
 // torch.optim.Adam (default, non-amsgrad, no weight decay) over ONE flat parameter buffer with per-segment learning
 // rates -- the reference steps 6 parameter groups with ~8 foreach kernels each (GaussianCurveModel.training_setup,

@@ -7,9 +7,14 @@
 
 The reference decides with host-side conditions (``visibility_filter.sum() > 0``, ``mask.any()``: a device-to-host
 sync each); here the same values come out of masked means whose denominators are clamped, so the step stays
-stream-ordered and capturable.  The O(B^2) end-point connection loss (:133-146, torch.cdist over all end points) is not
-reproduced.  These are plain torch ops: they act on per-curve / per-splat tensors once per
-iteration, outside the per-view hot path."""
+stream-ordered and capturable.
+
+  points_conn   lambda_points_conn * mean distance of end points of different curves closer than 0.05   (:133-146,
+                iteration > conn_from_iter) -- ``connection_loss_reference`` is the literal torch.cdist form (O(B^2)
+                memory, small B only: the test reference), ``connection_loss`` the O(B)-memory HIP op.
+
+The plain torch functions act on per-curve / per-splat tensors once per iteration, outside the per-view hot path; the
+fused ops replace them in the training step."""
 import torch
 import torch.nn.functional as F
 
@@ -104,3 +109,52 @@ def curve_regularizers(gaussians, radii, w_opacity=0.01, opacity_gate=1.0, w_smo
     opacity_gate: float or 0-dim device tensor (train.py's ``reset_timestep > 0``)."""
     return _CurveRegularizers.apply(gaussians._rotation, gaussians._opacity, gaussians._width, radii, gaussians.n_gaussians,
                                     w_opacity, opacity_gate, w_smooth, w_width, width_thr)
+
+
+def connection_loss_reference(gaussians, weight=0.1, dis_thr=0.05):
+    """train.py:133-146 as written (torch.cdist over all 2B end points; exact differences instead of the matmul
+    expansion cdist may pick for large inputs).  O(B^2) memory: the test reference of ``connection_loss``."""
+    curve_points = gaussians.get_curve_points
+    start_points, end_points = curve_points[:, 0], curve_points[:, -1]
+    all_points = torch.cat([start_points, end_points], dim=0)
+    mask = torch.eye(len(start_points), dtype=torch.bool, device=start_points.device)
+    mask = torch.cat([torch.cat([mask, mask], dim=1), torch.cat([mask, mask], dim=1)], dim=0)
+    dist = torch.cdist(all_points, all_points, p=2, compute_mode="donot_use_mm_for_euclid_dist")
+    with torch.no_grad():
+        valid_mask = (dist < dis_thr) & (~mask)
+    if valid_mask.any():
+        return weight * dist[valid_mask].mean()
+    return dist.sum() * 0.0
+
+
+class _ConnectionLoss(torch.autograd.Function):
+    """cgs_endpoint_connection_loss: value and gradient in one sweep, O(B) memory."""
+
+    @staticmethod
+    def forward(ctx, curve_points, weight, dis_thr):
+        _L.require_gpu_tensor(curve_points, "curve_points")
+        lib = _L.load()
+        dev = curve_points.device
+        cp = curve_points.detach().float().contiguous()
+        B = cp.shape[0]
+        with _L.device_guard(dev):
+            ws = torch.empty(int(lib.cgs_endpoint_connection_workspace_bytes(B)), dtype=torch.uint8, device=dev)
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+            grad = torch.empty_like(cp)
+            rc = lib.cgs_endpoint_connection_loss(B, _L.ptr(cp), _C.c_float(dis_thr), _C.c_float(weight), _L.ptr(ws),
+                                                  _L.ptr(loss), _L.ptr(grad), 0, _L.raw_stream(dev))
+            _L.check(rc, "cgs_endpoint_connection_loss")
+        ctx.save_for_backward(grad)
+        ctx.shape = curve_points.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        from .losses import scale_by_upstream as sc
+        return sc(grad, g).view(ctx.shape), None, None
+
+
+def connection_loss(gaussians, weight=0.1, dis_thr=0.05):
+    """lambda_points_conn * mean distance between end points of different curves closer than `dis_thr` (train.py:133-146)."""
+    return _ConnectionLoss.apply(gaussians._curve_points, float(weight), float(dis_thr))

@@ -19,7 +19,8 @@ from .view_parallel import FlatGrads, StaticCamera as _StaticCamera
 class TrainStep:
     def __init__(self, gaussians, cameras, gt_images, lambda_mse=10.0, lambda_dssim=0.1, lambda_mask=0.0005,
                  densify_until_iter=7000, mask_threshold=0.01, seed=0, rank=0, world=1, fused=True,
-                 regularisers=False, opacity_loss_weight=0.01, lambda_curve_smo=0.1, lambda_width=0.01):
+                 regularisers=False, opacity_loss_weight=0.01, lambda_curve_smo=0.1, lambda_width=0.01,
+                 lambda_points_conn=0.1, conn_from_iter=7000):
         self.g = gaussians
         self.cams = cameras
         self.gts = gt_images                      # list of [1,H,W] edge maps on the device
@@ -28,6 +29,8 @@ class TrainStep:
         # train.py:113-131 (off by default: the BASELINE train-step metric excludes them)
         self.regularisers = regularisers
         self.opacity_loss_weight, self.lambda_curve_smo, self.lambda_width = opacity_loss_weight, lambda_curve_smo, lambda_width
+        # train.py:133-146: end-point connection loss, from iteration conn_from_iter + 1 on (part of `regularisers`)
+        self.lambda_points_conn, self.conn_from_iter = lambda_points_conn, conn_from_iter
         self.reset_timestep = 0    # train.py:113: the opacity term is active after an opacity reset
         self.pipe = PipelineParams()
         self.bg = torch.zeros(3, device=gaussians.device)
@@ -58,18 +61,27 @@ class TrainStep:
         else:
             self.flat = FlatGrads(named)
 
-    def _regulariser_terms(self, radii, opacity_gate):
-        """train.py:113-131; opacity_gate (float or device scalar) switches the opacity term (reset_timestep > 0)."""
+    def _conn_active(self, iteration):
+        """train.py:133: `opt.lambda_points_conn > 0 and iteration > opt.conn_from_iter`."""
+        return self.regularisers and self.lambda_points_conn > 0 and iteration > self.conn_from_iter
+
+    def _regulariser_terms(self, radii, opacity_gate, with_conn=False):
+        """train.py:113-146; opacity_gate (float or device scalar) switches the opacity term (reset_timestep > 0)."""
         from .ops import regularizers as RG
         g = self.g
         if self.fused:   # one HIP op (three launches)
-            return RG.curve_regularizers(g, radii, self.opacity_loss_weight, opacity_gate, self.lambda_curve_smo,
-                                         self.lambda_width)
+            reg = RG.curve_regularizers(g, radii, self.opacity_loss_weight, opacity_gate, self.lambda_curve_smo,
+                                        self.lambda_width)
+            if with_conn:
+                reg = reg + RG.connection_loss(g, self.lambda_points_conn)
+            return reg
         reg = RG.opacity_loss(g, radii, self.opacity_loss_weight) * opacity_gate
         if self.lambda_curve_smo > 0:
             reg = reg + RG.curve_smoothness_loss(g, radii, self.lambda_curve_smo)
         if self.lambda_width > 0:
             reg = reg + RG.width_loss(g, self.lambda_width)
+        if with_conn:
+            reg = reg + RG.connection_loss_reference(g, self.lambda_points_conn)
         return reg
 
     def _next_view(self):
@@ -97,7 +109,8 @@ class TrainStep:
         if use_mask:
             loss = loss + self.lambda_mask * torch.mean(torch.sigmoid(g._mask))
         if self.regularisers:
-            loss = loss + self._regulariser_terms(pkg["radii"], 1.0 if self.reset_timestep > 0 else 0.0)
+            loss = loss + self._regulariser_terms(pkg["radii"], 1.0 if self.reset_timestep > 0 else 0.0,
+                                                  with_conn=self._conn_active(self.iteration))
         loss.backward(gradient=unit_grad(loss.device) if self.fused else None)
         self.flat.all_reduce()
         if self.fused:
@@ -176,6 +189,7 @@ class GraphedTrainStep(TrainStep):
         self._loss = None
         self._status = None
         self._use_mask = False
+        self._use_conn = False      # graph constant like _use_mask: the switch at conn_from_iter re-captures
         self._flag_host = torch.zeros(64, dtype=torch.int32).pin_memory()
         self._inflight = []   # (event, slot, view index, iteration)
         self.recaptures = 0
@@ -197,7 +211,7 @@ class GraphedTrainStep(TrainStep):
         if self._use_mask:      # train.py:110-111 (a graph constant: the switch at densify_until_iter re-captures)
             loss = loss + self.lambda_mask * torch.mean(torch.sigmoid(g._mask))
         if self.regularisers:   # sync-free torch ops; the opacity term is gated by a device scalar refreshed per step
-            loss = loss + self._regulariser_terms(pkg["radii"], self._opa_gate)
+            loss = loss + self._regulariser_terms(pkg["radii"], self._opa_gate, with_conn=self._use_conn)
         loss.backward(gradient=unit_grad(loss.device))
         status = sink[0]
         g.optimizer.step_dev(zero_grad=True, skip_flag=status[2:3])
@@ -246,6 +260,8 @@ class GraphedTrainStep(TrainStep):
         b["reg_loss"] = torch.zeros((), dtype=torch.float32, device=dev)
         b["r_rot"], b["r_op"], b["r_w"] = f(P, 4), f(B, 1), f(B, 1)
         b["mask_loss"] = torch.zeros((), dtype=torch.float32, device=dev)
+        b["conn_ws"] = torch.zeros(int(lib.cgs_endpoint_connection_workspace_bytes(B)), dtype=torch.uint8, device=dev)
+        b["conn_loss"] = torch.zeros((), dtype=torch.float32, device=dev)
         b["bg"] = self.bg.float().contiguous()
         self._bufs = b
         return b
@@ -310,6 +326,11 @@ class GraphedTrainStep(TrainStep):
                                            p(grads.view("width")), p(b["gv"]), s), "sample_curves_backward")
         if self.regularisers:
             grads.view("width").add_(b["r_w"])
+            if self._use_conn:   # adds to the curve-point gradient the sampling backward just wrote
+                chk(lib.cgs_endpoint_connection_loss(B, p(cp), cf(0.05), cf(self.lambda_points_conn), p(b["conn_ws"]),
+                                                     p(b["conn_loss"]), p(grads.view("curve_points")), 1, s),
+                    "endpoint_connection_loss")
+                loss = loss + b["conn_loss"]
         if self._use_mask:      # train.py:110-111: lambda_mask * mean(sigmoid(mask)), gradient added by hand
             sg = torch.sigmoid(mask)
             loss = loss + self.lambda_mask * sg.mean()
@@ -435,9 +456,10 @@ class GraphedTrainStep(TrainStep):
     def step(self, view_index=None):
         g = self.g
         use_mask = self.iteration + 1 >= self.densify_until_iter
-        if use_mask != self._use_mask:                      # mask phase starts: straight-through mask + mask loss
+        use_conn = self._conn_active(self.iteration + 1)
+        if use_mask != self._use_mask or use_conn != self._use_conn:   # a phase of train.py starts: re-capture
             self.finish()
-            self._use_mask = use_mask
+            self._use_mask, self._use_conn = use_mask, use_conn
             self._graph = None
         self._check_overflow()
         self.iteration += 1

@@ -205,6 +205,16 @@ int cgs_photometric_loss_indexed(int height, int width, const float* image, cons
                                  float threshold, const uint32_t* n_pos_table, float lambda_edge, float lambda_ssim,
                                  int clamp_input, void* workspace, float* dL_dimage, float* loss, void* stream);
 
+/* End-point connection loss of /root/reference/train.py:133-146 (active after opt.conn_from_iter): over the 2B curve end
+ * points (first and last control point of every curve), loss = weight * mean distance of all ordered pairs of DIFFERENT
+ * curves closer than distance_threshold (0.05 in the reference); 0 when there is no such pair.  The reference builds the
+ * (2B)^2 cdist matrix; this is O(B) memory and O(B^2) distance tests in one pass.  curve_points [B,4,3].
+ * dL_dcurve_points [B,4,3]: accumulate != 0 adds the gradient to the rows 0 and 3 (the other rows are untouched),
+ * accumulate == 0 writes the whole tensor (rows 1, 2 zero).  workspace: cgs_endpoint_connection_workspace_bytes(B). */
+size_t cgs_endpoint_connection_workspace_bytes(int B);
+int cgs_endpoint_connection_loss(int B, const float* curve_points, float distance_threshold, float weight, void* workspace,
+                                 float* loss, float* dL_dcurve_points, int accumulate, void* stream);
+
 /* The per-iteration regularisers of /root/reference/train.py:113-131 (PyTorch ops over all P splats in the reference),
  * value and gradients in three launches:
  *   loss = w_opacity * gate * mean_{splats with radii > 0} log(1 + sigmoid(opacity_logit[b])^2 / 0.5)

@@ -472,3 +472,55 @@ def test_bench_two_rank_control_flow_rehearsal():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 8 and out["value"] > 0
     assert "roofline" in out and out["config"]["parallelism"] == "view-parallel x2"
+
+
+def test_connection_loss_matches_the_reference_block():
+    """cgs_endpoint_connection_loss (O(B) memory, one sweep) against train.py:133-146 written out with torch.cdist:
+    value, gradient w.r.t. the control points (only first and last points receive one), the no-pair case, and end points
+    that coincide exactly (zero distance: counted, zero gradient)."""
+    from curve_gaussian_amd.ops import regularizers as RG
+
+    class G:
+        pass
+    g = torch.Generator().manual_seed(12)
+    for B, spread in ((700, 0.25), (257, 0.12), (40, 5.0)):
+        cp = (torch.rand(B, 4, 3, generator=g) * spread).to(DEV)
+        if B == 257:
+            cp[5, 0] = cp[9, 3]                     # coincident end points of different curves
+            cp[7, 3] = cp[7, 0]                     # a closed curve: same-curve pairs are excluded
+        a, b = G(), G()
+        a._curve_points = cp.clone().requires_grad_(True)
+        a.get_curve_points = a._curve_points
+        b._curve_points = cp.clone().requires_grad_(True)
+        ref = RG.connection_loss_reference(a, 0.1)
+        ref.backward()
+        val = RG.connection_loss(b, 0.1)
+        (3.0 * val).backward()
+        if B == 40:
+            assert float(ref) == 0.0 and float(val) == 0.0 and not bool(b._curve_points.grad.any())
+            continue
+        assert float(ref) > 0
+        np.testing.assert_allclose(float(val), float(ref), rtol=2e-5)
+        np.testing.assert_allclose(b._curve_points.grad.cpu().numpy(), 3.0 * a._curve_points.grad.cpu().numpy(),
+                                   rtol=2e-4, atol=1e-8)
+        assert not bool(b._curve_points.grad[:, 1:3].any())
+
+
+def test_graphed_train_step_crosses_the_connection_phase():
+    """After conn_from_iter the end-point connection loss joins the regularisers (train.py:133); the graphed step
+    re-captures at the switch and keeps following the eager trajectory (which uses the same fused op)."""
+    from curve_gaussian_amd.train_step import GraphedTrainStep, TrainStep
+    torch.manual_seed(0); ga, cams, gts = _train_fixture()
+    torch.manual_seed(0); gb, _, _ = _train_fixture()
+    kw = dict(seed=8, regularisers=True, conn_from_iter=4, lambda_points_conn=0.1)
+    ea = TrainStep(ga, cams, gts, **kw)
+    gs = GraphedTrainStep(gb, cams, gts, **kw)
+    for _ in range(9):
+        la = ea.step()[0]
+        lb = gs.step()[0]
+    gs.finish()
+    assert gs.recaptures == 2 and gs._use_conn
+    np.testing.assert_allclose(float(lb), float(la), rtol=1e-4)
+    for n in ("_curve_points", "_width", "_opacity"):
+        np.testing.assert_allclose(getattr(gb, n).detach().cpu().numpy(), getattr(ga, n).detach().cpu().numpy(),
+                                   rtol=1e-3, atol=1e-5, err_msg=n)
