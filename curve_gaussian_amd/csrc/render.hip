@@ -43,10 +43,7 @@ __device__ __forceinline__ StepConsts step_consts() {
     asm volatile("" : "+v"(k.big), "+v"(k.cA), "+v"(k.nbig), "+v"(k.one), "+v"(k.nbig100), "+v"(k.cT));
     return k;
 }
-#ifndef CGS_SLOTS
-#define CGS_SLOTS 8
-#endif
-constexpr int SLOTS = CGS_SLOTS;  // accepted splats buffered per wave between two splat-parallel moment passes (8 or 16)
+constexpr int SLOTS = 8;          // accepted splats buffered per wave between two splat-parallel moment passes
 constexpr int SLOT_STRIDE = 65;   // +1 pad: lane (s,q) reads s_g[s][16q+p] -> bank (s + 16q + p) % 32, conflict-free
 
 struct TileGeom {
@@ -521,11 +518,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(
                 if (slot < n && f < NF) {
                     const float v = s_t[g.wave][slot][f];
                     const uint32_t id = __float_as_uint(s_t[g.wave][slot][15]);
-#ifdef CGS_EXP_NOATOMIC
-                    if (v == 123.456f)
-#else
                     if (v != 0.f)
-#endif
                         atomicAdd(grad_acc + (size_t)id * ACC_STRIDE + f, v);
                 }
             }
