@@ -66,6 +66,9 @@ static void update_max_hint(uint32_t longest) {
     const int64_t decayed = old - old / 16;
     g_max_hint.store(std::max<int64_t>((int64_t)longest, decayed), std::memory_order_relaxed);
 }
+// Splats with oversized tile rects seen by the previous blocking forward: non-zero switches their deferral to
+// k_scatter_big on (one more launch, only worth it when there are any -- room-scale scenes with near-camera splats).
+static std::atomic<int64_t> g_big_hint{0};
 static thread_local int64_t g_last_stats[3] = {0, 0, 0};  // num_rendered, longest tile list, binning path (0 exact, 1 bucket)
 
 // Device-side zero fill.  hipMemsetAsync is NOT used anywhere in the library: captured into a hipGraph (ROCm 7.0 runtime
@@ -130,6 +133,7 @@ size_t cgs_binning_bytes(int64_t R) {
 void cgs_reset_binning_hints(void) {
     g_R_hint.store(0, std::memory_order_relaxed);
     g_max_hint.store(0, std::memory_order_relaxed);
+    g_big_hint.store(0, std::memory_order_relaxed);
 }
 int cgs_set_tile_culling(int on) {
     return g_tile_cull.exchange(on ? 1 : 0, std::memory_order_relaxed);
@@ -277,7 +281,9 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
                 return CGS_ERR_ALLOC;
             }
             BinState bin = bin_from_chunk(bchunk, (size_t)(cap * tiles));
-            launch_scatter_bucket(s, P, radii, geom.rec, gx, gy, img.tile_count, bin.keys, (uint32_t)cap, cull);
+            const bool defer_big = g_big_hint.load(std::memory_order_relaxed) > 0;
+            launch_scatter_bucket(s, P, radii, geom.rec, gx, gy, img.tile_count, bin.keys, (uint32_t)cap, cull, img.total + 3,
+                                  defer_big ? img.tile_cursor : nullptr, (uint32_t)tiles);   // (cursors: unused here)
             // (the fused sort+composite kernel is for the sync-free forward only: here num_rendered has to come back to
             // the host, and with the separate sort kernel that readback overlaps the compositor instead of following it)
             launch_tile_sort_bucket(s, tiles, img.tile_count, img.ranges, img.total, bin.keys, bin.point_list, (uint32_t)cap);
@@ -291,6 +297,7 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
                 longest = std::max(longest, h_tot[5 + 2 * k]);
             }
             update_max_hint(longest);
+            g_big_hint.store((int64_t)h_tot[3], std::memory_order_relaxed);
             if ((uint64_t)longest <= cap) {
                 g_R_hint.store(Rb, std::memory_order_relaxed);
                 g_last_stats[0] = Rb; g_last_stats[1] = (int64_t)longest; g_last_stats[2] = 1;
@@ -410,7 +417,9 @@ int cgs_rasterize_forward_static(void* geometry_buffer, void* binning_buffer, si
                           cov3D_precomp, colors_precomp, render_geo ? all_map : nullptr, viewmatrix, projmatrix, cam_pos,
                           width, height, tan_fovx, tan_fovy, focal_x, focal_y, radii, geom.rec, geom.rgb, gx, gy, nullptr,
                           antialiasing, 1, geom.grad_acc, img.tile_count, clear_bytes / sizeof(uint32_t));
-    launch_scatter_bucket(s, P, radii, geom.rec, gx, gy, img.tile_count, bin.keys, (uint32_t)cap, 1);
+    const bool defer_big = g_big_hint.load(std::memory_order_relaxed) > 0;   // (from the caller's probing forwards)
+    launch_scatter_bucket(s, P, radii, geom.rec, gx, gy, img.tile_count, bin.keys, (uint32_t)cap, 1, img.total + 3,
+                          defer_big ? img.tile_cursor : nullptr, (uint32_t)tiles);
     if (render_fwd_can_sort((uint32_t)cap) && fuse_sort()) {
         launch_render_fwd_sorting(s, render_geo != 0, tiles, img.tile_count, bin.keys, (uint32_t)cap, img.ranges, img.total,
                                   bin.point_list, width, height, gx, geom.rec, img.final_T, img.n_contrib, background,

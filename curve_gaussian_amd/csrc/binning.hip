@@ -290,17 +290,30 @@ __device__ __forceinline__ void wave_lds_fence() {  // same-wave LDS hand-off: t
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// Splats whose rect holds more than BIG_TILES tiles (a near-camera splat of a room-scale scene can cover the whole screen:
+// 3 225 tiles at cfg4) would keep one wave walking for tens of microseconds -- and the splats of one curve are neighbours,
+// so a wave tends to hold eight of them: the kernel's tail (54 us at cfg4 for 165 k instances).  They are counted in
+// big_count and, when the caller passes a queue, deferred to k_scatter_big (one workgroup per splat).
+constexpr uint32_t BIG_TILES = 96;
 __global__ void __launch_bounds__(256) k_scatter_grouped(int P, const int* __restrict__ radii,
                                                          const SplatRec* __restrict__ rec, int grid_x, int grid_y,
                                                          uint32_t* __restrict__ tile_count, uint64_t* __restrict__ keys,
-                                                         uint32_t cap, int cull) {
+                                                         uint32_t cap, int cull, uint32_t* __restrict__ big_count,
+                                                         uint32_t* __restrict__ big_queue, uint32_t big_cap) {
     __shared__ uint32_t s_sk[4][GS_LCAP + RANK_U];
     __shared__ uint64_t s_key[4][GS_LCAP];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* wsk = s_sk[wave];
     uint64_t* wkey = s_key[wave];
     const int idx = (blockIdx.x * 4 + (int)wave) * GS_SPW + (int)lane;
-    const SplatWalk me = load_splat_walk((int)lane < GS_SPW, idx, P, radii, rec, grid_x, grid_y);
+    SplatWalk me = load_splat_walk((int)lane < GS_SPW, idx, P, radii, rec, grid_x, grid_y);
+    if (me.nt > BIG_TILES) {
+        const uint32_t q = atomicAdd(big_count, 1u);       // (also the statistic that switches the queue on, see api.hip)
+        if (big_queue && q < big_cap) {
+            big_queue[q] = (uint32_t)idx;
+            me.nt = 0u;                                    // handled by k_scatter_big
+        }
+    }
     // ---- A: collect the (tile, key) instances of this wave's splats (cnt stays wave-uniform)
     uint32_t cnt = 0;
     quad_walk(me, grid_x, cull, [&](bool pass, uint32_t tile, uint64_t key) {
@@ -356,6 +369,34 @@ __global__ void __launch_bounds__(256) k_scatter_grouped(int P, const int* __res
         base = (uint32_t)__shfl((int)base, (int)hl, 64);
         const uint32_t slot = base + (lane - hl);
         if (valid && slot < cap) keys[(size_t)tile * cap + slot] = wkey[j];
+    }
+}
+
+// One workgroup per deferred splat: 256 tiles of its rect per step, one atomic per instance (its instances all fall into
+// different tiles: nothing to group).
+__global__ void __launch_bounds__(256) k_scatter_big(const uint32_t* __restrict__ big_count,
+                                                     const uint32_t* __restrict__ big_queue, uint32_t big_cap,
+                                                     const int* __restrict__ radii, const SplatRec* __restrict__ rec,
+                                                     int grid_x, int grid_y, uint32_t* __restrict__ tile_count,
+                                                     uint64_t* __restrict__ keys, uint32_t cap, int cull) {
+    const uint32_t n = min(*big_count, big_cap);
+    for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+        const int idx = (int)big_queue[e];
+        const float4 a = rec[idx].a;
+        const float4 d = rec[idx].d;
+        const float C = rec[idx].b.x;
+        uint2 rmin, rmax;
+        get_rect(a.x, a.y, radii[idx], grid_x, grid_y, rmin, rmax);
+        const uint32_t w = max(rmax.x - rmin.x, 1u), nt = (rmax.x - rmin.x) * (rmax.y - rmin.y);
+        const uint64_t key = ((uint64_t)__float_as_uint(d.x) << 32) | (uint32_t)idx;
+        for (uint32_t t = threadIdx.x; t < nt; t += 256) {
+            const uint32_t ty = t / w, tx = t - ty * w;
+            const uint32_t gxx = rmin.x + tx, gyy = rmin.y + ty;
+            if (cull && !tile_reach_det(a.x, a.y, a.z, a.w, C, d.z, (float)(gxx * TILE), (float)(gyy * TILE))) continue;
+            const uint32_t tile = gyy * (uint32_t)grid_x + gxx;
+            const uint32_t slot = atomicAdd(&tile_count[tile], 1u);
+            if (slot < cap) keys[(size_t)tile * cap + slot] = key;
+        }
     }
 }
 
@@ -463,15 +504,17 @@ void launch_tile_sort_big(hipStream_t s, int tiles, const uint2* ranges, uint64_
 // Single-pass bucket binning: scatter straight into fixed-capacity tile buckets, then sort each bucket and publish
 // ranges / num_rendered / longest list / overflow flag from the sort kernel.
 void launch_scatter_bucket(hipStream_t s, int P, const int* radii, const SplatRec* rec, int grid_x, int grid_y,
-                           uint32_t* tile_count, uint64_t* keys, uint32_t cap, int cull) {
+                           uint32_t* tile_count, uint64_t* keys, uint32_t cap, int cull, uint32_t* big_count,
+                           uint32_t* big_queue, uint32_t big_cap) {
     ProfScope p("scatter", s);
-#ifndef CGS_NO_GROUP
     if ((int64_t)grid_x * grid_y < (1 << 24)) {  // the grouping key packs the tile index into 24 bits
         hipLaunchKernelGGL(k_scatter_grouped, dim3((P + 4 * GS_SPW - 1) / (4 * GS_SPW)), dim3(256), 0, s, P, radii, rec,
-                           grid_x, grid_y, tile_count, keys, cap, cull);
+                           grid_x, grid_y, tile_count, keys, cap, cull, big_count, big_queue, big_cap);
+        if (big_queue)
+            hipLaunchKernelGGL(k_scatter_big, dim3(512), dim3(256), 0, s, big_count, big_queue, big_cap, radii, rec, grid_x,
+                               grid_y, tile_count, keys, cap, cull);
         return;
     }
-#endif
     hipLaunchKernelGGL(k_scatter_quad, dim3((P + 4 * QW_SPW - 1) / (4 * QW_SPW)), dim3(256), 0, s, P, radii, rec, grid_x,
                        grid_y, tile_count, keys, cap, cull);
 }

@@ -29,8 +29,11 @@ void launch_scan_tiles(hipStream_t s, int tiles, const uint32_t* tile_count, uin
 // `cap` = number of instances the binning buffer can hold: tiles whose range does not fit are skipped (speculative launch)
 void launch_scatter(hipStream_t s, int P, const int* radii, const SplatRec* rec, int grid_x, int grid_y,
                     const uint2* ranges, uint32_t* tile_cursor, uint64_t* keys, uint32_t cap, int cull);
+// big_count: status word counting the splats whose rect exceeds the wave walk's comfort zone; big_queue (nullable,
+// big_cap entries): where they are deferred to for a one-workgroup-per-splat second kernel
 void launch_scatter_bucket(hipStream_t s, int P, const int* radii, const SplatRec* rec, int grid_x, int grid_y,
-                           uint32_t* tile_count, uint64_t* keys, uint32_t cap, int cull);
+                           uint32_t* tile_count, uint64_t* keys, uint32_t cap, int cull, uint32_t* big_count,
+                           uint32_t* big_queue, uint32_t big_cap);
 void launch_tile_sort_bucket(hipStream_t s, int tiles, const uint32_t* tile_count, uint2* ranges, uint32_t* total,
                              uint64_t* keys, uint32_t* point_list, uint32_t cap);
 uint32_t bucket_cap_limit();

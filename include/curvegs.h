@@ -284,7 +284,10 @@ int cgs_set_tile_culling(int on);
  * Status words (u32) at byte offset cgs_image_status_offset(W, H) of the image buffer, valid in stream order:
  *   [2] != 0: some tile list outgrew its bucket -> the image and every gradient of this forward are INVALID (redo it
  *       with cgs_rasterize_forward or a larger capacity); [4 + 2k], [5 + 2k], k < (cgs_status_words() - 4) / 2:
- *       partial sums / maxima of the tile list lengths (num_rendered = sum of the sums, longest list = max of maxima).
+ *       partial sums / maxima of the tile list lengths (num_rendered = sum of the sums, longest list = max of maxima);
+ *   [3]: number of splats whose tile rectangle exceeds 96 tiles (near-camera splats of room-scale scenes).  When a
+ *       previous cgs_rasterize_forward on this process saw any, such splats are binned by a second kernel, one workgroup
+ *       each, instead of inside the wave that owns them (cgs_reset_binning_hints clears that memory too).
  * The backward is cgs_rasterize_backward with R = 1.
  * ------------------------------------------------------------------------------------------------ */
 int cgs_rasterize_forward_static(void* geometry_buffer, void* binning_buffer, size_t binning_bytes, void* image_buffer,

@@ -261,10 +261,18 @@ def test_tile_culling_drops_only_invisible_instances(case):
         assert stats[2] == 0 and stats[1] > 4096, stats
     assert R == first[0] and torch.equal(color, first[1]) and torch.equal(radii, first[2])
     assert torch.equal(invd, first[6]) and torch.equal(amap, first[7]), "both binning layouts must render identically"
+    # 3rd call: splats with oversized tile rects (seen and counted by the 2nd) are now deferred to their own kernel
+    third = _raster_raw(sp, cam, H, W, dev)
+    assert third[0] == R and torch.equal(third[1], color) and torch.equal(third[6], invd) and torch.equal(third[7], amap)
+    t_ranges, t_list, _, _ = _decode_state(third[3], third[4], third[5], P, H, W, R)
     assert 0 < R <= fw.num_rendered
     ranges, point_list, n_contrib, final_T = _decode_state(geomB, binB, imgB, P, H, W, R)
     lens = (ranges[:, 1] - ranges[:, 0]).astype(np.int64)
     assert lens.sum() == R
+    assert ((t_ranges[:, 1] - t_ranges[:, 0]) == lens).all()   # (bucket bases may differ: the capacity follows the hints)
+    for t in range(len(lens)):
+        assert (t_list[t_ranges[t, 0]:t_ranges[t, 1]] == point_list[ranges[t, 0]:ranges[t, 1]]).all(), \
+            "deferred big splats must bin identically"
     ref_ranges, ref_list = fw.ranges, fw.point_list
     xy = fw.means2D.astype(np.float64)
     co = fw.conic_opacity.astype(np.float64)
