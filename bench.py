@@ -520,6 +520,22 @@ def main():
         gr.finish()
         torch.cuda.synchronize()
         out["train_step_with_regularisers_ms"] = round((time.perf_counter() - tt0) / n_gs * 1e3, 4)
+        # the late phase of train.py (iteration > 7000): straight-through curve mask + mask loss + every regulariser
+        # including the end-point connection loss (O(B^2) memory in the reference, a hashed grid here)
+        gm4 = GaussianCurveModel(0, m, device=dev).create_from_curves(curves["curve_points"], curves["width"],
+                                                                      curves["opacity"], curves["mask"],
+                                                                      curves["is_bezier"])
+        gl = GraphedTrainStep(gm4, tcams, gts, regularisers=True, densify_until_iter=0, conn_from_iter=0)
+        for _ in range(3):
+            gl.step()
+        gl.finish()
+        torch.cuda.synchronize()
+        tt0 = time.perf_counter()
+        for _ in range(n_gs):
+            gl.step()
+        gl.finish()
+        torch.cuda.synchronize()
+        out["train_step_late_phase_ms"] = round((time.perf_counter() - tt0) / n_gs * 1e3, 4)
         out["train_step_ms"] = round(graph_ms, 4)
         out["train_step_eager_ms"] = round(eager_ms, 4)
         out["train_step_graph_recaptures"] = gs.recaptures

@@ -285,63 +285,74 @@ void launch_curve_regularizers(hipStream_t s, int B, int m, const float* rot_raw
 // ------------------------------------------------------------------------------------------------ end-point connection loss
 // train.py:133-146: the 2B curve end points (B starts, then B ends), every ordered pair (i, j) of DIFFERENT curves closer
 // than dis_thr; loss = weight * mean of those distances.  The reference materialises the full (2B)^2 cdist matrix and
-// its masks (O(B^2) memory: 111 GB at B = 83 k); here every thread owns one point, sweeps all others through LDS tiles
-// and keeps count, distance sum and the direction sum  g_i = sum_j (p_i - p_j) / d_ij  in registers.  The mean's
+// its masks (O(B^2) memory: 111 GB at B = 83 k); here every thread owns one point, finds its neighbours on a hashed
+// uniform grid and keeps count, distance sum and the direction sum  g_i = sum_j (p_i - p_j) / d_ij  in registers.  The mean's
 // denominator is only known at the end: a finish kernel scales, dL/dp_i = weight * 2 g_i / count (each unordered pair
-// appears twice in the mean; a zero distance has zero gradient, as in torch.cdist).  O(B) memory, O(B^2) distance tests
-// (a squared-distance prefilter keeps the square root and the division out of the common path).
+// appears twice in the mean; a zero distance has zero gradient, as in torch.cdist).
 constexpr int CONN_SLOTS = 64;
-constexpr int CONN_JSPLIT = 8;    // the sweep over the other points is split over this many workgroups per point block
-__global__ void __launch_bounds__(256) k_conn_zero(int n_floats, float* __restrict__ g_pt,
-                                                   unsigned long long* __restrict__ cnt_slots, double* __restrict__ sum_slots) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n_floats) g_pt[i] = 0.f;
-    if (i < CONN_SLOTS) { cnt_slots[i] = 0ull; sum_slots[i] = 0.0; }
+// Neighbour search on a hashed uniform grid: cells of edge dis_thr (+0.01 %: two points closer than dis_thr then differ by
+// at most one cell per axis whatever the rounding), every point in the linked list of its cell's hash bucket; a query visits
+// the 27 cells around its own and tests the points of those buckets whose cell really is the visited one (hash collisions
+// only add candidates; a bucket shared by two visited cells is not counted twice).  O(B) time and memory.
+struct ConnGrid { float inv_cell; uint32_t mask; };
+__device__ __forceinline__ int3 conn_cell(float x, float y, float z, float inv_cell) {
+    return make_int3((int)floorf(x * inv_cell), (int)floorf(y * inv_cell), (int)floorf(z * inv_cell));
 }
-__global__ void __launch_bounds__(256) k_conn_main(int B, const float* __restrict__ cp, float thr, float* __restrict__ g_pt,
-                                                   unsigned long long* __restrict__ cnt_slots, double* __restrict__ sum_slots) {
-    __shared__ float4 tile[256];
-    const int N = 2 * B;
+__device__ __forceinline__ uint32_t conn_hash(int3 c, uint32_t mask) {
+    return ((uint32_t)c.x * 73856093u ^ (uint32_t)c.y * 19349663u ^ (uint32_t)c.z * 83492791u) & mask;
+}
+__device__ __forceinline__ float4 conn_point(const float* __restrict__ cp, int B, int k) {
+    // k < B: first control point of curve k; else last control point of curve k - B
+    const float* q = cp + (size_t)(k < B ? k : k - B) * 12 + (k < B ? 0 : 9);
+    return make_float4(q[0], q[1], q[2], 0.f);
+}
+// one launch initialises the workspace: list heads = ~0 (empty), partial slots and per-point direction sums = 0
+__global__ void __launch_bounds__(256) k_conn_init(size_t n_zero, uint32_t* __restrict__ zero, size_t n_heads,
+                                                   uint32_t* __restrict__ heads) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_zero; i += stride) zero[i] = 0u;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_heads; i += stride) heads[i] = ~0u;
+}
+// bucket = singly linked list through `next`, built with one atomic exchange per point (no count / scan / fill passes)
+__global__ void __launch_bounds__(256) k_conn_build(int B, const float* __restrict__ cp, ConnGrid g,
+                                                    uint32_t* __restrict__ heads, uint32_t* __restrict__ next) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    auto point = [&](int k) {   // k < B: first control point of curve k; else last control point of curve k - B
-        const float* q = cp + (size_t)(k < B ? k : k - B) * 12 + (k < B ? 0 : 9);
-        return make_float4(q[0], q[1], q[2], 0.f);
-    };
-    const float4 pi = i < N ? point(i) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const int ci = i < B ? i : i - B;
-    const float thr2 = thr * thr * 1.000001f;   // cheap prefilter on the squared distance (exact test below)
+    if (i >= 2 * B) return;
+    const float4 p = conn_point(cp, B, i);
+    next[i] = atomicExch(&heads[conn_hash(conn_cell(p.x, p.y, p.z, g.inv_cell), g.mask)], (uint32_t)i);
+}
+// one thread per (point, neighbour cell): 27 N short independent list walks instead of N long dependent ones
+__global__ void __launch_bounds__(256) k_conn_main(int B, const float* __restrict__ cp, float thr, ConnGrid g,
+                                                   const uint32_t* __restrict__ heads, const uint32_t* __restrict__ next,
+                                                   float* __restrict__ g_pt, unsigned long long* __restrict__ cnt_slots,
+                                                   double* __restrict__ sum_slots) {
+    const int N = 2 * B;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     unsigned int cnt = 0;
     float sum = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
-    const int ntiles = (N + 255) / 256;
-    for (int tl = blockIdx.y; tl < ntiles; tl += CONN_JSPLIT) {
-        const int j0 = tl * 256;
-        const int jl = j0 + threadIdx.x;
-        __syncthreads();
-        tile[threadIdx.x] = jl < N ? point(jl) : make_float4(0.f, 0.f, 0.f, 0.f);
-        __syncthreads();
-        const int jn = min(256, N - j0);
-        if (i < N) {
-            for (int t = 0; t < jn; t++) {
-                const float4 pj = tile[t];          // uniform address: LDS broadcast
-                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-                const float d2 = dx * dx + dy * dy + dz * dz;
-                if (d2 < thr2) {
-                    const int j = j0 + t;
-                    const float d = sqrtf(d2);
-                    if (d < thr && (j < B ? j : j - B) != ci) {
-                        cnt++;
-                        sum += d;
-                        if (d > 0.f) {
-                            const float r = 1.0f / d;
-                            gx += dx * r; gy += dy * r; gz += dz * r;
-                        }
-                    }
+    const int i = (int)(t / 27);
+    if (i < N) {
+        const int k = (int)(t - (long long)i * 27);
+        const float4 pi = conn_point(cp, B, i);
+        const int ci = i < B ? i : i - B;
+        const int3 c0 = conn_cell(pi.x, pi.y, pi.z, g.inv_cell);
+        const int3 c = make_int3(c0.x + k % 3 - 1, c0.y + (k / 3) % 3 - 1, c0.z + k / 9 - 1);
+        for (uint32_t j = heads[conn_hash(c, g.mask)]; j != ~0u; j = next[j]) {
+            const float4 pj = conn_point(cp, B, (int)j);
+            const int3 cj = conn_cell(pj.x, pj.y, pj.z, g.inv_cell);
+            if (cj.x != c.x || cj.y != c.y || cj.z != c.z) continue;     // another cell of this bucket
+            const float ex = pi.x - pj.x, ey = pi.y - pj.y, ez = pi.z - pj.z;
+            const float d = sqrtf(ex * ex + ey * ey + ez * ez);
+            if (d < thr && ((int)j < B ? (int)j : (int)j - B) != ci) {
+                cnt++;
+                sum += d;
+                if (d > 0.f) {
+                    const float rr = 1.0f / d;
+                    gx += ex * rr; gy += ey * rr; gz += ez * rr;
                 }
             }
         }
-    }
-    if (i < N && cnt) {   // (a pair contributes to g only if it was counted)
-        atomicAdd(&g_pt[3 * i], gx); atomicAdd(&g_pt[3 * i + 1], gy); atomicAdd(&g_pt[3 * i + 2], gz);
+        if (cnt) { atomicAdd(&g_pt[3 * i], gx); atomicAdd(&g_pt[3 * i + 1], gy); atomicAdd(&g_pt[3 * i + 2], gz); }
     }
     // block totals -> partial slots
     __shared__ unsigned int s_c[4];
@@ -355,9 +366,8 @@ __global__ void __launch_bounds__(256) k_conn_main(int B, const float* __restric
     if (threadIdx.x == 0) {
         const unsigned int ct = s_c[0] + s_c[1] + s_c[2] + s_c[3];
         if (ct) {
-            const int slot = (blockIdx.x * CONN_JSPLIT + blockIdx.y) % CONN_SLOTS;
-            atomicAdd(&cnt_slots[slot], (unsigned long long)ct);
-            atomicAdd(&sum_slots[slot], (double)s_s[0] + (double)s_s[1] + (double)s_s[2] + (double)s_s[3]);
+            atomicAdd(&cnt_slots[blockIdx.x % CONN_SLOTS], (unsigned long long)ct);
+            atomicAdd(&sum_slots[blockIdx.x % CONN_SLOTS], (double)s_s[0] + (double)s_s[1] + (double)s_s[2] + (double)s_s[3]);
         }
     }
 }
@@ -382,19 +392,36 @@ __global__ void __launch_bounds__(256) k_conn_finish(int B, float weight, const 
         else { row[k] = gs; row[3 + k] = 0.f; row[6 + k] = 0.f; row[9 + k] = ge; }
     }
 }
+// workspace: [slots: 64 u64 + 64 f64][g_pt 3N floats][next N][heads Hs]
+static uint32_t conn_hash_size(int B) {
+    uint32_t h = 1024;
+    while (h < 4u * (uint32_t)B && h < (1u << 24)) h <<= 1;   // >= 2 buckets per point
+    return h;
+}
 size_t endpoint_connection_workspace_bytes(int B) {
-    return (((size_t)6 * B * sizeof(float) + 127) & ~(size_t)127) + CONN_SLOTS * (sizeof(unsigned long long) + sizeof(double));
+    const size_t Hs = conn_hash_size(B), N = 2 * (size_t)B;
+    return CONN_SLOTS * 16 + N * 12 + N * 4 + Hs * 4 + 256;
 }
 void launch_endpoint_connection(hipStream_t s, int B, const float* cp, float thr, float weight, void* workspace, float* loss,
                                 float* dL_dcp, int accumulate) {
-    float* g_pt = reinterpret_cast<float*>(workspace);
-    char* tail = reinterpret_cast<char*>(workspace) + (((size_t)6 * B * sizeof(float) + 127) & ~(size_t)127);
-    unsigned long long* cnt_slots = reinterpret_cast<unsigned long long*>(tail);
-    double* sum_slots = reinterpret_cast<double*>(tail + CONN_SLOTS * sizeof(unsigned long long));
+    const uint32_t Hs = conn_hash_size(B);
     const int N = 2 * B;
-    { ProfScope p("conn_zero", s); hipLaunchKernelGGL(k_conn_zero, dim3((3 * N + 255) / 256), dim3(256), 0, s, 3 * N, g_pt, cnt_slots, sum_slots); }
-    { ProfScope p("conn_main", s); hipLaunchKernelGGL(k_conn_main, dim3((N + 255) / 256, CONN_JSPLIT), dim3(256), 0, s, B, cp, thr, g_pt, cnt_slots, sum_slots); }
-    { ProfScope p("conn_finish", s); hipLaunchKernelGGL(k_conn_finish, dim3((B + 255) / 256), dim3(256), 0, s, B, weight, g_pt, cnt_slots, sum_slots, loss, dL_dcp, accumulate); }
+    char* w = reinterpret_cast<char*>(workspace);
+    unsigned long long* cnt_slots = reinterpret_cast<unsigned long long*>(w);
+    double* sum_slots = reinterpret_cast<double*>(w + CONN_SLOTS * 8);
+    float* g_pt = reinterpret_cast<float*>(w + CONN_SLOTS * 16);
+    uint32_t* next = reinterpret_cast<uint32_t*>(g_pt + 3 * (size_t)N);
+    uint32_t* heads = next + N;
+    const ConnGrid g{1.0f / (thr * 1.0001f), Hs - 1u};
+    const size_t zero_words = (CONN_SLOTS * 16) / 4 + 3 * (size_t)N;    // slots + g_pt
+    const dim3 blk(256);
+    { ProfScope p("conn_grid", s);
+      hipLaunchKernelGGL(k_conn_init, dim3((unsigned)std::min<size_t>((std::max<size_t>(zero_words, Hs) + 255) / 256, 2048)), blk, 0, s,
+                         zero_words, reinterpret_cast<uint32_t*>(w), (size_t)Hs, heads);
+      hipLaunchKernelGGL(k_conn_build, dim3((N + 255) / 256), blk, 0, s, B, cp, g, heads, next); }
+    { ProfScope p("conn_main", s);
+      hipLaunchKernelGGL(k_conn_main, dim3((unsigned)(((long long)N * 27 + 255) / 256)), blk, 0, s, B, cp, thr, g, heads, next, g_pt, cnt_slots, sum_slots); }
+    { ProfScope p("conn_finish", s); hipLaunchKernelGGL(k_conn_finish, dim3((B + 255) / 256), blk, 0, s, B, weight, g_pt, cnt_slots, sum_slots, loss, dL_dcp, accumulate); }
 }
 
 // ------------------------------------------------------------------------------------------------ flat Adam
