@@ -208,7 +208,7 @@ int cgs_photometric_loss_indexed(int height, int width, const float* image, cons
 /* End-point connection loss of /root/reference/train.py:133-146 (active after opt.conn_from_iter): over the 2B curve end
  * points (first and last control point of every curve), loss = weight * mean distance of all ordered pairs of DIFFERENT
  * curves closer than distance_threshold (0.05 in the reference); 0 when there is no such pair.  The reference builds the
- * (2B)^2 cdist matrix; this is O(B) memory and O(B^2) distance tests in one pass.  curve_points [B,4,3].
+ * (2B)^2 cdist matrix; this is a neighbour search on a hashed uniform grid, O(B) memory and time.  curve_points [B,4,3].
  * dL_dcurve_points [B,4,3]: accumulate != 0 adds the gradient to the rows 0 and 3 (the other rows are untouched),
  * accumulate == 0 writes the whole tensor (rows 1, 2 zero).  workspace: cgs_endpoint_connection_workspace_bytes(B). */
 size_t cgs_endpoint_connection_workspace_bytes(int B);
