@@ -69,6 +69,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true",
                     help="view mode: launch every view eagerly (Python autograd + ctypes) instead of replaying one "
                          "captured hipGraph per stream")
+    ap.add_argument("--train-step-multi", action="store_true",
+                    help="N > 1 only: also time the view-parallel training iteration (GraphedTrainStep in collective mode: "
+                         "every rank renders one view, ONE all-reduce of the flat gradients, identical Adam step on all "
+                         "ranks).  Off by default: the scaling run measures the raster throughput only")
     ap.add_argument("--no-pingpong", action="store_true",
                     help="view mode: one set of per-stream gradient buffers (the streams drain at every step boundary) "
                          "instead of two used by alternate steps")
@@ -364,6 +368,33 @@ def main():
         serial_graph_ms = serial.get("graph")
         vstreams, G, use_graphs[0] = keep_s, keep_G, keep_u
 
+    # ---------------------------------------------------------------- view-parallel training iteration (all ranks)
+    vp_train_ms = None
+    if dist is not None and world > 1 and args.train_step_multi and args.mode == "view":
+        from curve_gaussian_amd.scene import GaussianCurveModel
+        from curve_gaussian_amd.train_step import GraphedTrainStep
+        gmv = GaussianCurveModel(0, m, device=dev).create_from_curves(curves["curve_points"], curves["width"],
+                                                                      curves["opacity"], curves["mask"],
+                                                                      curves["is_bezier"])
+        vcams = my_cams[:8]
+        ggv = torch.Generator(device="cpu").manual_seed(7 + rank)
+        vgts = [((torch.rand(1, H, W, generator=ggv) > 0.97).float() * torch.rand(1, H, W, generator=ggv)).to(dev) for _ in vcams]
+        tsv = GraphedTrainStep(gmv, vcams, vgts, rank=rank, world=world)
+        for _ in range(3):
+            tsv.step()
+        tsv.finish()
+        barrier()
+        tv0 = time.perf_counter()
+        n_vp = 32
+        for _ in range(n_vp):
+            tsv.step()
+        tsv.finish()
+        barrier()
+        tvt = torch.tensor([(time.perf_counter() - tv0) / n_vp * 1e3], device=dev, dtype=torch.float64)
+        dist.all_reduce(tvt, op=dist.ReduceOp.MAX)
+        vp_train_ms = float(tvt.item())
+        del tsv, gmv
+
     # ---------------------------------------------------------------- per-kernel times (HIP events on the launch stream)
     kernel_ms = {}
     if not args.no_kernel_times and rank == 0:
@@ -413,6 +444,8 @@ def main():
                                     "step s+1)" if n_sets > 1 else "join per step",
                    "parallelism": f"view-parallel x{world}"},
     }
+    if vp_train_ms is not None:   # one optimizer step = `world` views (one per rank), gradients summed by ONE all-reduce
+        out["train_step_view_parallel_ms"] = round(vp_train_ms, 4)
     if grad_check is not None:
         out["step_gradient_rel_l2_vs_serial_eager"] = float(f"{grad_check:.3e}")
     if serial_ms is not None:

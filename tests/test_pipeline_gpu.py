@@ -464,7 +464,7 @@ def test_bench_two_rank_control_flow_rehearsal():
     env = dict(os.environ, CGS_BENCH_REHEARSAL="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "8",
-           "--warmup", "2", "--config", "cfg1", "--no-cpu-baseline"]
+           "--warmup", "2", "--config", "cfg1", "--no-cpu-baseline", "--train-step-multi"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -472,6 +472,7 @@ def test_bench_two_rank_control_flow_rehearsal():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 8 and out["value"] > 0
     assert "roofline" in out and out["config"]["parallelism"] == "view-parallel x2"
+    assert out["train_step_view_parallel_ms"] > 0
 
 
 def test_connection_loss_matches_the_reference_block():
