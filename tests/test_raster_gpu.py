@@ -543,3 +543,64 @@ def test_full_size_properties(cfg, P):
     assert np.isfinite(c).all() and c.min() >= 0 and c.max() <= 1.0 + 1e-5
     assert final_T.min() >= 0 and final_T.max() <= 1.0
     np.testing.assert_allclose(c[0], om.cpu().numpy()[3], atol=1e-6)  # quirk 11
+
+
+def test_bucket_path_equals_exact_path_on_random_scenes():
+    """Random scenes (image sizes that are not tile multiples, 1 .. 12 000 splats, tiny to screen-filling footprints,
+    coincident depths): the default forward -- first call exact layout, then single-pass buckets, then buckets with the
+    oversized splats deferred -- must reproduce the debug forward (count -> scan -> scatter -> sort) bit for bit in its
+    images, radii and per-tile lists, and its gradients within the parity tolerance (float atomics reorder sums)."""
+    import random
+    from curve_gaussian_amd import _lib
+    from curve_gaussian_amd.diff_cur_rasterization import _C
+    dev = torch.device(DEV)
+    rng = random.Random(3)
+    lib = _lib.load()
+    e = torch.empty(0, device=dev)
+
+    def fwd(d, rs, H, W, debug):
+        out = _C.rasterize_gaussians(rs.bg, d["means3D"], d["colors"], d["opacities"], d["scales"], d["rotations"], 1.0, e,
+                                     d["all_map"], rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, e, 0,
+                                     rs.campos, False, False, True, debug)
+        torch.cuda.synchronize()
+        return out
+
+    def bwd(out, d, rs, g):
+        (R, color, radii, gB, bB, iB, invd, om) = out
+        r = _C.rasterize_gaussians_backward(rs.bg, e, d["means3D"], radii, d["colors"], d["all_map"], d["opacities"],
+                                            d["scales"], d["rotations"], 1.0, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+                                            rs.tanfovy, g[0], g[1], g[2], e, 0, rs.campos, gB, R, bB, iB, False, True, False)
+        torch.cuda.synchronize()
+        return r
+    try:
+        for case in range(14):
+            H, W = rng.choice([16, 33, 64, 100, 160]), rng.choice([16, 47, 64, 128, 208])
+            P = rng.choice([1, 7, 64, 500, 3000, 12000])
+            lo = rng.choice([0.002, 0.01, 0.05, 0.3])
+            sp = S.random_splats(P, 2000 + case, scale_range=(lo, lo * rng.choice([2, 10, 40])))
+            if case % 3 == 0:
+                sp["means3D"] = sp["means3D"][torch.arange(P) % max(1, P // 20)]      # depth ties
+            cam = S.make_camera(*CAMS[case % len(CAMS)], H, W)
+            rs = hip_settings(cam, torch.zeros(3), dev)
+            d = {k: v.to(dev) for k, v in sp.items()}
+            lib.cgs_reset_binning_hints()
+            ref = fwd(d, rs, H, W, True)
+            R = ref[0]
+            rr, rl, _, _ = _decode_state(ref[3], ref[4], ref[5], P, H, W, R)
+            lens = rr[:, 1] - rr[:, 0]
+            g = [torch.randn(1, H, W, device=dev), torch.randn(1, H, W, device=dev), torch.randn(4, H, W, device=dev)]
+            gref = bwd(ref, d, rs, g)
+            for k in range(3):
+                o = fwd(d, rs, H, W, False)
+                assert o[0] == R, (case, k)
+                for a, b in ((o[1], ref[1]), (o[2], ref[2]), (o[6], ref[6]), (o[7], ref[7])):
+                    assert torch.equal(a, b), (case, k)
+                orr, ol, _, _ = _decode_state(o[3], o[4], o[5], P, H, W, R)
+                assert ((orr[:, 1] - orr[:, 0]) == lens).all(), (case, k)
+                for t in range(len(lens)):
+                    assert (ol[orr[t, 0]:orr[t, 1]] == rl[rr[t, 0]:rr[t, 1]]).all(), (case, k, t)
+                for a, b in zip(bwd(o, d, rs, g), gref):
+                    if a.numel():
+                        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-9, (case, k)
+    finally:
+        lib.cgs_reset_binning_hints()
