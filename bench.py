@@ -54,8 +54,9 @@ KERNEL_ALG_BYTES = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=256,
+                    help="timed steps; one step = one view per rank (views_per_step of them share one gradient exchange)")
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--mode", default="view", choices=["view", "raster"],
                     help="view: full per-view hot path (curve sampling -> splat attrs -> raster fwd+bwd -> curve grads "
