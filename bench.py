@@ -116,7 +116,13 @@ def main():
     H, W = cams[0].image_height, cams[0].image_width
     bg = torch.zeros(3, device=dev)
     n_my = K + Wm
-    my_cams = [cams[(rank + i * world) % len(cams)].to(dev) for i in range(n_my)]
+    dev_cams = {}      # one device copy per distinct view (the list below cycles through them)
+    my_cams = []
+    for i in range(n_my):
+        vi = (rank + i * world) % len(cams)
+        if vi not in dev_cams:
+            dev_cams[vi] = cams[vi].to(dev)
+        my_cams.append(dev_cams[vi])
     tanx, tany = math.tan(cams[0].FoVx * 0.5), math.tan(cams[0].FoVy * 0.5)
     # per-view direction map (gaussian_renderer/__init__.py:98-104) precomputed: raster-only benchmark
     Rm = curve_sampling.quaternion_to_matrix(rotn)[..., 0]
