@@ -408,9 +408,12 @@ def main():
         exchange[0] = False     # the other ranks are past their last collective
         lib.cgs_prof_reset()
         lib.cgs_prof_enable(1)
-        n_prof = min(K, 16)
+        # the same views whatever --steps / --warmup say (the first 18 of this rank: what profiles/collect.sh traces), so
+        # the live per-kernel times are comparable from run to run and with the committed rocprofv3 summary
+        prof_cams = my_cams[:min(len(my_cams), 18)]
+        n_prof = len(prof_cams)
         vstreams, keep = ViewStreams(1), vstreams   # serial views: per-kernel event times must not overlap
-        run_views(my_cams[Wm:Wm + n_prof], collect=True)
+        run_views(prof_cams, collect=True)
         vstreams = keep
         torch.cuda.synchronize()
         lib.cgs_prof_enable(0)
@@ -419,9 +422,9 @@ def main():
         if args.mode == "view":  # instance counts come from the raster-only call on the same views
             for i in range(n_prof):
                 (R_i, *_rest) = _C.rasterize_gaussians(
-                    bg, xyz, colors, opac, scl, rotn, 1.0, empty, amaps[id(my_cams[Wm + i])],
-                    my_cams[Wm + i].world_view_transform, my_cams[Wm + i].full_proj_transform, tanx, tany, H, W, empty,
-                    0, my_cams[Wm + i].camera_center, False, False, True, False)
+                    bg, xyz, colors, opac, scl, rotn, 1.0, empty, amaps[id(prof_cams[i])],
+                    prof_cams[i].world_view_transform, prof_cams[i].full_proj_transform, tanx, tany, H, W, empty,
+                    0, prof_cams[i].camera_center, False, False, True, False)
                 stats["R"] += R_i
         R_mean = stats["R"] / n_prof
         vis_mean = stats["visible"] / n_prof
