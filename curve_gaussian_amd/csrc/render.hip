@@ -16,6 +16,7 @@
 // (quadrant, splat, field) -- no LDS atomics, no per-pixel global atomics (the reference issues 12 per pixel pair,
 // backward.cu:613-672).
 #include "kernels.h"
+#include <stdlib.h>
 
 namespace cgs {
 
@@ -29,18 +30,12 @@ constexpr float ALPHA_MIN = 1.0f / 255.0f;
 __device__ __forceinline__ float sat01(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 1.f); }  // folds into "clamp"
 struct StepConsts {
     float big, cA;       // [alpha >= 1/255] = sat(alpha * 2^100 - pred(1/255) * 2^100)
-    float nbig, one;     // [!(p2 > 0)]      = sat(1 - p2 * 2^127): any positive normal float times 2^127 is >= 2
-    float nbig100, cT;   // [T < 1e-4]       = sat(1e-4 * 2^100 - T * 2^100)
 };
 __device__ __forceinline__ StepConsts step_consts() {
     StepConsts k;
     k.big = 0x1p100f;
     k.cA = -__uint_as_float(0x3b808080u) * 0x1p100f;   // pred(1/255f = 0x3b808081)
-    k.nbig = -0x1p127f;
-    k.one = 1.0f;
-    k.nbig100 = -0x1p100f;
-    k.cT = 0.0001f * 0x1p100f;                          // T < 1e-4  <=>  (1e-4 - T) * 2^100 >= 1
-    asm volatile("" : "+v"(k.big), "+v"(k.cA), "+v"(k.nbig), "+v"(k.one), "+v"(k.nbig100), "+v"(k.cT));
+    asm volatile("" : "+v"(k.big), "+v"(k.cA));
     return k;
 }
 constexpr int SLOTS = 8;          // accepted splats buffered per wave between two splat-parallel moment passes
@@ -212,12 +207,17 @@ __global__ void __launch_bounds__(256) k_render_fwd(const uint2* __restrict__ ra
     // version's 3 compares + 5 selects were 36 of its ~78 issue cycles per pair; no exec-mask or SGPR-pair bookkeeping
     // either (the scalar unit was the bottleneck before that: ~30 SALU per splat vs ~9).
     const StepConsts k = step_consts();
+    // Per-lane state.  A live pixel carries its transmittance in Tw and the acceptance constant cA = -pred(1/255) 2^100 of
+    // the [alpha >= 1/255] step; when a pixel terminates (reference: done = true) its transmittance is parked in T_dead,
+    // Tw becomes 1 and cA -huge, so every later alpha evaluates to a_eff = 0: the pixel blends nothing and its
+    // test_T = Tw = 1 never trips the termination test again -- no per-pair bookkeeping for dead pixels.
     float T_dead = 0.0f;
-    float Tw = g.inside ? 1.0f : 0.0f;
+    float Tw = 1.0f;
+    float cA = g.inside ? k.cA : -0x1p126f;
     uint32_t last_contributor = 0;
     float C = 0.f, Dacc = 0.f;
     float A0 = 0.f, A1 = 0.f, A2 = 0.f, A3 = 0.f;
-    bool wave_done = ballot64(Tw > 0.f) == 0ull;
+    bool wave_done = ballot64(cA > -0x1p120f) == 0ull;
     for (int i = 0; i < rounds; i++) {
         // vote: stop when every wave is finished (reference: __syncthreads_count(done) == BLOCK_SIZE); this barrier
         // also guarantees every wave is done with the previous batch's staged data
@@ -255,28 +255,33 @@ __global__ void __launch_bounds__(256) k_render_fwd(const uint2* __restrict__ ra
             const float dx = a.x - pixfx, dy = a.y - pixfy;
             const float p2 = dx * (a.z * dx + a.w * dy) + b.x * dy * dy;
             const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(p2));
-            // reference: power > 0 -> skip, alpha < 1/255 -> skip (both leave the pixel untouched)
-            const float hA = sat01(fmaf(alpha, k.big, k.cA));         // [alpha >= 1/255]
-            const float hB = sat01(fmaf(p2, k.nbig, k.one));          // [!(p2 > 0)]
-            e.a_eff = (alpha * hA) * hB;                              // alpha if hit, else 0
+            // reference: alpha < 1/255 -> skip.  (Its power > 0 skip, forward.cu:362-363, cannot fire for a positive
+            // definite conic except on rounding noise where G = 1 to 1e-6: not evaluated, DESIGN.md deviations.)
+            const float hA = sat01(fmaf(alpha, k.big, cA));           // [alpha >= 1/255] and the pixel is live
+            e.a_eff = alpha * hA;                                     // alpha if hit, else 0
             e.col = b.z;
             e.invd = b.w;
             if (GEO) e.cc = s_c[j];
             e.pos1 = base + (uint32_t)j;
             return e;
         };
-        auto blend = [&](const Eval& e) {
-            const float test_T = fmaf(-Tw, e.a_eff, Tw);
-            // stop = 0: the pixel is live and stays above 1e-4 (then this splat is blended if it hit); stop = 1: the
-            // pixel is dead (Tw == 0) or this hit would take T below 1e-4 -- it terminates, the splat is NOT blended
-            const float stop = sat01(fmaf(test_T, k.nbig100, k.cT));  // [test_T < 1e-4]
-            const float aT = e.a_eff * Tw;
-            const float w = fmaf(-aT, stop, aT);
+        auto blend = [&](const Eval& e, float& next_a_eff) {   // next_a_eff: the already evaluated partner of the trip
+            float test_T = fmaf(-Tw, e.a_eff, Tw);
+            float w = e.a_eff * Tw;
+            // reference forward.cu:371-376: a hit that would take T below 1e-4 terminates the pixel and is NOT blended.
+            // Rare (once per pixel at most): a wave-uniform branch instead of per-pair arithmetic.
+            const bool dying = test_T < 0.0001f;
+            if (__builtin_expect(ballot64(dying) != 0ull, 0)) {
+                T_dead = dying ? Tw : T_dead;
+                cA = dying ? -0x1p126f : cA;
+                w = dying ? 0.f : w;
+                test_T = dying ? 1.0f : test_T;
+                next_a_eff = dying ? 0.f : next_a_eff;
+            }
             C = fmaf(e.col, w, C);
             Dacc = fmaf(e.invd, w, Dacc);
             if (GEO) { A0 = fmaf(e.cc.x, w, A0); A1 = fmaf(e.cc.y, w, A1); A2 = fmaf(e.cc.z, w, A2); A3 = fmaf(e.cc.w, w, A3); }
-            T_dead = fmaf(stop, Tw, T_dead);        // += Tw on the terminating splat (0 while live, Tw == 0 after)
-            Tw = fmaf(-test_T, stop, test_T);
+            Tw = test_T;
             // 1-based list position of the last blended splat: w > 0 exactly when this one was blended, its bit
             // pattern then exceeds any list position, and positions only grow -> the median of the three
             const uint32_t wb = __float_as_uint(w);
@@ -291,11 +296,12 @@ __global__ void __launch_bounds__(256) k_render_fwd(const uint2* __restrict__ ra
                 const int j1 = m ? c * 64 + __builtin_ctzll(m) : BATCH;
                 m &= m - 1;    // (0 & anything = 0)
                 const Eval e0 = eval(j0);
-                const Eval e1 = eval(j1);
-                blend(e0);
-                blend(e1);
+                Eval e1 = eval(j1);
+                float none = 0.f;
+                blend(e0, e1.a_eff);
+                blend(e1, none);
             }
-            if (ballot64(Tw > 0.f) == 0ull) {  // checked once per 64-splat chunk
+            if (ballot64(cA > -0x1p120f) == 0ull) {  // checked once per 64-splat chunk
                 wave_done = true;
                 break;
             }
@@ -303,7 +309,7 @@ __global__ void __launch_bounds__(256) k_render_fwd(const uint2* __restrict__ ra
     }
     if (g.inside) {
         const size_t HW = (size_t)H * W;
-        const float T = Tw + T_dead;   // live: Tw (T_dead == 0); terminated: T_dead (Tw == 0)
+        const float T = cA > -0x1p120f ? Tw : T_dead;   // live: Tw; terminated: the transmittance it stopped at
         final_T[g.pix_id] = T;
         n_contrib[g.pix_id] = last_contributor;
         out_color[g.pix_id] = C + T * bg_color[0];
@@ -608,6 +614,312 @@ __global__ void __launch_bounds__(256) k_render_bwd(
     }
 }
 
+// ------------------------------------------------------------------------------------------------ backward, v2
+// Same mapping and reduction idea as k_render_bwd above, restructured around the fact that the kernel is bound by VALU
+// issue (profiles/r01_pmc.csv: SQ_ACTIVE_INST_VALU = 131.7 M quad-cycles = 514 k cycles per SIMD against 499 k busy
+// cycles) -- every vector instruction and every VGPR-returning LDS read removed from the per-pair path counts:
+//   * each wave compacts the staged indices its quadrant accepted into a private list of LDS byte offsets (one
+//     mbcnt + ds_write_b16 per 64 entries) and walks it as a COUNTED loop, eight entries per trip: no scalar bit walk,
+//     no m0 / v_writelane slot bookkeeping, slot buffers addressed by instruction-immediate offsets;
+//   * the "power > 0" skip (backward.cu:583-585) is dropped from the per-pair path: for a positive-definite conic it
+//     can only fire on rounding noise at pixels where G = 1 to 1e-6 (deviations);
+//   * the 64-pixel moment sums leave the (slot, pixel-row) lanes through LDS (6 ds_write_b32, 2 ds_read_b128 + 7 adds in
+//     the (slot, field) lanes that issue the atomics) instead of 6 DPP adds + 5 permlane swaps + the transposing stores.
+constexpr int LSTRIDE = 68;   // floats per slot row: 64 pixels + 4 (16-byte aligned rows; (slot * 68 + x) % 32 banks spread)
+constexpr uint32_t DUMMY_OFF = BATCH * 16;   // byte offset of the all-zero staged entry (opacity 0: never active)
+
+template <bool GEO, bool INVD, bool COLG>
+__global__ void __launch_bounds__(256) k_render_bwd2(
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int grid_x,
+    const float* __restrict__ bg_color, const SplatRec* __restrict__ rec, const float* __restrict__ final_Ts,
+    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
+    const float* __restrict__ dL_dout_invdepth, const float* __restrict__ dL_dout_all_map,
+    float* __restrict__ grad_acc) {
+    constexpr int NF = GEO ? 12 : 8;
+    __shared__ float4 s_a[BATCH + 1];   // entry BATCH: zeros
+    __shared__ float4 s_b[BATCH + 1];
+    __shared__ float4 s_c[GEO ? BATCH + 1 : 1];
+    __shared__ uint32_t s_id[BATCH + 1];
+    __shared__ uint64_t s_qmask[4][4];
+    __shared__ __attribute__((aligned(16))) uint16_t s_list[4][BATCH + 8];   // per wave: byte offsets (16 * staged index)
+    __shared__ __attribute__((aligned(16))) float s_g[4][SLOTS * LSTRIDE];   // per wave: g of 8 slots x 64 pixels; then the row sums
+    __shared__ float s_x[4][SLOTS][8];                                       // per wave: colour / inv-depth / all_map sums per slot
+    const TileGeom g = tile_geom(W, H, grid_x);
+    const int lane = g.lane;
+    const float pixfx = (float)g.px, pixfy = (float)g.py;
+    const float X0 = (float)(g.tx * TILE), Y0 = (float)(g.ty * TILE);
+    const uint2 range = ranges[g.tile];
+    const int total = (int)(range.y - range.x);
+    if (total == 0) return;
+    const int rounds = (total + BATCH - 1) / BATCH;
+    const size_t HW = (size_t)H * W;
+    if (threadIdx.x == 0) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_a[BATCH] = z;
+        s_b[BATCH] = z;
+        if (GEO) s_c[GEO ? BATCH : 0] = z;
+        s_id[BATCH] = 0u;
+    }
+
+    const float T_final = g.inside ? final_Ts[g.pix_id] : 0.f;
+    float T = T_final;
+    const uint32_t last_contributor = g.inside ? n_contrib[g.pix_id] : 0u;
+    uint32_t wave_last = last_contributor;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, off, 64));
+    wave_last = __builtin_amdgcn_readfirstlane(wave_last);
+
+    float accum_rec = 0.f, accum_invd = 0.f, accum_m0 = 0.f, accum_m1 = 0.f, accum_m2 = 0.f, accum_m3 = 0.f;
+    float dL_dpixel = 0.f, dL_invd = 0.f, dm0 = 0.f, dm1 = 0.f, dm2 = 0.f, dm3 = 0.f;
+    if (g.inside) {
+        dL_dpixel = dL_dpixels[g.pix_id];
+        if (INVD) dL_invd = dL_dout_invdepth[g.pix_id];
+        if (GEO) {
+            dm0 = dL_dout_all_map[g.pix_id];
+            dm1 = dL_dout_all_map[HW + g.pix_id];
+            dm2 = dL_dout_all_map[2 * HW + g.pix_id];
+            dm3 = dL_dout_all_map[3 * HW + g.pix_id];
+        }
+    }
+    const float nTf_bg = -T_final * (bg_color[0] * dL_dpixel);
+    float Tp = T_final * dL_dpixel;
+    const int col = lane & 15;
+    uint16_t* const list = s_list[g.wave];
+    float* const sg = s_g[g.wave];
+    const char* const sa_bytes = reinterpret_cast<const char*>(s_a);
+    const char* const sb_bytes = reinterpret_cast<const char*>(s_b);
+    const char* const sc_bytes = reinterpret_cast<const char*>(s_c);
+    // flush roles: lane (sl, q) folds pixel row q of slot sl; lane (fs, ff) sums field ff of slot fs over the rows
+    const int sl = lane & (SLOTS - 1), q = lane >> 3;
+    const int fs = lane >> 3, ff = lane & 7;
+    const float qx0 = (float)(g.tx * TILE + ((g.wave & 1) << 3));
+    const float qyr = (float)(g.ty * TILE + ((g.wave >> 1) << 3) + q);
+
+    for (int i = 0; i < rounds; i++) {
+        if (i > 0) __syncthreads();
+        const int progress = i * BATCH + threadIdx.x;
+        uint32_t qm = 0;
+        if (progress < total) {
+            const uint32_t id = point_list[range.y - progress - 1];
+            const SplatRec* r = rec + id;
+            const float4 a = r->a, b = r->b;
+            float4 sa, sb;
+            stage_splat(a, b, sa, sb);
+            s_id[threadIdx.x] = id;
+            s_a[threadIdx.x] = sa;
+            s_b[threadIdx.x] = sb;
+            if (GEO) s_c[threadIdx.x] = r->c;
+            qm = quadrant_mask(a, b, r->d.z, X0, Y0);
+        }
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) {
+            const uint64_t bal = ballot64((qm >> qq) & 1u);
+            if (lane == 0) s_qmask[qq][g.wave] = bal;
+        }
+        __syncthreads();
+        // ---- this wave's list: accepted staged indices J >= first_J (everything before is behind the last splat any
+        // pixel of the quadrant blended), in staging order = back to front
+        const int first_J = total - (int)wave_last - i * BATCH;
+        int n = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            uint64_t m = uniform64(s_qmask[g.wave][c]);
+            const int lo = first_J - c * 64;
+            if (lo >= 64) m = 0;
+            else if (lo > 0) m &= ~((1ull << lo) - 1ull);
+            if ((m >> lane) & 1ull) {
+                const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                list[pos] = (uint16_t)((c * 64 + lane) * 16);
+            }
+            n += __builtin_popcountll(m);
+        }
+        if (lane < 8) list[n + lane] = (uint16_t)DUMMY_OFF;
+        // lane-private: a staged entry J matters to this pixel iff its list position total-1-(i*256+J) < last_contributor
+        const int first_lane = total - (int)last_contributor - i * BATCH;
+        const uint32_t jmin_off = (uint32_t)max(first_lane, 0) * 16u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef CGS_X_NOWALK
+        n = 0;
+#endif
+        for (int k0 = 0; k0 < n; k0 += SLOTS) {
+            const uint4 w4 = *reinterpret_cast<const uint4*>(list + k0);   // eight offsets, same address in every lane
+            const uint32_t wv[4] = {w4.x, w4.y, w4.z, w4.w};
+            float t_c = 0.f, t_invd = 0.f, t_m0 = 0.f, t_m1 = 0.f, t_m2 = 0.f, t_m3 = 0.f;
+#pragma unroll
+            for (int u = 0; u < SLOTS; u++) {
+                const uint32_t joff = (u & 1) ? (wv[u >> 1] >> 16) : (wv[u >> 1] & 0xffffu);
+#ifdef CGS_X_NOLDS
+                const float jf = __uint_as_float(joff | 0x3f800000u);
+                const float4 a = make_float4(X0 + jf, Y0 + jf, -0.01f, 0.001f);
+                const float4 b = make_float4(-0.01f, 0.6f, 1.0f, jf);
+#else
+                const float4 a = *reinterpret_cast<const float4*>(sa_bytes + joff);
+#ifdef CGS_X_NOB
+                const float4 b = make_float4(a.z, 0.6f, 1.0f, 0.f);
+#else
+                const float4 b = *reinterpret_cast<const float4*>(sb_bytes + joff);
+#endif
+#endif
+                const float dx = a.x - pixfx, dy = a.y - pixfy;
+                const float p2 = dx * (a.z * dx + a.w * dy) + b.x * dy * dy;
+#ifdef CGS_X_NOTRANS
+                const float G = fmaf(p2, 0.01f, 1.0f);
+#else
+                const float G = __builtin_amdgcn_exp2f(p2);
+#endif
+                const float alpha = fminf(0.99f, b.y * G);
+                const bool active = (joff >= jmin_off) && !(alpha < ALPHA_MIN);
+                float v_g = 0.f, v_c = 0.f, v_invd = 0.f, v_m0 = 0.f, v_m1 = 0.f, v_m2 = 0.f, v_m3 = 0.f;
+                if (active) {
+#ifdef CGS_X_NOTRANS
+                    const float rcp_1ma = 1.f + alpha;
+#else
+                    const float rcp_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+#endif
+                    float dL_dalpha;
+                    if (!INVD && !GEO) {
+                        Tp = Tp * rcp_1ma;
+                        const float d_c = b.z - accum_rec;
+                        accum_rec = fmaf(alpha, d_c, accum_rec);
+                        if (COLG) v_c = alpha * Tp;
+                        dL_dalpha = fmaf(nTf_bg, rcp_1ma, d_c * Tp);
+                    } else {
+                        T = T * rcp_1ma;
+                        const float dchannel_dcolor = alpha * T;
+                        const float d_c = b.z - accum_rec;
+                        accum_rec = fmaf(alpha, d_c, accum_rec);
+                        float sum = d_c * dL_dpixel;
+                        if (COLG) v_c = dchannel_dcolor * dL_dpixel;
+                        if (INVD) {
+                            const float d_i = b.w - accum_invd;
+                            accum_invd = fmaf(alpha, d_i, accum_invd);
+                            sum = fmaf(d_i, dL_invd, sum);
+                            v_invd = dchannel_dcolor * dL_invd;
+                        }
+                        if (GEO) {
+                            const float4 cm = *reinterpret_cast<const float4*>(sc_bytes + joff);
+                            const float d0 = cm.x - accum_m0, d1 = cm.y - accum_m1, d2 = cm.z - accum_m2, d3 = cm.w - accum_m3;
+                            accum_m0 = fmaf(alpha, d0, accum_m0); accum_m1 = fmaf(alpha, d1, accum_m1);
+                            accum_m2 = fmaf(alpha, d2, accum_m2); accum_m3 = fmaf(alpha, d3, accum_m3);
+                            sum = fmaf(d0, dm0, sum); sum = fmaf(d1, dm1, sum); sum = fmaf(d2, dm2, sum); sum = fmaf(d3, dm3, sum);
+                            v_m0 = dchannel_dcolor * dm0; v_m1 = dchannel_dcolor * dm1;
+                            v_m2 = dchannel_dcolor * dm2; v_m3 = dchannel_dcolor * dm3;
+                        }
+                        dL_dalpha = fmaf(nTf_bg, rcp_1ma, sum * T);
+                    }
+                    v_g = G * dL_dalpha;
+                }
+                sg[u * LSTRIDE + lane] = v_g;
+                if (COLG || INVD || GEO) {
+                    const bool mine = col == u;
+                    if (COLG) { v_c = row16_sum(v_c); t_c = mine ? v_c : t_c; }
+                    if (INVD) { v_invd = row16_sum(v_invd); t_invd = mine ? v_invd : t_invd; }
+                    if (GEO) {
+                        v_m0 = row16_sum(v_m0); v_m1 = row16_sum(v_m1); v_m2 = row16_sum(v_m2); v_m3 = row16_sum(v_m3);
+                        t_m0 = mine ? v_m0 : t_m0; t_m1 = mine ? v_m1 : t_m1;
+                        t_m2 = mine ? v_m2 : t_m2; t_m3 = mine ? v_m3 : t_m3;
+                    }
+                }
+            }
+#ifdef CGS_X_NOFLUSH
+            continue;
+#endif
+            // ---- flush the eight slots
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float Sg, Sx, Sy, Sxx, Sxy, Syy;
+            {
+                const uint32_t joff = list[k0 + sl];
+                const float2 cxy = *reinterpret_cast<const float2*>(sa_bytes + joff);
+                const float dx0 = cxy.x - qx0, dyr = cxy.y - qyr;
+                const float4 g0 = *reinterpret_cast<const float4*>(sg + sl * LSTRIDE + 8 * q);
+                const float4 g1 = *reinterpret_cast<const float4*>(sg + sl * LSTRIDE + 8 * q + 4);
+                // moments of the row's 8 values about its first pixel, then shifted to the splat centre
+#ifdef CGS_X_FB
+                Sg = g0.x + g1.x; Sx = g0.y * dx0; Sxx = g0.z; Sy = g0.w * dyr; Sxy = g1.y; Syy = g1.z + g1.w;
+#else
+                float M0 = g0.x + g0.y, M1 = g0.y, M2 = g0.y;
+                M0 += g0.z; M1 = fmaf(g0.z, 2.f, M1); M2 = fmaf(g0.z, 4.f, M2);
+                M0 += g0.w; M1 = fmaf(g0.w, 3.f, M1); M2 = fmaf(g0.w, 9.f, M2);
+                M0 += g1.x; M1 = fmaf(g1.x, 4.f, M1); M2 = fmaf(g1.x, 16.f, M2);
+                M0 += g1.y; M1 = fmaf(g1.y, 5.f, M1); M2 = fmaf(g1.y, 25.f, M2);
+                M0 += g1.z; M1 = fmaf(g1.z, 6.f, M1); M2 = fmaf(g1.z, 36.f, M2);
+                M0 += g1.w; M1 = fmaf(g1.w, 7.f, M1); M2 = fmaf(g1.w, 49.f, M2);
+                const float Rx = fmaf(dx0, M0, -M1);
+                const float Rxx = fmaf(dx0, Rx - M1, M2);
+                Sg = M0; Sx = Rx; Sxx = Rxx;
+                Sy = dyr * M0; Sxy = dyr * Rx; Syy = (dyr * dyr) * M0;
+#endif
+            }
+            if (COLG) t_c = rows_sum(t_c);
+            if (INVD) t_invd = rows_sum(t_invd);
+            if (GEO) { t_m0 = rows_sum(t_m0); t_m1 = rows_sum(t_m1); t_m2 = rows_sum(t_m2); t_m3 = rows_sum(t_m3); }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // every lane has read its slot row: the buffer becomes [slot][field][row]
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef CGS_X_FC
+            if (Sg == 1.2345e-33f) sg[lane] = Sg + Sx + Sy + Sxx + Sxy + Syy;
+            continue;
+#endif
+            {
+#ifdef CGS_X_FD
+                float* rp = sg + lane;   // [field][lane]: contiguous, conflict-free
+                rp[0] = Sg; rp[72] = Sx; rp[144] = Sy; rp[216] = Sxx; rp[288] = Sxy; rp[360] = Syy;
+#else
+                float* rp = sg + sl * LSTRIDE + q;
+                rp[0] = Sg; rp[8] = Sx; rp[16] = Sy; rp[24] = Sxx; rp[32] = Sxy; rp[40] = Syy;
+#endif
+                if ((COLG || INVD || GEO) && lane < SLOTS) {
+                    float* xp = &s_x[g.wave][lane][0];
+                    xp[0] = COLG ? t_c : 0.f; xp[1] = INVD ? t_invd : 0.f;
+                    if (GEO) { xp[2] = t_m0; xp[3] = t_m1; xp[4] = t_m2; xp[5] = t_m3; }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef CGS_X_FA
+            continue;
+#endif
+            {
+                const uint32_t joff = list[k0 + fs];
+                const uint32_t id = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_id) + (joff >> 2));
+                float v = 0.f;
+                if (ff < 6) {
+#ifdef CGS_X_FD
+                    const float* rr = sg + ff * 72 + fs;   // lane of (slot fs, row r) is fs + 8 r
+                    v = ((rr[0] + rr[8]) + (rr[16] + rr[24])) + ((rr[32] + rr[40]) + (rr[48] + rr[56]));
+#else
+                    const float4 r0 = *reinterpret_cast<const float4*>(sg + fs * LSTRIDE + 8 * ff);
+                    const float4 r1 = *reinterpret_cast<const float4*>(sg + fs * LSTRIDE + 8 * ff + 4);
+                    v = ((r0.x + r0.y) + (r0.z + r0.w)) + ((r1.x + r1.y) + (r1.z + r1.w));
+#endif
+                } else if (COLG || INVD || GEO) {
+                    v = s_x[g.wave][fs][ff - 6];
+                }
+#ifdef CGS_X_NOATOMIC
+                if (v == 1.2345e-33f) grad_acc[(size_t)id * ACC_STRIDE + ff] = v;
+#elif defined(CGS_X_PLAINSTORE)
+                if (v != 0.f) grad_acc[(size_t)id * ACC_STRIDE + ff] = v;
+#else
+                if (v != 0.f) atomicAdd(grad_acc + (size_t)id * ACC_STRIDE + ff, v);
+#endif
+                if (GEO) {
+                    const float v2 = ff < 4 ? s_x[g.wave][fs][2 + ff] : 0.f;
+                    if (v2 != 0.f) atomicAdd(grad_acc + (size_t)id * ACC_STRIDE + 8 + ff, v2);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // the slot buffer may be overwritten from here on
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    (void)NF;
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 void launch_render_fwd(hipStream_t s, bool geo, int tiles, const uint2* ranges, const uint32_t* point_list, int W,
                        int H, int grid_x, const SplatRec* rec, float* final_T, uint32_t* n_contrib,
@@ -639,6 +951,19 @@ void launch_render_bwd(hipStream_t s, bool geo, bool invd, bool colg, int tiles,
                        const SplatRec* rec, const float* final_Ts, const uint32_t* n_contrib, const float* dL_dpixels,
                        const float* dL_dout_invdepth, const float* dL_dout_all_map, float* grad_acc) {
     ProfScope p("render_bwd", s);
+    static const bool v1 = getenv("CGS_BWD_V1") && getenv("CGS_BWD_V1")[0] == '1';   // A/B: the round-1 kernel
+    if (!v1) {
+#define CGS_BWD2(G, I, C)                                                                                        \
+    hipLaunchKernelGGL((k_render_bwd2<G, I, C>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H, grid_x, \
+                       bg_color, rec, final_Ts, n_contrib, dL_dpixels, dL_dout_invdepth, dL_dout_all_map, grad_acc)
+        if (geo && invd) CGS_BWD2(true, true, true);
+        else if (geo) CGS_BWD2(true, false, true);
+        else if (invd) CGS_BWD2(false, true, true);
+        else if (colg) CGS_BWD2(false, false, true);
+        else CGS_BWD2(false, false, false);
+#undef CGS_BWD2
+        return;
+    }
 #define CGS_BWD(G, I, C)                                                                                        \
     hipLaunchKernelGGL((k_render_bwd<G, I, C>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H, grid_x, \
                        bg_color, rec, final_Ts, n_contrib, dL_dpixels, dL_dout_invdepth, dL_dout_all_map, grad_acc)
