@@ -2,7 +2,10 @@
 """bench.py -- headline benchmark of the curve-Gaussian hot path on MI355X.
 
 Metric (BASELINE.json): Msplats rasterized/s, forward+backward, plus train-step ms and the HBM-roofline fraction.
-A "step" is one pass of the per-view hot path over one view of the synthetic workload:
+A "step" is one gradient-exchange batch: `--views-per-step` (default 8) independent views per rank through the per-view
+hot path, their curve-parameter gradients summed and (N > 1) all-reduced once -- the unit BASELINE's "train-step" implies.
+The timed region is the K-step region repeated until it lasts >= 0.5 s (`repeats`, `views_timed` in the output; `steps`
+and `warmup` are echoed unchanged), so the driver's small K still measures a steady state.  One view is:
     rasterizer forward  (preprocess -> tile binning + per-tile depth sort -> alpha-composite)
   + rasterizer backward (dL/d{mean2D,conic,opacity,colour,all_map} -> dL/d{mean3D,scale,rotation})
 with inputs already resident in HBM (SURVEY.md section 8d "raster-only benchmark": dL_dcolor ~ N(0,1)*1e-3,
@@ -51,12 +54,37 @@ KERNEL_ALG_BYTES = {
 }
 
 
+def committed_profile(config):
+    """The newest profiles/rNN_traffic.json + rNN_pmc.csv pair whose `config` is `config` (files without the field are
+    the round-1 cfg3 profiles), or None."""
+    import glob
+    for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")), reverse=True):
+        try:
+            tj = json.load(open(tf))
+            if tj.get("config", "cfg3") != config:
+                continue
+            pmc = {}
+            pf = tf.replace("_traffic.json", "_pmc.csv")
+            if os.path.exists(pf):
+                for line in open(pf):
+                    f = line.strip().split(",")
+                    if len(f) == 3 and not line.startswith("#") and f[0] != "Kernel":
+                        pmc.setdefault(f[0], {})[f[1]] = float(f[2])
+            return {"traffic": tj.get("kernels", {}), "pmc": pmc, "source": "profiles/" + os.path.basename(tf)}
+        except Exception:
+            continue
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256,
-                    help="timed steps; one step = one view per rank (views_per_step of them share one gradient exchange)")
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=32,
+                    help="timed steps; one step = one gradient-exchange batch of --views-per-step views per rank "
+                         "(raster mode: one view)")
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--min-seconds", type=float, default=0.5,
+                    help="the K-step region is repeated (inside one barrier-bracketed timing) until it lasts this long")
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--mode", default="view", choices=["view", "raster"],
                     help="view: full per-view hot path (curve sampling -> splat attrs -> raster fwd+bwd -> curve grads "
@@ -115,7 +143,8 @@ def main():
     colors = torch.ones(P, 1, device=dev)
     H, W = cams[0].image_height, cams[0].image_width
     bg = torch.zeros(3, device=dev)
-    n_my = K + Wm
+    G = max(1, args.views_per_step) if args.mode == "view" else 1   # views per step (per rank)
+    n_my = (K + Wm) * G
     dev_cams = {}      # one device copy per distinct view (the list below cycles through them)
     my_cams = []
     for i in range(n_my):
@@ -192,7 +221,6 @@ def main():
     # reference's one-view-per-iteration schedule.)
     from curve_gaussian_amd.view_parallel import ViewStreams
     vstreams = ViewStreams(args.streams if args.mode == "view" else 1, dev)
-    G = max(1, args.views_per_step) if args.mode == "view" else 1
     # every stream accumulates into its own flat buffer through its own leaf aliases (a shared .grad would make
     # autograd funnel all accumulation through one stream and serialise the views); slot 0 is the exchanged buffer
     # Two such sets, used by alternate steps: the streams start step s+1 (other set) while the main stream is still
@@ -317,21 +345,37 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         use_graphs[0] = bool(int(flag.item()))
 
+    reps = [1]
+
     def timed():
-        run_views(my_cams[:Wm])
+        """Wm warm-up steps, then the K-step region `reps` times back to back inside ONE barrier + synchronize bracket."""
+        run_views(my_cams[:Wm * G])
         barrier()
         t0 = time.perf_counter()
-        run_views(my_cams[Wm:Wm + K])
+        for _ in range(reps[0]):
+            run_views(my_cams[Wm * G:(Wm + K) * G])
         barrier()
         return time.perf_counter() - t0
 
-    elapsed = timed()
+    def timed_long():
+        """A pilot K-step region sizes the repeat count (max over ranks, so every rank repeats equally), then the
+        measurement proper."""
+        reps[0] = 1
+        pilot = timed()
+        if dist is not None:
+            tp = torch.tensor([pilot], device=dev, dtype=torch.float64)
+            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+            pilot = float(tp.item())
+        reps[0] = max(1, min(10000, int(math.ceil(args.min_seconds / max(pilot, 1e-6)))))
+        return timed() if reps[0] > 1 else pilot
+
+    elapsed = timed_long()
     if dist is not None:   # every rank takes the same decision (the re-timing below contains collectives)
         dist.all_reduce(overflow_acc, op=dist.ReduceOp.MAX)
     if int(overflow_acc.item()) != 0:   # a tile list outgrew its bucket on some rank: graph results invalid
         print("bench: bucket overflow in graph mode, re-timing with eager launches", file=sys.stderr)
         use_graphs[0] = False
-        elapsed = timed()
+        elapsed = timed_long()
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -366,11 +410,13 @@ def main():
             if name == "graph" and not ug:
                 continue
             use_graphs[0] = ug
+            sv = my_cams[:min(len(my_cams), 64)]
+            run_views(sv[:4])
             barrier()
             ts0 = time.perf_counter()
-            run_views(my_cams[Wm:Wm + K])
+            run_views(sv)
             barrier()
-            serial[name] = (time.perf_counter() - ts0) / K * 1e3
+            serial[name] = (time.perf_counter() - ts0) / len(sv) * 1e3
         serial_ms = serial["eager"]
         serial_graph_ms = serial.get("graph")
         vstreams, G, use_graphs[0] = keep_s, keep_G, keep_u
@@ -437,23 +483,30 @@ def main():
         return
 
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
-    ms_per_step = elapsed / K * 1e3
-    value = P * world * K / elapsed / 1e6
+    steps_timed = K * reps[0]
+    views_timed = steps_timed * G            # per rank
+    ms_per_step = elapsed / steps_timed * 1e3
+    value = P * world * views_timed / elapsed / 1e6
     out = {
         "metric": "Msplats rasterized/s (fwd+bwd)", "value": round(value, 3), "unit": "Msplats/s",
         "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(ms_per_step, 4),
+        "repeats": reps[0], "views_timed": views_timed * world, "timed_seconds": round(elapsed, 4),
+        "ms_per_view": round(elapsed / views_timed * 1e3, 5),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config}: synthetic curve-Gaussians, {B} curves x {m} = {P} splats, "
                                f"{W}x{H}, " + ("curve sampling + splat attrs + raster fwd+bwd + curve-param grads per view" if args.mode == "view" else "raster fwd+bwd per view"),
                    "mode": args.mode,
                    "splats": P, "curves": B, "width": W, "height": H, "tiles": tiles,
                    "instances_per_view_R": round(R_mean, 1), "visible_per_view": round(vis_mean, 1),
-                   "views_per_rank": K, "views_per_step_per_rank": G, "views_in_flight_per_gpu": vstreams.n,
+                   "step": f"{G} view(s) per rank, gradients summed" + (", one RCCL all-reduce" if world > 1 else ""),
+                   "views_per_rank": views_timed, "views_per_step_per_rank": G, "views_in_flight_per_gpu": vstreams.n,
                    "launch": "hipGraph replay per view" if use_graphs[0] else "eager",
                    "step_boundary": "double-buffered gradient sets (reduction/all-reduce of step s overlaps the views of "
                                     "step s+1)" if n_sets > 1 else "join per step",
                    "parallelism": f"view-parallel x{world}"},
     }
+    if dist is not None:
+        out["rccl_ranks"] = dist.get_world_size()
     if vp_train_ms is not None:   # one optimizer step = `world` views (one per rank), gradients summed by ONE all-reduce
         out["train_step_view_parallel_ms"] = round(vp_train_ms, 4)
     if grad_check is not None:
@@ -467,44 +520,30 @@ def main():
         dom = max(kernel_ms, key=kernel_ms.get)
         alg_dom = KERNEL_ALG_BYTES.get(dom, lambda *a: 0)(P, R_mean, H * W, tiles)
         ach = alg_dom / (kernel_ms[dom] * 1e-3) / 1e9
-        traffic = None  # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            traffic = tj["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            pass
+        # HBM bytes per launch and instruction counts come from the rocprofv3 PMC passes committed under profiles/ -- they
+        # belong to ONE workload: used only when that profile was taken on this --config (never as constants on another)
+        traffic = None
+        prof = committed_profile(args.config)
+        if prof is not None:
+            traffic = prof["traffic"].get(dom, {}).get("hbm_bytes_per_launch")
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                            "kernel_ms": round(kernel_ms[dom], 5), "algorithmic_bytes_per_launch": int(alg_dom)}
-        # what actually binds the dominant kernel: vector-instruction issue.  Instruction count per
-        # launch from the committed PMC pass (profiles/r01_pmc.csv, same workload), rate from the live kernel time; peak =
-        # 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (v_fma_f32 measured at 2 cycles, most others more).
-        try:
-            insts = {}
-            for line in open(os.path.join(ROOT, "profiles", "r01_pmc.csv")):
-                f = line.strip().split(",")
-                if len(f) == 3 and f[0] == dom:
-                    insts[f[1]] = float(f[2])
+        if prof is not None:
+            out["roofline"]["traffic_source"] = prof["source"]
+            insts = prof["pmc"].get(dom, {})
             if "SQ_INSTS_VALU" in insts:
+                # what binds the dominant kernel: the SIMDs' vector issue.  Instruction counts per
+                # launch from the committed PMC pass, rate from the live kernel time; peak = 1024 SIMDs x 2.4 GHz / 2
+                # cycles per wave64 VALU instruction (v_fma_f32; most other instructions take 4 or more).
                 rate = insts["SQ_INSTS_VALU"] / (kernel_ms[dom] * 1e-3) / 1e9
                 peak = 1024 * 2.4 / 2.0
-                out["issue_roofline"] = {"bound": "valu-issue", "kernel": dom,
+                out["issue_roofline"] = {"bound": "valu-issue", "kernel": dom, "source": prof["source"],
                                          "valu_wave_instr_per_launch": int(insts["SQ_INSTS_VALU"]),
                                          "salu_instr_per_launch": int(insts.get("SQ_INSTS_SALU", 0)),
+                                         "lds_instr_per_launch": int(insts.get("SQ_INSTS_LDS", 0)),
                                          "achieved": round(rate, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
                                          "frac": round(rate / peak, 4)}
-                # busy fractions of the other two issue-limited units in the profiled run (PMC ratios; SQ_BUSY_CYCLES is
-                # summed over the 32 shader engines): the scalar ALU issues one instruction per cycle per CU, the LDS
-                # pipeline reports its active cycles directly
-                if insts.get("SQ_BUSY_CYCLES"):
-                    cyc = insts["SQ_BUSY_CYCLES"] / 32.0
-                    out["issue_roofline"]["scalar_alu_busy_frac"] = round(insts.get("SQ_INSTS_SALU", 0) / (256 * cyc), 3)
-                    if "SQ_LDS_IDX_ACTIVE" in insts:
-                        out["issue_roofline"]["lds_busy_frac"] = round(insts["SQ_LDS_IDX_ACTIVE"] / (256 * cyc), 3)
-                    out["issue_roofline"]["note"] = ("vector pipes ~3 cycles per instruction on this mix (profiles/probes): "
-                                                     "no single unit is saturated, see DESIGN.md section 4")
-        except Exception:
-            pass
         out["kernel_ms_per_view"] = {k: round(v, 5) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])}
         out["whole_path"] = {"algorithmic_bytes_per_view": int(alg_view),
                              "achieved_GBps": round(alg_view / (ms_per_step * 1e-3) / 1e9, 2),
@@ -603,7 +642,7 @@ def main():
         t_fwd = t_bwd = 0.0
         err = {}
         for i in range(nv):
-            cam = my_cams[Wm + i]
+            cam = my_cams[i % len(my_cams)]
             tc0 = time.perf_counter()
             fw = ORA.forward(n(bg), a_xyz, a_col, a_op, a_sc, a_rot, 1.0, None, n(amaps[id(cam)]),
                              n(cam.world_view_transform), n(cam.full_proj_transform), tanx, tany, H, W, None, 0,
@@ -633,6 +672,8 @@ def main():
                                "kind": "port", "fwd_ms_per_view": round(t_fwd / nv * 1e3, 1),
                                "bwd_ms_per_view": round(t_bwd / nv * 1e3, 1),
                                "gpu_vs_cpu_frac_over_1e-4_of_max": {k: (v if isinstance(v, bool) else float(f"{v:.2e}")) for k, v in err.items()},
+                               "covers": "rasterizer forward + backward only (value times the whole per-view path: curve "
+                                         "sampling + splat attributes + raster + curve-parameter gradients)",
                                "sample": f"{nv} views of the same workload (raster fwd+bwd), oracle/raster_ref.c with "
                                          f"OpenMP ({threads} threads of {cores} host cores), {tc:.1f} s"}
     if dist is not None:

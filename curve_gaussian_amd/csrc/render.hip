@@ -265,27 +265,40 @@ __global__ void __launch_bounds__(256) k_render_fwd(const uint2* __restrict__ ra
             e.pos1 = base + (uint32_t)j;
             return e;
         };
-        auto blend = [&](const Eval& e, float& next_a_eff) {   // next_a_eff: the already evaluated partner of the trip
-            float test_T = fmaf(-Tw, e.a_eff, Tw);
-            float w = e.a_eff * Tw;
-            // reference forward.cu:371-376: a hit that would take T below 1e-4 terminates the pixel and is NOT blended.
-            // Rare (once per pixel at most): a wave-uniform branch instead of per-pair arithmetic.
-            const bool dying = test_T < 0.0001f;
-            if (__builtin_expect(ballot64(dying) != 0ull, 0)) {
-                T_dead = dying ? Tw : T_dead;
-                cA = dying ? -0x1p126f : cA;
-                w = dying ? 0.f : w;
-                test_T = dying ? 1.0f : test_T;
-                next_a_eff = dying ? 0.f : next_a_eff;
+        // The two splats of a trip are blended together.  reference forward.cu:371-376: a hit that would take T below 1e-4
+        // terminates the pixel and is NOT blended -- at most once per pixel, so it is one compare and a wave-uniform
+        // branch per trip (the transmittance after both splats is below 1e-4 iff either of them trips the test), and
+        // the slow path redoes the two steps one by one.
+        auto blend2 = [&](const Eval& e0, const Eval& e1) {
+            float w0 = e0.a_eff * Tw;
+            float T1 = fmaf(-Tw, e0.a_eff, Tw);
+            float w1 = e1.a_eff * T1;
+            float T2 = fmaf(-T1, e1.a_eff, T1);
+            if (__builtin_expect(ballot64(T2 < 0.0001f) != 0ull, 0)) {
+                const bool d0 = T1 < 0.0001f;                 // dies on the first splat: neither is blended
+                T_dead = d0 ? Tw : T_dead;
+                w0 = d0 ? 0.f : w0;
+                T1 = d0 ? 1.0f : T1;
+                const float a1 = d0 ? 0.f : e1.a_eff;
+                w1 = a1 * T1;
+                T2 = fmaf(-T1, a1, T1);
+                const bool d1 = T2 < 0.0001f;                 // dies on the second: the first is blended
+                T_dead = d1 ? T1 : T_dead;
+                w1 = d1 ? 0.f : w1;
+                T2 = d1 ? 1.0f : T2;
+                cA = (d0 || d1) ? -0x1p126f : cA;
             }
-            C = fmaf(e.col, w, C);
-            Dacc = fmaf(e.invd, w, Dacc);
-            if (GEO) { A0 = fmaf(e.cc.x, w, A0); A1 = fmaf(e.cc.y, w, A1); A2 = fmaf(e.cc.z, w, A2); A3 = fmaf(e.cc.w, w, A3); }
-            Tw = test_T;
-            // 1-based list position of the last blended splat: w > 0 exactly when this one was blended, its bit
-            // pattern then exceeds any list position, and positions only grow -> the median of the three
-            const uint32_t wb = __float_as_uint(w);
-            last_contributor = max(min(last_contributor, e.pos1), min(max(last_contributor, e.pos1), wb));  // v_med3_u32
+            Tw = T2;
+            C = fmaf(e0.col, w0, C);
+            Dacc = fmaf(e0.invd, w0, Dacc);
+            if (GEO) { A0 = fmaf(e0.cc.x, w0, A0); A1 = fmaf(e0.cc.y, w0, A1); A2 = fmaf(e0.cc.z, w0, A2); A3 = fmaf(e0.cc.w, w0, A3); }
+            C = fmaf(e1.col, w1, C);
+            Dacc = fmaf(e1.invd, w1, Dacc);
+            if (GEO) { A0 = fmaf(e1.cc.x, w1, A0); A1 = fmaf(e1.cc.y, w1, A1); A2 = fmaf(e1.cc.z, w1, A2); A3 = fmaf(e1.cc.w, w1, A3); }
+            // 1-based list position of the last blended splat: w > 0 exactly when a splat was blended, its bit pattern
+            // then exceeds any list position, and positions only grow -> the median of the three
+            last_contributor = max(min(last_contributor, e0.pos1), min(max(last_contributor, e0.pos1), __float_as_uint(w0)));  // v_med3_u32
+            last_contributor = max(min(last_contributor, e1.pos1), min(max(last_contributor, e1.pos1), __float_as_uint(w1)));
         };
 #pragma unroll 1
         for (int c = 0; c < 4; c++) {
@@ -296,10 +309,8 @@ __global__ void __launch_bounds__(256) k_render_fwd(const uint2* __restrict__ ra
                 const int j1 = m ? c * 64 + __builtin_ctzll(m) : BATCH;
                 m &= m - 1;    // (0 & anything = 0)
                 const Eval e0 = eval(j0);
-                Eval e1 = eval(j1);
-                float none = 0.f;
-                blend(e0, e1.a_eff);
-                blend(e1, none);
+                const Eval e1 = eval(j1);
+                blend2(e0, e1);
             }
             if (ballot64(cA > -0x1p120f) == 0ull) {  // checked once per 64-splat chunk
                 wave_done = true;
@@ -747,6 +758,13 @@ __global__ void __launch_bounds__(256) k_render_bwd2(
             const uint4 w4 = *reinterpret_cast<const uint4*>(list + k0);   // eight offsets, same address in every lane
             const uint32_t wv[4] = {w4.x, w4.y, w4.z, w4.w};
             float t_c = 0.f, t_invd = 0.f, t_m0 = 0.f, t_m1 = 0.f, t_m2 = 0.f, t_m3 = 0.f;
+#ifdef CGS_X_PREFETCH
+            // what the flush lanes need (splat centre of slot sl, splat id of slot fs) is requested before the walk, so
+            // the flush does not start with two dependent LDS round trips
+            const uint32_t pf_joff = list[k0 + sl];
+            const float2 pf_cxy = *reinterpret_cast<const float2*>(sa_bytes + pf_joff);
+            const uint32_t pf_id = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_id) + (list[k0 + fs] >> 2));
+#endif
 #pragma unroll
             for (int u = 0; u < SLOTS; u++) {
                 const uint32_t joff = (u & 1) ? (wv[u >> 1] >> 16) : (wv[u >> 1] & 0xffffu);
@@ -832,8 +850,12 @@ __global__ void __launch_bounds__(256) k_render_bwd2(
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             float Sg, Sx, Sy, Sxx, Sxy, Syy;
             {
+#ifdef CGS_X_PREFETCH
+                const float2 cxy = pf_cxy;
+#else
                 const uint32_t joff = list[k0 + sl];
                 const float2 cxy = *reinterpret_cast<const float2*>(sa_bytes + joff);
+#endif
                 const float dx0 = cxy.x - qx0, dyr = cxy.y - qyr;
                 const float4 g0 = *reinterpret_cast<const float4*>(sg + sl * LSTRIDE + 8 * q);
                 const float4 g1 = *reinterpret_cast<const float4*>(sg + sl * LSTRIDE + 8 * q + 4);
@@ -885,8 +907,12 @@ __global__ void __launch_bounds__(256) k_render_bwd2(
             continue;
 #endif
             {
+#ifdef CGS_X_PREFETCH
+                const uint32_t id = pf_id;
+#else
                 const uint32_t joff = list[k0 + fs];
                 const uint32_t id = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_id) + (joff >> 2));
+#endif
                 float v = 0.f;
                 if (ff < 6) {
 #ifdef CGS_X_FD

@@ -49,6 +49,7 @@ for t in tiles:
     S["bwd_pairs"] += int(need_b.sum())
     lane_act = h & (pos[:, :, None] < ncq[None, :, :])
     S["bwd_lane_active"] += int(lane_act.sum())
+    S["bwd_pairs_live"] = S.get("bwd_pairs_live", 0) + int(lane_act.any(2).sum())
     after = h & (pos[:, :, None] >= ncq[None, :, :])
     anyafter = after.any(0)
     death = np.where(anyafter, after.argmax(0), n)            # [4,64] entry index at which the lane dies (n = never)
@@ -65,6 +66,7 @@ for t in tiles:
         fwd_lane_live += int(live.sum())
 print(f"{cfg} view {view}, {len(tiles)} tiles: list entries {S['entries']}, accepted (quadrant,splat) pairs {S['pairs']}")
 print(f"backward: pairs before wave_last {S['bwd_pairs']} ({S['bwd_pairs']/S['pairs']:.3f} of all); active lanes per visited pair {S['bwd_lane_active']/max(S['bwd_pairs'],1):.1f}/64")
+print(f"backward: pairs with at least one active lane {S['bwd_pairs_live']} ({S['bwd_pairs_live']/S['pairs']:.3f} of all accepted)")
 print(f"forward: ideal stop {S['fwd_ideal']} ({S['fwd_ideal']/S['pairs']:.3f}); live-hit lanes per visited pair {fwd_lane_live/max(S['fwd_ideal'],1):.1f}/64")
 for g, v in fwd_g.items():
     print(f"   check every {g:3d} entries: {v} pairs ({v/S['pairs']:.3f})")

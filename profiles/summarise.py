@@ -9,6 +9,7 @@ import re
 import sys
 
 tag, rnd = sys.argv[1], sys.argv[2]
+config = sys.argv[3] if len(sys.argv) > 3 else "cfg3"
 root = f"gpurun_out/{tag}"
 
 SHORT = [("k_render_bwd", "render_bwd"), ("k_render_fwd", "render_fwd"), ("k_tile_rank_sort", "tile_sort"),
@@ -16,7 +17,8 @@ SHORT = [("k_render_bwd", "render_bwd"), ("k_render_fwd", "render_fwd"), ("k_til
          ("k_preprocess_bwd", "preprocess_bwd"), ("k_scan_tiles", "scan_tiles"), ("k_sample_f12", "sample_f12"),
          ("k_sample_f3", "sample_f3"), ("k_sample_bwd<1>", "sample_b1"),
           ("k_sample_bwd<3>", "sample_b3"), ("k_attrs_fwd", "attrs_fwd"),
-         ("k_attrs_bwd", "attrs_bwd"), ("k_zero_vec", "zero_fill"), ("k_zero_words", "zero_fill")]
+         ("k_attrs_bwd", "attrs_bwd"), ("k_zero_vec", "zero_fill"), ("k_zero_words", "zero_fill"),
+         ("k_view_fwd", "view_fwd"), ("k_view_bwd", "view_bwd")]
 
 
 def short(name):
@@ -63,7 +65,7 @@ with open(f"profiles/{rnd}_pmc.csv", "w") as o:
 traffic = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, profiles/collect.sh), bench.py --steps 4 serial "
                    "eager view mode cfg3, per-launch averages; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE "
                    "half-count correction of MI355X_MICROARCH.md; WRITE_SIZE uncalibrated)",
-           "round": int(rnd[1:]), "snapshot": tag, "kernels": {}}
+           "round": int(rnd[1:]), "snapshot": tag, "config": config, "kernels": {}}
 for k in agg:
     if "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
         fv, wv = agg[k]["FETCH_SIZE"], agg[k]["WRITE_SIZE"]
