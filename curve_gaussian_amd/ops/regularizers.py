@@ -106,7 +106,8 @@ class _CurveRegularizers(torch.autograd.Function):
 
 def curve_regularizers(gaussians, radii, w_opacity=0.01, opacity_gate=1.0, w_smooth=0.1, w_width=0.01, width_thr=0.005):
     """opacity_loss * gate + curve_smoothness_loss + width_loss (the three functions above), fused.
-    opacity_gate: float or 0-dim device tensor (train.py's ``reset_timestep > 0``)."""
+    opacity_gate: float or 0-dim device tensor (train.py:114's ``reset_timestep > 0``; the counter is incremented at the
+    top of every iteration, train.py:76, so the gate is 1 from the first iteration on)."""
     return _CurveRegularizers.apply(gaussians._rotation, gaussians._opacity, gaussians._width, radii, gaussians.n_gaussians,
                                     w_opacity, opacity_gate, w_smooth, w_width, width_thr)
 

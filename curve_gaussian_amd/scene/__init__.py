@@ -1,1 +1,1 @@
-from .gaussian_curve_model import GaussianCurveModel  # noqa: F401
+from .gaussian_curve_model import GaussianCurveModel, Scene, initialize_bezier_curves  # noqa: F401

@@ -21,7 +21,7 @@ import json
 import math
 import os
 from dataclasses import dataclass
-from typing import List
+from typing import List, NamedTuple
 
 import numpy as np
 import torch
@@ -69,16 +69,19 @@ class EdgeCamera:
         return c
 
 
-def camera_from_emap_frame(uid, name, camtoworld, intrinsics, image_chw, znear=0.01, zfar=100.0):
-    """dataset_readers.py:303-324 + cameras.py:53-66 for one frame."""
+def camera_from_emap_frame(uid, name, camtoworld, intrinsics, image_chw, znear=0.01, zfar=100.0, orig_size=None):
+    """dataset_readers.py:303-324 + cameras.py:53-66 for one frame.  `orig_size` = (width, height) of the image file the
+    intrinsics belong to: readEMAP computes the field of view from the ORIGINAL size (:320-321) and loadCam only then
+    rescales the pixels (camera_utils.py:28-42), so a down-scaled image keeps its field of view."""
     c2w = np.array(camtoworld, dtype=np.float64)
     K = np.array(intrinsics, dtype=np.float64)
     w2c = np.linalg.inv(c2w)
     R = np.transpose(w2c[:3, :3])   # stored transposed "due to glm in the CUDA code" (:306)
     T = w2c[:3, 3]
     H, W = int(image_chw.shape[1]), int(image_chw.shape[2])
-    fovy = focal2fov(K[1, 1], H)
-    fovx = focal2fov(K[0, 0], W)
+    ow, oh = orig_size if orig_size is not None else (W, H)
+    fovy = focal2fov(K[1, 1], oh)
+    fovx = focal2fov(K[0, 0], ow)
     wv = torch.tensor(world2view(R, T)).transpose(0, 1).contiguous()
     proj = projection_matrix(znear, zfar, fovx, fovy).transpose(0, 1)
     full = (wv.unsqueeze(0).bmm(proj.unsqueeze(0))).squeeze(0).contiguous()
@@ -113,8 +116,39 @@ def read_emap(path, transformsfile="meta_data.json", detector="DexiNed", max_wid
             res = (int(ow / scale), int(oh / scale))
         rgb = torch.cat([_pil_to_chw(im, res) for im in image.split()[:3]], dim=0).float()
         name = os.path.splitext(os.path.basename(frame["rgb_path"]))[0]
-        cams.append(camera_from_emap_frame(idx, name, frame["camtoworld"], frame["intrinsics"], rgb))
+        cams.append(camera_from_emap_frame(idx, name, frame["camtoworld"], frame["intrinsics"], rgb, orig_size=(ow, oh)))
     return cams
+
+
+class BasicPointCloud(NamedTuple):
+    """utils/graphics_utils.py:17-20"""
+    points: np.ndarray
+    colors: np.ndarray
+    normals: np.ndarray
+
+
+SH_C0 = 0.28209479177387814   # utils/sh_utils.py:24
+
+
+def RGB2SH(rgb):
+    """utils/sh_utils.py:114-115"""
+    return (rgb - 0.5) / SH_C0
+
+
+def SH2RGB(sh):
+    """utils/sh_utils.py:117-118"""
+    return sh * SH_C0 + 0.5
+
+
+def grid_point_cloud(num_pts_per_axis: int = 15, rng=None) -> BasicPointCloud:
+    """The initial point cloud of the EMAP loader (dataset_readers.py:404-412,439-441, init_random_init): a regular
+    num_pts_per_axis^3 grid over [-0.05, 1.05]^3 (meshgrid in 'xy' order, as numpy's default), near-black random colours.
+    `rng`: a numpy Generator / RandomState for the colours (the reference uses the global numpy state)."""
+    x = np.linspace(-0.05, 1.05, num_pts_per_axis)
+    xx, yy, zz = np.meshgrid(x, x, x)
+    xyz = np.vstack([xx.ravel(), yy.ravel(), zz.ravel()]).T
+    rnd = (rng.random if rng is not None else np.random.random)((xyz.shape[0], 3))
+    return BasicPointCloud(points=xyz, colors=SH2RGB(rnd / 255.0), normals=np.zeros((xyz.shape[0], 3)))
 
 
 def write_emap(path, cameras, edge_maps, detector="DexiNed"):

@@ -30,6 +30,14 @@ def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, ma
     return helper
 
 
+def initialize_bezier_curves(points, bound, n_control_points=4):
+    """One cubic Bezier per seed point, laid along +-Y (reference :27-51): P0 = p - (0, bound, 0), P3 = p + (0, bound, 0),
+    P1 / P2 at half that distance.  points [B,3], bound [B,1] -> [B,4,3]."""
+    assert n_control_points == 4
+    direction = torch.cat([torch.zeros_like(bound), bound, torch.zeros_like(bound)], dim=1)
+    return torch.stack([points - direction, points - 0.5 * direction, points + 0.5 * direction, points + direction], dim=1)
+
+
 class GaussianCurveModel:
     def __init__(self, sh_degree: int = 0, n_gaussians: int = 12, optimizer_type: str = "default", device="cuda"):
         self.active_sh_degree = 0
@@ -76,10 +84,53 @@ class GaussianCurveModel:
         self.prepare_scaling_rot()
         return self
 
+    def create_from_pcd(self, pcd, cam_infos, spatial_lr_scale: float, init_size: float = 0.5, n_control_points: int = 4):
+        """Reference :142-178: one curve per point of the seed cloud.  bound = init_size * sqrt(mean squared distance to
+        the 3 nearest neighbours) from the HIP ``simple_knn.distCUDA2``; control points along +-Y; opacity 0.6, width
+        5e-3; DC feature = RGB2SH of the red channel, replicated over the curve's m samples; mask = 1; all curves Bezier;
+        one 3x4 identity exposure per camera.  `pcd`: anything with ``.points`` / ``.colors`` ([N,3] arrays)."""
+        from ..simple_knn import distCUDA2
+        from .dataset_io import RGB2SH
+        dev = self.device
+        m = self.n_gaussians
+        self.spatial_lr_scale = spatial_lr_scale
+        fused_point_cloud = torch.tensor(np.asarray(pcd.points)).float().to(dev)
+        dist2 = torch.clamp_min(distCUDA2(torch.from_numpy(np.asarray(pcd.points)).float().to(dev)), 0.0000001)
+        self.dist = torch.sqrt(dist2).mean()
+        bound = init_size * torch.sqrt(dist2).unsqueeze(1)
+        points_per_curve = initialize_bezier_curves(fused_point_cloud, bound, n_control_points)
+        B = fused_point_cloud.shape[0]
+        opacities = torch.logit(0.6 * torch.ones((B, 1), dtype=torch.float, device=dev))   # inverse_sigmoid
+        widths = self.scaling_inverse_activation(5e-3 * torch.ones((B, 1), dtype=torch.float, device=dev))
+        pcd_colors = np.asarray(pcd.colors)[:, None, :].repeat(m, axis=1)
+        fused_color = RGB2SH(torch.tensor(np.asarray(pcd_colors[..., 0:1])).float().to(dev))
+        features = torch.zeros((B, m, 1, (self.max_sh_degree + 1) ** 2)).float().to(dev)
+        features[:, :, :1, 0] = fused_color
+        features[:, :, 1:, 1:] = 0.0
+        self._curve_points = nn.Parameter(points_per_curve.contiguous().requires_grad_(True))
+        self._features_dc = nn.Parameter(features[:, :, :, 0:1].transpose(2, 3).contiguous().requires_grad_(True))
+        self._features_rest = nn.Parameter(features[:, :, :, 1:].transpose(2, 3).contiguous().requires_grad_(True))
+        self._opacity = nn.Parameter(opacities.requires_grad_(True))
+        self._width = nn.Parameter(widths.requires_grad_(True))
+        self._mask = nn.Parameter(torch.ones((B, m, 1), device=dev).requires_grad_(True))
+        self.max_radii2D = torch.zeros(B * m, device=dev)
+        self.is_bezier = torch.ones(B, dtype=torch.bool, device=dev)
+        cam_infos = list(cam_infos) if cam_infos is not None else []
+        self.exposure_mapping = {cam_info.image_name: idx for idx, cam_info in enumerate(cam_infos)}
+        self.pretrained_exposures = None
+        exposure = torch.eye(3, 4, device=dev)[None].repeat(len(cam_infos), 1, 1)
+        self._exposure = nn.Parameter(exposure.requires_grad_(True))
+        self.prepare_scaling_rot()
+        return self
+
     def training_setup(self, feature_lr=0.0025, opacity_lr=0.025, scaling_lr=0.005, lr_curve_points_init=0.0005,
                        mask_lr=0.01, lr_curve_points_final=0.000005, position_lr_delay_mult=0.01,
                        position_lr_max_steps=30000):
-        """Adam groups of the reference (:200-213; lrs from arguments/__init__.py:83-89)."""
+        """Adam groups of the reference (:200-213; lrs from arguments/__init__.py:83-89); the densification statistics
+        start at zero (:201-202)."""
+        P = self._curve_points.shape[0] * self.n_gaussians
+        self.denom = torch.zeros((P, 1), device=self._curve_points.device)
+        self.xyz_gradient_accum = torch.zeros((P, 1), device=self._curve_points.device)
         l = [
             {'params': [self._features_dc], 'lr': feature_lr, "name": "f_dc"},
             {'params': [self._features_rest], 'lr': feature_lr / 20.0, "name": "f_rest"},
@@ -160,6 +211,29 @@ class GaussianCurveModel:
         self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1,
                                                              keepdim=True)
         self.denom[update_filter] += 1
+
+
+class Scene:
+    """What the reference's ``Scene(args, gaussians)`` (scene/__init__.py:27-92) does for an EMAP scan, minus the file
+    copies: read the cameras (dataset_io.read_emap = readEMAP + loadCam), build the seed cloud of rendemapInfo
+    (dataset_readers.py:404-441: the 15^3 grid when ``init_random_init``) and call ``gaussians.create_from_pcd``."""
+
+    def __init__(self, source_path, gaussians, detector="DexiNed", num_pts_per_axis=15, cameras_extent=None, rng=None,
+                 device=None):
+        from . import dataset_io
+        self.gaussians = gaussians
+        self.train_cameras = dataset_io.read_emap(source_path, detector=detector)
+        self.point_cloud = dataset_io.grid_point_cloud(num_pts_per_axis, rng)
+        if cameras_extent is None:   # getNerfppNorm (dataset_readers.py:46-67): 1.1 x the largest distance to the mean centre
+            centres = torch.stack([c.camera_center for c in self.train_cameras]).double()
+            cameras_extent = float((centres - centres.mean(0)).norm(dim=1).max() * 1.1)
+        self.cameras_extent = cameras_extent
+        if device is not None:
+            self.train_cameras = [c.to(device) for c in self.train_cameras]
+        gaussians.create_from_pcd(self.point_cloud, self.train_cameras, self.cameras_extent)
+
+    def getTrainCameras(self, scale=1.0):
+        return self.train_cameras
 
 
 def _install_topology():

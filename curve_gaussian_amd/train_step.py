@@ -31,7 +31,8 @@ class TrainStep:
         self.opacity_loss_weight, self.lambda_curve_smo, self.lambda_width = opacity_loss_weight, lambda_curve_smo, lambda_width
         # train.py:133-146: end-point connection loss, from iteration conn_from_iter + 1 on (part of `regularisers`)
         self.lambda_points_conn, self.conn_from_iter = lambda_points_conn, conn_from_iter
-        self.reset_timestep = 0    # train.py:113: the opacity term is active after an opacity reset
+        self.reset_timestep = 0    # train.py:74-76: 0 before the loop, += 1 at the top of EVERY iteration -- the
+                                   # `reset_timestep > 0` gate of the opacity term (train.py:114) is true from iteration 1
         self.pipe = PipelineParams()
         self.bg = torch.zeros(3, device=gaussians.device)
         self.rng = random.Random(seed + rank)     # rank-dependent view choice
@@ -92,6 +93,7 @@ class TrainStep:
     def step(self, view_index=None):
         g = self.g
         self.iteration += 1
+        self.reset_timestep += 1                   # train.py:76
         it = self.iteration
         g.update_learning_rate(it)
         vi = self._next_view() if view_index is None else view_index
@@ -463,6 +465,7 @@ class GraphedTrainStep(TrainStep):
             self._graph = None
         self._check_overflow()
         self.iteration += 1
+        self.reset_timestep += 1                   # train.py:76
         g.update_learning_rate(self.iteration)
         vi = self._next_view() if view_index is None else view_index
         if self._graph is None:

@@ -270,3 +270,40 @@ def knn_mean_dist2(points):
         fmax = torch.full((P, 3 - k), 3.4028234663852886e38, dtype=torch.float64)
         best = torch.cat([best, fmax], 1)
     return (best.sum(1) / 3.0).float()
+
+
+# ----------------------------------------------------------------------------- model initialisation
+def initialize_bezier_curves(points, bound, n_control_points=4):
+    """/root/reference/scene/gaussian_curve_model.py:27-51 restated."""
+    assert n_control_points == 4
+    direction = torch.cat([torch.zeros_like(bound), bound, torch.zeros_like(bound)], dim=1)
+    P0 = points - direction
+    P3 = points + direction
+    P1 = points - 0.5 * direction
+    P2 = points + 0.5 * direction
+    return torch.stack([P0, P1, P2, P3], dim=1)
+
+
+def create_from_pcd(points, colors, n_gaussians=12, max_sh_degree=0, init_size=0.5):
+    """/root/reference/scene/gaussian_curve_model.py:142-178 restated on the CPU (distCUDA2 -> brute-force 3-NN):
+    returns the tensors create_from_pcd installs on the model, plus the derived per-splat tensors."""
+    C0 = 0.28209479177387814
+    pts = torch.as_tensor(points).float()
+    B = pts.shape[0]
+    dist2 = torch.clamp_min(knn_mean_dist2(pts), 0.0000001)
+    bound = init_size * torch.sqrt(dist2).unsqueeze(1)
+    cp = initialize_bezier_curves(pts, bound)
+    opac = torch.full((B, 1), 0.6)
+    opacities = torch.log(opac / (1 - opac))                         # inverse_sigmoid, utils/general_utils.py:88-89
+    widths = torch.log(5e-3 * torch.ones(B, 1))
+    pcd_colors = torch.as_tensor(colors).float()[:, None, :].repeat(1, n_gaussians, 1)
+    fused_color = (pcd_colors[..., 0:1] - 0.5) / C0                  # RGB2SH
+    features = torch.zeros(B, n_gaussians, 1, (max_sh_degree + 1) ** 2)
+    features[:, :, :1, 0] = fused_color
+    out = dict(curve_points=cp, opacity=opacities, width=widths,
+               features_dc=features[:, :, :, 0:1].transpose(2, 3).contiguous(),
+               features_rest=features[:, :, :, 1:].transpose(2, 3).contiguous(),
+               mask=torch.ones(B, n_gaussians, 1), is_bezier=torch.ones(B, dtype=torch.bool),
+               dist=torch.sqrt(dist2).mean())
+    out["xyz"], out["rotation"], out["scaling"] = prepare_scaling_rot(cp, widths, out["is_bezier"], n_gaussians)
+    return out

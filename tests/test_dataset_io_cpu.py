@@ -108,3 +108,37 @@ def test_splat_snapshot_ply_round_trip(tmp_path):
     np.testing.assert_allclose(1.0 / (1.0 + np.exp(-v["opacity"].astype(np.float64))), g.get_opacity[:, 0].numpy(), rtol=1e-5)
     np.testing.assert_array_equal(np.stack([v[f"scale_{i}"] for i in range(3)], 1), g._scaling.numpy())
     np.testing.assert_array_equal(np.stack([v[f"rot_{i}"] for i in range(4)], 1), g._rotation.numpy())
+
+
+def test_emap_wide_images_keep_their_field_of_view(tmp_path):
+    """Images wider than 1600 px are rescaled by loadCam (camera_utils.py:28-42) AFTER readEMAP computed the field of view
+    from the original size (dataset_readers.py:320-321): the pixels shrink, the projection does not change."""
+    from PIL import Image
+    ow, oh = 2000, 1000
+    cam = S.make_camera((1.5, 0.2, 0.4), (0.5, 0.5, 0.5), (0, 0, 1), oh, ow, fovx=0.9, fovy=0.5)
+    os.makedirs(tmp_path / "edge_DexiNed")
+    Image.fromarray((np.random.default_rng(0).random((oh, ow)) * 255).astype(np.uint8)).save(tmp_path / "edge_DexiNed" / "0_colors.png")
+    K = np.eye(4)
+    K[0, 0], K[1, 1] = IO.fov2focal(cam.FoVx, ow), IO.fov2focal(cam.FoVy, oh)
+    K[0, 2], K[1, 2] = ow / 2, oh / 2
+    c2w = np.linalg.inv(cam.world_view_transform.numpy().T.astype(np.float64))
+    json.dump({"height": oh, "width": ow, "frames": [{"rgb_path": "0_colors.png", "camtoworld": c2w.tolist(),
+                                                      "intrinsics": K.tolist()}]}, open(tmp_path / "meta_data.json", "w"))
+    back = IO.read_emap(str(tmp_path))[0]
+    assert (back.image_width, back.image_height) == (1600, 800)
+    np.testing.assert_allclose([back.FoVx, back.FoVy], [IO.focal2fov(K[0, 0], ow), IO.focal2fov(K[1, 1], oh)], rtol=1e-12)
+    np.testing.assert_allclose([back.FoVx, back.FoVy], [cam.FoVx, cam.FoVy], rtol=1e-9)
+    np.testing.assert_allclose(back.full_proj_transform.numpy(), cam.full_proj_transform.numpy(), atol=2e-5)
+
+
+def test_grid_point_cloud_is_the_reference_seed_grid():
+    """dataset_readers.py:404-412: 15^3 points, np.meshgrid's default 'xy' ordering, colours SH2RGB(U[0,1)/255)."""
+    pcd = IO.grid_point_cloud(15, np.random.default_rng(1))
+    assert pcd.points.shape == (3375, 3) and pcd.colors.shape == (3375, 3) and not pcd.normals.any()
+    x = np.linspace(-0.05, 1.05, 15)
+    np.testing.assert_array_equal(pcd.points[0], [x[0], x[0], x[0]])
+    np.testing.assert_array_equal(pcd.points[1], [x[0], x[0], x[1]])      # z runs fastest
+    np.testing.assert_array_equal(pcd.points[15], [x[1], x[0], x[0]])     # then x ('xy' meshgrid), then y
+    np.testing.assert_array_equal(pcd.points[225], [x[0], x[1], x[0]])
+    assert 0.5 <= pcd.colors.min() and pcd.colors.max() <= 0.5 + IO.SH_C0 / 255 + 1e-12
+    np.testing.assert_allclose(IO.RGB2SH(IO.SH2RGB(np.array([0.1, 0.7]))), [0.1, 0.7])

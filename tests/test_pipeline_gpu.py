@@ -301,10 +301,38 @@ def test_cfg1_plumbing_scan_on_disk_to_parametric_edges(tmp_path):
     np.testing.assert_allclose(np.array(saved["curves_ctl_pts"]), gm._curve_points.detach().cpu().numpy(), rtol=1e-6)
 
 
+def test_scene_builds_the_model_from_a_scan_like_the_reference(tmp_path):
+    """scene/__init__.py:27-92 for an EMAP scan: cameras from meta_data.json, the 15^3 seed grid, create_from_pcd (HIP
+    distCUDA2) -- then the reference's training_setup and a few eager iterations on the HIP path."""
+    from curve_gaussian_amd.gaussian_renderer import PipelineParams, render
+    from curve_gaussian_amd.scene import GaussianCurveModel, Scene, dataset_io as IO
+    from curve_gaussian_amd.train_step import TrainStep
+    H = W = 128
+    cams = S.fibonacci_cameras(4, H, W)
+    g = torch.Generator().manual_seed(0)
+    maps = [(torch.rand(1, H, W, generator=g) > 0.97).float() for _ in cams]
+    IO.write_emap(str(tmp_path / "scan"), cams, maps)
+    gm = GaussianCurveModel(0, 12, device=DEV)
+    scene = Scene(str(tmp_path / "scan"), gm, rng=np.random.default_rng(0), device=DEV)
+    assert gm._curve_points.shape == (3375, 4, 3) and gm._xyz.shape == (3375 * 12, 3)
+    assert len(scene.getTrainCameras()) == 4 and gm.exposure_mapping == {"0_colors": 0, "1_colors": 1, "2_colors": 2, "3_colors": 3}
+    centres = np.stack([c.camera_center.numpy() for c in cams])
+    np.testing.assert_allclose(scene.cameras_extent, 1.1 * np.linalg.norm(centres - centres.mean(0), axis=1).max(), rtol=1e-5)
+    out = render(scene.getTrainCameras()[0], gm, PipelineParams(), torch.zeros(3, device=DEV))
+    assert out["render"].shape == (1, H, W) and float(out["render"].max()) > 0
+    ts = TrainStep(gm, scene.getTrainCameras(), [c.original_image[:1].contiguous() for c in scene.getTrainCameras()], seed=0)
+    l0 = float(ts.step()[0])
+    for _ in range(5):
+        l = float(ts.step()[0])
+    assert np.isfinite([l0, l]).all()
+    assert gm.xyz_gradient_accum.shape == (3375 * 12, 1)
+
+
 def test_regularisers_match_the_reference_formulas():
     """ops/regularizers.py (sync-free masked means) against train.py:113-131 written out literally with its host-side
     conditions, values and gradients; then the eager and the graphed train step with regularisers on agree."""
     import torch.nn.functional as F
+    from curve_gaussian_amd.gaussian_renderer import PipelineParams, render
     from curve_gaussian_amd.ops import regularizers as RG
     from curve_gaussian_amd.train_step import GraphedTrainStep, TrainStep
     gm, cams, gts = _train_fixture()
@@ -357,14 +385,26 @@ def test_regularisers_match_the_reference_formulas():
     with torch.no_grad():
         gm._width.fill_(-9.0)
     assert float(RG.width_loss(gm)) == 0.0
+    # train.py:74-76,114: reset_timestep is incremented at the top of every iteration, so the opacity term is part of
+    # the loss from the FIRST iteration: default regularisers=True step == photometric loss + the literal formulas
+    torch.manual_seed(0); g0, cams0, gts0 = _train_fixture()
+    torch.manual_seed(0); g1, _, _ = _train_fixture()
+    with torch.no_grad():
+        rad0 = render(cams0[0], g1, PipelineParams(), torch.zeros(3, device=DEV))["radii"]
+        want = (RG.opacity_loss(g1, rad0, 0.01) + RG.curve_smoothness_loss(g1, rad0, 0.1) + RG.width_loss(g1, 0.01))
+    plain = TrainStep(g0, cams0, gts0, seed=4).step(view_index=0)[0]
+    with_regs = TrainStep(g1, cams0, gts0, seed=4, regularisers=True)
+    assert with_regs.reset_timestep == 0
+    l_regs = with_regs.step(view_index=0)[0]
+    assert with_regs.reset_timestep == 1 and float(want) > 0
+    np.testing.assert_allclose(float(l_regs) - float(plain), float(want), rtol=2e-3, atol=1e-7)
     # eager vs graphed step with the regularisers switched on
     torch.manual_seed(0); ga, cams, gts = _train_fixture()
     torch.manual_seed(0); gb, _, _ = _train_fixture()
     ea = TrainStep(ga, cams, gts, seed=4, regularisers=True)
     gs = GraphedTrainStep(gb, cams, gts, seed=4, regularisers=True)
-    for it in range(8):
-        if it == 4:
-            ea.reset_timestep = gs.reset_timestep = 1     # opacity term switches on without a re-capture
+    ea.reset_timestep = gs.reset_timestep = -4            # (a resumed counter: the gate opens at the fifth iteration,
+    for it in range(8):                                   #  on the device, without a re-capture)
         la = ea.step()[0]
         lb = gs.step()[0]
     gs.finish()
@@ -383,9 +423,8 @@ def test_graphed_train_step_autograd_body_matches_direct_body(regs):
     torch.manual_seed(0); gb, _, _ = _train_fixture()
     sa = GraphedTrainStep(ga, cams, gts, seed=8, direct=False, regularisers=regs, densify_until_iter=6)
     sb = GraphedTrainStep(gb, cams, gts, seed=8, direct=True, regularisers=regs, densify_until_iter=6)
+    sa.reset_timestep = sb.reset_timestep = -3
     for it in range(10):
-        if it == 3:
-            sa.reset_timestep = sb.reset_timestep = 1
         la, lb = sa.step()[0], sb.step()[0]
     sa.finish(); sb.finish()
     np.testing.assert_allclose(float(lb), float(la), rtol=1e-4)
