@@ -30,7 +30,10 @@ def _bezier_mask(is_bezier, dev):
         if len(_ALL_BEZIER_CACHE) > 64:
             _ALL_BEZIER_CACHE.clear()
         allb = bool(is_bezier.all())
-        hit = (allb, None if allb else is_bezier.to(device=dev, dtype=torch.uint8).contiguous())
+        # the entry holds the key tensor itself: while it is cached its storage cannot be freed and handed to a NEW
+        # is_bezier tensor with the same address and version 0 (topology edits allocate fresh ones), which would alias
+        # a stale mask
+        hit = (allb, None if allb else is_bezier.to(device=dev, dtype=torch.uint8).contiguous(), is_bezier)
         _ALL_BEZIER_CACHE[key] = hit
     return hit[1]
 

@@ -14,8 +14,10 @@ Reference: /root/reference/scene/gaussian_curve_model.py
 
 The functions take the model as first argument and are installed as methods of
 ``curve_gaussian_amd.scene.GaussianCurveModel`` under the reference's names.  Parity: the reference's scene package
-cannot be imported here (open3d / pytorch3d / simple_knn missing), so these are restatements checked through their
-mathematical properties (tests/test_topology_gpu.py) -- parity unpinned."""
+cannot be imported here (open3d / pytorch3d / simple_knn missing); the checker is oracle/topology_ref.py, a
+statement-by-statement CPU restatement of the cited lines over a real torch.optim.Adam -- parameters, statistics
+buffers, derived splat tensors and the Adam moments of every group are compared after each edit for both optimizer back
+ends (tests/test_topology_oracle_gpu.py), next to the property tests of tests/test_topology_gpu.py."""
 import torch
 from torch import nn
 

@@ -14,7 +14,7 @@ _LIB = None
 def build(force: bool = False) -> str:
     """Compile oracle/*.c into oracle/liboracle.so with gcc (seconds)."""
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("raster_ref.c", "satellites_ref.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("raster_ref.c",)]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
