@@ -157,6 +157,13 @@ def _stats_buffers(g):
     g.max_radii2D = torch.zeros((P,), device=dev)
 
 
+def _check_ranks(g):
+    """View-parallel runs: every rank must come out of a topology edit with the same number of curves (one small
+    all-reduce per public edit; no-op on a single rank)."""
+    from ..view_parallel import assert_same_topology
+    assert_same_topology(int(g._curve_points.shape[0]), g._curve_points.device)
+
+
 def prune_curves(g, mask):
     """:283-304 -- remove the curves where mask is True."""
     valid = ~mask
@@ -206,6 +213,8 @@ def densify_and_split_curve(g, selected_pts_mask, t, N=2):
 def densify_and_prune(g, max_grad, min_opacity, extent=None, max_screen_size=None, radii=None):
     """:351-365 -- split the curves whose largest per-splat mean screen-space gradient reaches max_grad at the sample
     where it is largest, then prune curves below min_opacity."""
+    from ..view_parallel import sync_densification_stats
+    sync_densification_stats(g)      # view-parallel runs: statistics of all ranks' views (no-op on one rank)
     grads = g.xyz_gradient_accum / g.denom
     grads[grads.isnan()] = 0.0
     g.tmp_radii = radii
@@ -218,6 +227,7 @@ def densify_and_prune(g, max_grad, min_opacity, extent=None, max_screen_size=Non
         densify_and_split_curve(g, selected, t.squeeze(-1))
     prune_mask = (g.get_curve_opacity < min_opacity).squeeze(-1)
     prune_curves(g, prune_mask)
+    _check_ranks(g)
 
 
 def curve_split_curvature(g, threshold_angle=20, threshold_radian_skip=30):
@@ -238,6 +248,7 @@ def curve_split_curvature(g, threshold_angle=20, threshold_radian_skip=30):
     if int(mask_split.sum()) > 0:
         densify_and_split_curve(g, mask_split, end_t[mask_split].squeeze(-1))
     g.prepare_scaling_rot()
+    _check_ranks(g)
 
 
 def only_prune(g, min_opacity, mask_threshold):
@@ -247,6 +258,7 @@ def only_prune(g, min_opacity, mask_threshold):
                                   (g.get_curve_opacity.detach() < min_opacity).squeeze(-1))
     small = g._scaling[:, 0].clone().detach().reshape(-1, m).sum(-1) < 1e-2
     prune_curves(g, torch.logical_or(small, prune_mask))
+    _check_ranks(g)
 
 
 def reset_opacity(g):

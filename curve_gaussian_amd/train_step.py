@@ -35,7 +35,8 @@ class TrainStep:
                                    # `reset_timestep > 0` gate of the opacity term (train.py:114) is true from iteration 1
         self.pipe = PipelineParams()
         self.bg = torch.zeros(3, device=gaussians.device)
-        self.rng = random.Random(seed + rank)     # rank-dependent view choice
+        self.rng = random.Random(seed)            # the SAME stream on every rank: rank r takes the r-th of each group of
+                                                  # `world` draws (train.py:85-90 pops one random view per iteration)
         self.stack = []
         self.rank, self.world = rank, world
         if gaussians.optimizer is None:
@@ -86,9 +87,14 @@ class TrainStep:
         return reg
 
     def _next_view(self):
-        if not self.stack:
-            self.stack = list(range(len(self.cams)))
-        return self.stack.pop(self.rng.randint(0, len(self.stack) - 1))   # train.py:85-90
+        mine = None
+        for r in range(max(1, self.world)):      # every rank draws the whole group: the streams stay in lock step
+            if not self.stack:
+                self.stack = list(range(len(self.cams)))
+            v = self.stack.pop(self.rng.randint(0, len(self.stack) - 1))   # train.py:85-90
+            if r == self.rank:
+                mine = v
+        return mine
 
     def step(self, view_index=None):
         g = self.g

@@ -17,6 +17,42 @@ def shard_views(n_views: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_views, world))
 
 
+def _dist_world(group=None):
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None, 1
+    return dist, dist.get_world_size(group)
+
+
+def sync_densification_stats(g, group=None):
+    """Make the densification statistics of a view-parallel run rank-consistent right before a topology decision: every
+    rank accumulated ``xyz_gradient_accum`` / ``denom`` (gaussian_model.py:618-620) over ITS views only, so the sums are
+    all-reduced (the quotient densify_and_prune thresholds, gaussian_curve_model.py:352, becomes the mean over the views
+    of all ranks) and ``max_radii2D`` takes the maximum.  With identical parameters (same all-reduced gradients, same
+    Adam step) every rank then takes the same split / prune decisions and the flat buffers keep the same size.
+    8 B/splat + 4 B/splat, only on densification iterations.  No-op without a process group."""
+    dist, world = _dist_world(group)
+    if world == 1:
+        return
+    for name, op in (("xyz_gradient_accum", dist.ReduceOp.SUM), ("denom", dist.ReduceOp.SUM), ("max_radii2D", dist.ReduceOp.MAX)):
+        t = getattr(g, name, None)
+        if t is not None and t.numel():
+            dist.all_reduce(t, op=op, group=group)
+
+
+def assert_same_topology(n_curves: int, device=None, group=None):
+    """Raises on every rank if the ranks disagree on the number of curves (the next gradient all-reduce would mix
+    buffers of different sizes)."""
+    dist, world = _dist_world(group)
+    if world == 1:
+        return
+    t = torch.tensor([n_curves, -n_curves], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    if int(t[0]) != -int(t[1]):
+        raise RuntimeError(f"view-parallel ranks diverged: curve counts between {-int(t[1])} and {int(t[0])} after a "
+                           "topology edit (were the densification statistics synchronised?)")
+
+
 class ViewStreams:
     """Keeps several independent views in flight on one GPU by rotating them over `n` HIP streams.
 

@@ -79,3 +79,101 @@ def test_flat_layout_matches_survey_message_size():
     a, b = f.slices["width"]
     assert float(f.flat[a:b].sum()) == 5.0 and float(f.flat.sum()) == 5.0
     f.all_reduce()  # no process group: no-op
+
+
+# ---------------------------------------------------------------- topology edits stay rank-consistent
+def _cpu_model(B=40, seed=3):
+    """The product's curve model and topology code on CPU tensors: only prepare_scaling_rot (a HIP op in the product) is
+    swapped for the torch restatement of the oracle -- this test is about the host logic around it."""
+    sys.path.insert(0, ROOT)
+    from curve_gaussian_amd import synthetic as S
+    from curve_gaussian_amd.scene import GaussianCurveModel
+    from oracle import torch_ref as TR
+
+    class CpuModel(GaussianCurveModel):
+        def prepare_scaling_rot(self, eps=1e-8):
+            self._xyz, self._rotation, self._scaling = TR.prepare_scaling_rot(self._curve_points, self._width,
+                                                                              self.is_bezier, self.n_gaussians, eps)
+    g = torch.Generator().manual_seed(seed)
+    c = S.make_curves(B, seed)
+    c["opacity"] = torch.randn(B, 1, generator=g) * 2
+    gm = CpuModel(0, 12, device="cpu").create_from_curves(c["curve_points"], c["width"], c["opacity"], c["mask"], c["is_bezier"])
+    gm.training_setup()
+    return gm
+
+
+def _local_stats(gm, rank):
+    """What one rank accumulates over ITS views: different on every rank."""
+    g = torch.Generator().manual_seed(100 + rank)
+    P = gm._xyz.shape[0]
+    for _ in range(3):
+        class VS:
+            grad = torch.randn(P, 3, generator=g) * 3e-4
+        gm.add_densification_stats(VS, torch.rand(P, generator=g) > 0.4)
+    gm.max_radii2D = torch.rand(P, generator=g) * 10
+
+
+def _topology_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from curve_gaussian_amd.view_parallel import FlatGrads
+    gm = _cpu_model()
+    _local_stats(gm, rank)
+    thr = 6.2e-4
+    gm.densify_and_prune(thr, 0.1, 1.0, 20, torch.zeros(gm._xyz.shape[0], dtype=torch.int32))
+    named = {"curve_points": gm._curve_points, "width": gm._width, "opacity": gm._opacity, "mask": gm._mask}
+    flat = FlatGrads(named)          # the next step's exchange buffer: same size on every rank, or all_reduce would fail
+    flat.flat.fill_(float(rank + 1))
+    flat.all_reduce()
+    torch.save({"cp": gm._curve_points.detach().clone(), "op": gm._opacity.detach().clone(), "isb": gm.is_bezier.clone(),
+                "n": flat.flat.numel(), "sum": float(flat.flat[0]), "denom": gm.denom.clone()}, out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_take_the_same_densify_and_prune_decisions(tmp_path):
+    """Each rank accumulates densification statistics over its own views; densify_and_prune all-reduces them first
+    (sum, sum, max), so both ranks split / prune the same curves and end with identical shapes and parameters -- equal to
+    a single process that saw all the views."""
+    out = str(tmp_path / "topo.pt")
+    mp.spawn(_topology_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    a, b = torch.load(out + ".0"), torch.load(out + ".1")
+    assert a["n"] == b["n"] and a["sum"] == 3.0
+    assert torch.equal(a["cp"], b["cp"]) and torch.equal(a["op"], b["op"]) and torch.equal(a["isb"], b["isb"])
+    # single process with the statistics of both ranks
+    gm = _cpu_model()
+    other = _cpu_model()
+    _local_stats(gm, 0)
+    _local_stats(other, 1)
+    gm.xyz_gradient_accum += other.xyz_gradient_accum
+    gm.denom += other.denom
+    n_before = gm._curve_points.shape[0]
+    gm.densify_and_prune(6.2e-4, 0.1, 1.0, 20, torch.zeros(gm._xyz.shape[0], dtype=torch.int32))
+    assert gm._curve_points.shape[0] != n_before          # the edit really changed the topology
+    assert torch.equal(a["cp"], gm._curve_points.detach()) and torch.equal(a["op"], gm._opacity.detach())
+    # without the synchronisation the two ranks WOULD diverge: their local statistics select different curves
+    g0, g1 = _cpu_model(), _cpu_model()
+    _local_stats(g0, 0)
+    _local_stats(g1, 1)
+    sel = lambda g: (((g.xyz_gradient_accum / g.denom).nan_to_num(0.0)).reshape(-1, 12).max(1).values >= 6.2e-4)
+    assert not torch.equal(sel(g0), sel(g1))
+
+
+def test_ranks_draw_disjoint_views_from_one_stream():
+    """TrainStep._next_view: every rank runs the same random stream and takes its own element of each group of `world`
+    draws -- no view is rendered twice in one step, every view once per epoch (train.py:85-90 across ranks)."""
+    import random
+    from curve_gaussian_amd.train_step import TrainStep
+
+    def draws(rank, world, n_cams, steps):
+        t = TrainStep.__new__(TrainStep)
+        t.rng, t.stack, t.rank, t.world, t.cams = random.Random(5), [], rank, world, list(range(n_cams))
+        return [t._next_view() for _ in range(steps)]
+    a, b = draws(0, 2, 8, 8), draws(1, 2, 8, 8)
+    for i in range(8):
+        assert a[i] != b[i]
+    assert sorted(a[:4] + b[:4]) == list(range(8)) and sorted(a[4:] + b[4:]) == list(range(8))
+    assert sorted(draws(0, 1, 5, 5)) == list(range(5))
