@@ -58,17 +58,40 @@ bool check_launch(const char* what, bool debug, hipStream_t s) {
 }
 
 static std::atomic<int> g_tile_cull{1};   // exact tile-level culling of (splat, tile) instances (cgs_set_tile_culling)
-static std::atomic<int64_t> g_R_hint{0};  // num_rendered of the previous forward (speculative binning capacity)
-// Longest tile list seen recently (decaying maximum): sizes the fixed-capacity buckets of the single-pass binning.
-static std::atomic<int64_t> g_max_hint{0};
-static void update_max_hint(uint32_t longest) {
-    const int64_t old = g_max_hint.load(std::memory_order_relaxed);
-    const int64_t decayed = old - old / 16;
-    g_max_hint.store(std::max<int64_t>((int64_t)longest, decayed), std::memory_order_relaxed);
+// Binning capacity hints, one set per workload shape (P, width, height): a process that alternates train and test cameras,
+// two resolutions or two models keeps a separate history for each instead of thrashing one (each mismatch used to cost a
+// bucket overflow and an exact-path redo).  Small LRU table behind a mutex; the three numbers of an entry:
+//   R     num_rendered of the previous forward of this shape (speculative binning capacity of the exact path)
+//   max   longest tile list seen recently (decaying maximum): sizes the fixed-capacity buckets of the single-pass binning
+//   big   splats with oversized tile rects seen by the previous blocking forward: non-zero switches their deferral to
+//         k_scatter_big on (one more launch, only worth it when there are any -- room-scale scenes with near-camera splats)
+struct BinHints { int64_t R = 0, max = 0, big = 0; };
+struct HintEntry { int P = -1, W = 0, H = 0; uint64_t stamp = 0; BinHints h; };
+static std::mutex g_hint_mu;
+static HintEntry g_hint_tab[32];
+static uint64_t g_hint_clock = 0;
+static HintEntry* hint_entry_locked(int P, int W, int H) {
+    HintEntry* lru = &g_hint_tab[0];
+    for (auto& e : g_hint_tab) {
+        if (e.P == P && e.W == W && e.H == H) { e.stamp = ++g_hint_clock; return &e; }
+        if (e.stamp < lru->stamp) lru = &e;
+    }
+    *lru = HintEntry{};
+    lru->P = P; lru->W = W; lru->H = H; lru->stamp = ++g_hint_clock;
+    return lru;
 }
-// Splats with oversized tile rects seen by the previous blocking forward: non-zero switches their deferral to
-// k_scatter_big on (one more launch, only worth it when there are any -- room-scale scenes with near-camera splats).
-static std::atomic<int64_t> g_big_hint{0};
+static BinHints hints_load(int P, int W, int H) {
+    std::lock_guard<std::mutex> lk(g_hint_mu);
+    return hint_entry_locked(P, W, H)->h;
+}
+// R < 0 / big < 0: leave that field; longest: folded into the decaying maximum
+static void hints_update(int P, int W, int H, int64_t R, uint32_t longest, int64_t big) {
+    std::lock_guard<std::mutex> lk(g_hint_mu);
+    BinHints& h = hint_entry_locked(P, W, H)->h;
+    if (R >= 0) h.R = R;
+    if (big >= 0) h.big = big;
+    h.max = std::max<int64_t>((int64_t)longest, h.max - h.max / 16);
+}
 static thread_local int64_t g_last_stats[3] = {0, 0, 0};  // num_rendered, longest tile list, binning path (0 exact, 1 bucket)
 
 // Device-side zero fill.  hipMemsetAsync is NOT used anywhere in the library: captured into a hipGraph (ROCm 7.0 runtime
@@ -131,9 +154,8 @@ size_t cgs_binning_bytes(int64_t R) {
 }
 
 void cgs_reset_binning_hints(void) {
-    g_R_hint.store(0, std::memory_order_relaxed);
-    g_max_hint.store(0, std::memory_order_relaxed);
-    g_big_hint.store(0, std::memory_order_relaxed);
+    std::lock_guard<std::mutex> lk(g_hint_mu);
+    for (auto& e : g_hint_tab) e = HintEntry{};
 }
 int cgs_set_tile_culling(int on) {
     return g_tile_cull.exchange(on ? 1 : 0, std::memory_order_relaxed);
@@ -269,7 +291,8 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
     // for the 16-byte readback (num_rendered is part of the reference's API) while the compositor is already running.
     // A tile that outgrows its bucket raises the overflow flag and the call falls through to the exact path below.
     bool preprocessed = false;
-    const int64_t max_hint = g_max_hint.load(std::memory_order_relaxed);
+    const BinHints hints = hints_load(P, width, height);
+    const int64_t max_hint = hints.max;
     if (cull && !debug && max_hint > 0) {
         const uint64_t cap = (((uint64_t)max_hint * 5 / 4 + 64) + 63) & ~63ull;
         if (cap <= bucket_cap_limit() && cap * (uint64_t)tiles < (1ull << 31)) {
@@ -281,7 +304,7 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
                 return CGS_ERR_ALLOC;
             }
             BinState bin = bin_from_chunk(bchunk, (size_t)(cap * tiles));
-            const bool defer_big = g_big_hint.load(std::memory_order_relaxed) > 0;
+            const bool defer_big = hints.big > 0;
             launch_scatter_bucket(s, P, radii, geom.rec, gx, gy, img.tile_count, bin.keys, (uint32_t)cap, cull, img.total + 3,
                                   defer_big ? img.tile_cursor : nullptr, (uint32_t)tiles);   // (cursors: unused here)
             // (the fused sort+composite kernel is for the sync-free forward only: here num_rendered has to come back to
@@ -296,10 +319,8 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
                 Rb += (int64_t)h_tot[4 + 2 * k];
                 longest = std::max(longest, h_tot[5 + 2 * k]);
             }
-            update_max_hint(longest);
-            g_big_hint.store((int64_t)h_tot[3], std::memory_order_relaxed);
+            hints_update(P, width, height, (uint64_t)longest <= cap ? Rb : -1, longest, (int64_t)h_tot[3]);
             if ((uint64_t)longest <= cap) {
-                g_R_hint.store(Rb, std::memory_order_relaxed);
                 g_last_stats[0] = Rb; g_last_stats[1] = (int64_t)longest; g_last_stats[2] = 1;
                 return Rb;
             }
@@ -324,7 +345,7 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
     // marks the readback; the host then waits on the event only.  If the guess was too small (scene changed a lot)
     // the kernels skipped every tile that would not fit and are re-run on an exact-size buffer.
     if (!read_totals()) return CGS_ERR_HIP;
-    const int64_t hint = g_R_hint.load(std::memory_order_relaxed);
+    const int64_t hint = hints.R;
     int64_t cap = 0;
     char* bchunk = nullptr;
     BinState bin{};
@@ -342,8 +363,7 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
     if (!wait_totals()) return CGS_ERR_HIP;
     const int64_t R = (int64_t)h_tot[0];
     const uint32_t max_count = h_tot[1];
-    g_R_hint.store(R, std::memory_order_relaxed);
-    update_max_hint(max_count);
+    hints_update(P, width, height, R, max_count, -1);
     if (!bchunk || R > cap) {  // first call, debug mode, or the speculative buffer was too small: exact-size (re)run
         if (cap > 0 && zero_async(img.tile_cursor, (size_t)tiles * sizeof(uint32_t), s) != hipSuccess) {
             set_error("zero_async(tile cursors) failed");
@@ -417,7 +437,7 @@ int cgs_rasterize_forward_static(void* geometry_buffer, void* binning_buffer, si
                           cov3D_precomp, colors_precomp, render_geo ? all_map : nullptr, viewmatrix, projmatrix, cam_pos,
                           width, height, tan_fovx, tan_fovy, focal_x, focal_y, radii, geom.rec, geom.rgb, gx, gy, nullptr,
                           antialiasing, 1, geom.grad_acc, img.tile_count, clear_bytes / sizeof(uint32_t));
-    const bool defer_big = g_big_hint.load(std::memory_order_relaxed) > 0;   // (from the caller's probing forwards)
+    const bool defer_big = hints_load(P, width, height).big > 0;   // (from the caller's probing forwards of this shape)
     launch_scatter_bucket(s, P, radii, geom.rec, gx, gy, img.tile_count, bin.keys, (uint32_t)cap, 1, img.total + 3,
                           defer_big ? img.tile_cursor : nullptr, (uint32_t)tiles);
     if (render_fwd_can_sort((uint32_t)cap) && fuse_sort()) {

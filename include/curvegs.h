@@ -286,7 +286,7 @@ int cgs_set_tile_culling(int on);
  *       with cgs_rasterize_forward or a larger capacity); [4 + 2k], [5 + 2k], k < (cgs_status_words() - 4) / 2:
  *       partial sums / maxima of the tile list lengths (num_rendered = sum of the sums, longest list = max of maxima);
  *   [3]: number of splats whose tile rectangle exceeds 96 tiles (near-camera splats of room-scale scenes).  When a
- *       previous cgs_rasterize_forward on this process saw any, such splats are binned by a second kernel, one workgroup
+ *       previous cgs_rasterize_forward of the same (P, width, height) saw any, such splats are binned by a second kernel, one workgroup
  *       each, instead of inside the wave that owns them (cgs_reset_binning_hints clears that memory too).
  * The backward is cgs_rasterize_backward with R = 1.
  * ------------------------------------------------------------------------------------------------ */
@@ -302,7 +302,10 @@ size_t cgs_image_status_offset(int width, int height);
 int cgs_status_words(void);
 uint32_t cgs_bucket_capacity_limit(void);
 
-/* Forget the sizes learnt from earlier forwards (the next forward takes the exact path and re-learns them). */
+/* cgs_rasterize_forward learns, per workload shape (P, width, height), how large the previous forward of that shape was
+ * (num_rendered, longest tile list, oversized splats) and sizes its speculative buffers from it; shapes do not disturb
+ * each other (a process may alternate train / test cameras, resolutions or models; the 32 most recent shapes are kept).
+ * This call forgets everything learnt (the next forward of every shape takes the exact path and re-learns). */
 void cgs_reset_binning_hints(void);
 void cgs_last_forward_stats(int64_t* num_rendered, int64_t* longest_tile_list, int* binning_path);
 

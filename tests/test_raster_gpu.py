@@ -357,7 +357,7 @@ def test_bucket_overflow_falls_back_to_exact_layout():
     dev = torch.device(DEV)
     H, W = 96, 96
     cam = S.make_camera(*CAMS[0], H, W)
-    small = S.random_splats(300, 91)
+    small = S.random_splats(6000, 91, scale_range=(0.0005, 0.002))   # same (P, W, H): the two share one set of hints
     big = S.random_splats(6000, 92, scale_range=(0.02, 0.1))
     fw = oracle_forward(big, cam, torch.zeros(3))
     _raster_raw(small, cam, H, W, dev, reset_hints=True)
@@ -372,6 +372,27 @@ def test_bucket_overflow_falls_back_to_exact_layout():
     out2 = _raster_raw(big, cam, H, W, dev)  # hint now fits: bucket path, same image
     assert _forward_stats()[2] == 1 and out2[0] == out[0] and torch.equal(out2[1], out[1])
     fw.free()
+
+
+def test_binning_hints_are_kept_per_workload_shape():
+    """Alternating two resolutions (and two cloud sizes) must not thrash the learnt binning capacities: after the first
+    forward of each (P, width, height) -- which has to take the exact path -- every forward runs the single-pass bucket
+    path, and the images stay identical to the first ones."""
+    dev = torch.device(DEV)
+    shapes = [(S.random_splats(4000, 95), 96, 144), (S.random_splats(4000, 95), 208, 160),
+              (S.random_splats(1500, 96, scale_range=(0.02, 0.08)), 96, 144)]
+    cams = [S.make_camera(*CAMS[0], H, W) for _, H, W in shapes]
+    first, paths = {}, []
+    for it in range(21):
+        k = it % 3
+        sp, H, W = shapes[k]
+        out = _raster_raw(sp, cams[k], H, W, dev, reset_hints=(it == 0))
+        paths.append(_forward_stats()[2])
+        if k not in first:
+            first[k] = (out[0], out[1].clone())
+        else:
+            assert out[0] == first[k][0] and torch.equal(out[1], first[k][1])
+    assert paths[:3] == [0, 0, 0] and all(p == 1 for p in paths[3:]), paths
 
 
 @pytest.mark.parametrize("H,W,P,cam_i,seed", [(112, 176, 5000, 1, 72), (77, 130, 3000, 2, 73), (50, 70, 800, 0, 74)])
