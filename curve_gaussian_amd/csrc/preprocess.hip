@@ -1,7 +1,7 @@
 // Per-splat kernels: forward preprocess (reference K1: forward.cu:155-274) fused with per-tile counting, and the
 // fused backward of the projection / covariance chain (reference K9 + K10: backward.cu:146-325, :397-448).
 // One thread per splat; memory-bound; no MFMA (no dense contraction on this path).
-#include "kernels.h"
+#include "splat_math.h"
 
 namespace cgs {
 
@@ -124,11 +124,6 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(
     float conic_z = 1.f, tau2 = -1.f;
     if (idx < P) do {
         const float3 p_orig = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
-        const float3 p_view = xform4x3(p_orig, viewmatrix);
-        if (p_view.z <= 0.2f) break;  // near cull only, auxiliary.h:166
-        const float4 p_hom = xform4x4(p_orig, projmatrix);
-        const float p_w = 1.0f / (p_hom.w + 0.0000001f);
-        const float3 p_proj = make_float3(p_hom.x * p_w, p_hom.y * p_w, p_hom.z * p_w);
         float cov3D[6];
         if (cov3D_precomp) {
 #pragma unroll
@@ -138,28 +133,9 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(
             const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
             cov3d_from_scale_rot(s, scale_modifier, q, cov3D);
         }
-        float3 t, cov;
-        float Mt[2][3], txtz, tytz;
-        cov2d_terms(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, viewmatrix, t, Mt, cov, txtz, tytz);
-        constexpr float h_var = 0.3f;
-        const float det_cov = cov.x * cov.z - cov.y * cov.y;
-        cov.x += h_var;
-        cov.z += h_var;
-        const float det_cov_plus_h_cov = cov.x * cov.z - cov.y * cov.y;
-        float h_convolution_scaling = 1.0f;
-        if (antialiasing) h_convolution_scaling = sqrtf(fmaxf(0.000025f, det_cov / det_cov_plus_h_cov));
-        const float det = det_cov_plus_h_cov;
-        if (det == 0.0f) break;
-        const float det_inv = 1.f / det;
-        const float3 conic = make_float3(cov.z * det_inv, -cov.y * det_inv, cov.x * det_inv);
-        const float mid = 0.5f * (cov.x + cov.z);
-        const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
-        const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
-        const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
-        const float px = ndc2pix(p_proj.x, W), py = ndc2pix(p_proj.y, H);
-        uint2 r0, r1;
-        get_rect(px, py, (int)my_radius, grid_x, grid_y, r0, r1);
-        if ((r1.x - r0.x) * (r1.y - r0.y) == 0) break;
+        const ViewParams vp{viewmatrix, projmatrix, tan_fovx, tan_fovy, focal_x, focal_y, W, H, grid_x, grid_y};
+        SplatGeom g;
+        if (!splat_geometry(p_orig, cov3D, vp, antialiasing, g)) break;
         float color;
         if (colors_precomp) {
             color = colors_precomp[idx];
@@ -167,20 +143,15 @@ __global__ void __launch_bounds__(256) k_preprocess_fwd(
             color = sh_to_color(idx, D, M, p_orig, make_float3(cam_pos[0], cam_pos[1], cam_pos[2]), shs, clamped);
             rgb[idx] = color;
         }
-        SplatRec r;
-        r.a = make_float4(px, py, conic.x, conic.y);
-        const float op_eff = opacities[idx] * h_convolution_scaling;
-        r.b = make_float4(conic.z, op_eff, color, 1.f / p_view.z);
-        r.c = all_map ? reinterpret_cast<const float4*>(all_map)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-        // tau2 = 2 ln(255 * opacity): alpha >= 1/255  <=>  conic quadratic form <= tau2 (used by the quadrant culling)
-        r.d = make_float4(p_view.z, my_radius, 2.f * logf(255.f * op_eff), 0.f);
+        const SplatRec r = splat_record(g, opacities[idx], color,
+                                        all_map ? reinterpret_cast<const float4*>(all_map)[idx] : make_float4(0.f, 0.f, 0.f, 0.f));
         rec[idx] = r;
         ra = r.a;
         conic_z = r.b.x;
         tau2 = r.d.z;
-        out_radius = (int)my_radius;
-        rmin = r0;
-        rmax = r1;
+        out_radius = (int)g.radius;
+        rmin = g.rmin;
+        rmax = g.rmax;
     } while (false);
     if (idx < P) radii[idx] = out_radius;
     // per-tile instance counts (replaces the reference's per-splat scan K2 + duplicateWithKeys offsets)
@@ -231,31 +202,14 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(
         accp[0] = z; accp[1] = z; accp[2] = z;
     }
     const bool vis = radii[idx] > 0;
-    float g2x = 0.f, g2y = 0.f, dcx = 0.f, dcy = 0.f, dcz = 0.f;
-    float dopac = acc0.x;
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+    float3 mean = make_float3(0.f, 0.f, 0.f), sc = mean;
+    float4 q = ra;
+    float cov3D[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (vis) {
-        const float4 ra = rec[idx].a, rb = rec[idx].b;
-        const float cA = ra.z, cB = ra.w, cC = rb.x, op = rb.y;
-        g2x = -op * (cA * acc0.y + cB * acc0.z) * (float)(0.5 * W);  // backward.cu:542-543, 659-664
-        g2y = -op * (cC * acc0.z + cB * acc0.y) * (float)(0.5 * H);
-        dcx = -0.5f * op * acc0.w;                                   // backward.cu:667-669
-        dcy = -0.5f * op * acc1.x;
-        dcz = -0.5f * op * acc1.y;
-    }
-    dL_dmean2D[3 * idx] = g2x; dL_dmean2D[3 * idx + 1] = g2y; dL_dmean2D[3 * idx + 2] = 0.f;
-    if (dL_dconic) reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(dcx, dcy, 0.f, dcz);
-    if (dL_dcolor) dL_dcolor[idx] = acc1.z;
-    if (dL_dinvdepth) dL_dinvdepth[idx] = acc1.w;
-    if (dL_dall_map) reinterpret_cast<float4*>(dL_dall_map)[idx] = acc2;
-    float3 dmean = make_float3(0.f, 0.f, 0.f);
-    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float3 dscale = make_float3(0.f, 0.f, 0.f);
-    float4 drot = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (vis) {
-        const float3 mean = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
-        float cov3D[6];
-        float3 sc = make_float3(0.f, 0.f, 0.f);
-        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        ra = rec[idx].a;
+        rb = rec[idx].b;
+        mean = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
         if (cov3D_precomp) {
 #pragma unroll
             for (int i = 0; i < 6; i++) cov3D[i] = cov3D_precomp[6 * (size_t)idx + i];
@@ -264,121 +218,25 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(
             q = reinterpret_cast<const float4*>(rotations)[idx];
             cov3d_from_scale_rot(sc, scale_modifier, q, cov3D);
         }
-        float3 t, cov;
-        float T_[2][3], txtz, tytz;
-        cov2d_terms(mean, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, viewmatrix, t, T_, cov, txtz, tytz);
-        const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
-        const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
-        const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
-        float c_xx = cov.x, c_xy = cov.y, c_yy = cov.z;
-        constexpr float h_var = 0.3f;
-        float d_inside_root = 0.f;
-        if (antialiasing) {
-            const float det_cov = c_xx * c_yy - c_xy * c_xy;
-            c_xx += h_var;
-            c_yy += h_var;
-            const float det_cov_plus_h_cov = c_xx * c_yy - c_xy * c_xy;
-            const float h_convolution_scaling = sqrtf(fmaxf(0.000025f, det_cov / det_cov_plus_h_cov));
-            const float dL_dopacity_v = dopac;
-            const float d_h_convolution_scaling = dL_dopacity_v * opacities[idx];
-            dopac = dL_dopacity_v * h_convolution_scaling;
-            d_inside_root = (det_cov / det_cov_plus_h_cov) <= 0.000025f ? 0.f : d_h_convolution_scaling / (2 * h_convolution_scaling);
-        } else {
-            c_xx += h_var;
-            c_yy += h_var;
-        }
-        float dL_dc_xx = 0, dL_dc_xy = 0, dL_dc_yy = 0;
-        if (antialiasing) {
-            const float x = c_xx, y = c_yy, z = c_xy, w = h_var;
-            const float sqv = (w * w + w * (x + y) + x * y - z * z);
-            const float denom_f = d_inside_root / (sqv * sqv);
-            dL_dc_xx = w * (w * y + y * y + z * z) * denom_f;
-            dL_dc_yy = w * (w * x + x * x + z * z) * denom_f;
-            dL_dc_xy = -2.f * w * z * (w + x + y) * denom_f;
-        }
-        const float denom = c_xx * c_yy - c_xy * c_xy;
-        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-        if (denom2inv != 0) {
-            dL_dc_xx += denom2inv * (-c_yy * c_yy * dcx + 2 * c_xy * c_yy * dcy + (denom - c_xx * c_yy) * dcz);
-            dL_dc_yy += denom2inv * (-c_xx * c_xx * dcz + 2 * c_xx * c_xy * dcy + (denom - c_xx * c_yy) * dcx);
-            dL_dc_xy += denom2inv * 2 * (c_xy * c_yy * dcx - (denom + 2 * c_xy * c_xy) * dcy + c_xx * c_xy * dcz);
-            dcov[0] = (T_[0][0] * T_[0][0] * dL_dc_xx + T_[0][0] * T_[1][0] * dL_dc_xy + T_[1][0] * T_[1][0] * dL_dc_yy);
-            dcov[3] = (T_[0][1] * T_[0][1] * dL_dc_xx + T_[0][1] * T_[1][1] * dL_dc_xy + T_[1][1] * T_[1][1] * dL_dc_yy);
-            dcov[5] = (T_[0][2] * T_[0][2] * dL_dc_xx + T_[0][2] * T_[1][2] * dL_dc_xy + T_[1][2] * T_[1][2] * dL_dc_yy);
-            dcov[1] = 2 * T_[0][0] * T_[0][1] * dL_dc_xx + (T_[0][0] * T_[1][1] + T_[0][1] * T_[1][0]) * dL_dc_xy + 2 * T_[1][0] * T_[1][1] * dL_dc_yy;
-            dcov[2] = 2 * T_[0][0] * T_[0][2] * dL_dc_xx + (T_[0][0] * T_[1][2] + T_[0][2] * T_[1][0]) * dL_dc_xy + 2 * T_[1][0] * T_[1][2] * dL_dc_yy;
-            dcov[4] = 2 * T_[0][2] * T_[0][1] * dL_dc_xx + (T_[0][1] * T_[1][2] + T_[0][2] * T_[1][1]) * dL_dc_xy + 2 * T_[1][1] * T_[1][2] * dL_dc_yy;
-        }
-        const float V[3][3] = {{cov3D[0], cov3D[1], cov3D[2]}, {cov3D[1], cov3D[3], cov3D[4]}, {cov3D[2], cov3D[4], cov3D[5]}};
-        float dT0[3], dT1[3];
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const float u0 = T_[0][0] * V[j][0] + T_[0][1] * V[j][1] + T_[0][2] * V[j][2];
-            const float u1 = T_[1][0] * V[j][0] + T_[1][1] * V[j][1] + T_[1][2] * V[j][2];
-            dT0[j] = 2 * u0 * dL_dc_xx + u1 * dL_dc_xy;
-            dT1[j] = 2 * u1 * dL_dc_yy + u0 * dL_dc_xy;
-        }
-        const float* vm = viewmatrix;
-        const float dL_dJ00 = vm[0] * dT0[0] + vm[4] * dT0[1] + vm[8] * dT0[2];
-        const float dL_dJ02 = vm[2] * dT0[0] + vm[6] * dT0[1] + vm[10] * dT0[2];
-        const float dL_dJ11 = vm[1] * dT1[0] + vm[5] * dT1[1] + vm[9] * dT1[2];
-        const float dL_dJ12 = vm[2] * dT1[0] + vm[6] * dT1[1] + vm[10] * dT1[2];
-        const float tz = 1.f / t.z, tz2 = tz * tz, tz3 = tz2 * tz;
-        const float dL_dtx = x_grad_mul * -focal_x * tz2 * dL_dJ02;
-        const float dL_dty = y_grad_mul * -focal_y * tz2 * dL_dJ12;
-        float dL_dtz = -focal_x * tz2 * dL_dJ00 - focal_y * tz2 * dL_dJ11 + (2 * focal_x * t.x) * tz3 * dL_dJ02 +
-                       (2 * focal_y * t.y) * tz3 * dL_dJ12;
-        if (dL_dinvdepth) dL_dtz -= acc1.w / (t.z * t.z);  // backward.cu:313-314
-        // K9 assigns (backward.cu:324) ...
-        dmean.x = vm[0] * dL_dtx + vm[1] * dL_dty + vm[2] * dL_dtz;
-        dmean.y = vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz;
-        dmean.z = vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz;
-        // ... K10 adds the 2D-mean path (backward.cu:425-439)
-        const float* proj = projmatrix;
-        const float4 m_hom = xform4x4(mean, proj);
-        const float m_w = 1.0f / (m_hom.w + 0.0000001f);
-        const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
-        const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
-        dmean.x += (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
-        dmean.y += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
-        dmean.z += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
-        if (shs) {
-            const float3 dm = sh_to_color_bwd(idx, D, M, mean, make_float3(cam_pos[0], cam_pos[1], cam_pos[2]), shs,
-                                              clamped, acc1.z, dL_dsh);
-            dmean.x += dm.x; dmean.y += dm.y; dmean.z += dm.z;
-        }
-        if (scales) {
-            // computeCov3D backward, backward.cu:329-392 (raw quaternion gradient, no normalisation Jacobian)
-            const float r = q.x, x = q.y, y = q.z, z = q.w;
-            float Rq[3][3];
-            quat_rows(q, Rq);
-            const float s[3] = {scale_modifier * sc.x, scale_modifier * sc.y, scale_modifier * sc.z};
-            float Mm[3][3];
-#pragma unroll
-            for (int k = 0; k < 3; k++)
-#pragma unroll
-                for (int a = 0; a < 3; a++) Mm[k][a] = s[k] * Rq[a][k];
-            const float dS[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
-                                    {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
-                                    {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
-            float dM[3][3];
-#pragma unroll
-            for (int a = 0; a < 3; a++)
-#pragma unroll
-                for (int b = 0; b < 3; b++) dM[a][b] = 2.0f * (Mm[a][0] * dS[0][b] + Mm[a][1] * dS[1][b] + Mm[a][2] * dS[2][b]);
-            dscale.x = Rq[0][0] * dM[0][0] + Rq[1][0] * dM[0][1] + Rq[2][0] * dM[0][2];
-            dscale.y = Rq[0][1] * dM[1][0] + Rq[1][1] * dM[1][1] + Rq[2][1] * dM[1][2];
-            dscale.z = Rq[0][2] * dM[2][0] + Rq[1][2] * dM[2][1] + Rq[2][2] * dM[2][2];
-            float G[3][3];
-#pragma unroll
-            for (int a = 0; a < 3; a++)
-#pragma unroll
-                for (int b = 0; b < 3; b++) G[a][b] = s[a] * dM[a][b];
-            drot.x = 2 * z * (G[0][1] - G[1][0]) + 2 * y * (G[2][0] - G[0][2]) + 2 * x * (G[1][2] - G[2][1]);
-            drot.y = 2 * y * (G[1][0] + G[0][1]) + 2 * z * (G[2][0] + G[0][2]) + 2 * r * (G[1][2] - G[2][1]) - 4 * x * (G[2][2] + G[1][1]);
-            drot.z = 2 * x * (G[1][0] + G[0][1]) + 2 * r * (G[2][0] - G[0][2]) + 2 * z * (G[1][2] + G[2][1]) - 4 * y * (G[2][2] + G[0][0]);
-            drot.w = 2 * r * (G[0][1] - G[1][0]) + 2 * x * (G[2][0] + G[0][2]) + 2 * y * (G[1][2] + G[2][1]) - 4 * z * (G[1][1] + G[0][0]);
-        }
+    }
+    const ViewParams vp{viewmatrix, projmatrix, tan_fovx, tan_fovy, focal_x, focal_y, W, H, 0, 0};
+    SplatGrads o;
+    splat_backward(acc0, acc1, vis, ra, rb, mean, cov3D, sc, q, scales != nullptr, scale_modifier,
+                   (vis && antialiasing) ? opacities[idx] : 0.f, vp, antialiasing, dL_dinvdepth != nullptr, o);
+    const float g2x = o.g2x, g2y = o.g2y, dcx = o.dcx, dcy = o.dcy, dcz = o.dcz, dopac = o.dopac;
+    float3 dmean = o.dmean;
+    const float* dcov = o.dcov;
+    const float3 dscale = o.dscale;
+    const float4 drot = o.drot;
+    dL_dmean2D[3 * idx] = g2x; dL_dmean2D[3 * idx + 1] = g2y; dL_dmean2D[3 * idx + 2] = 0.f;
+    if (dL_dconic) reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(dcx, dcy, 0.f, dcz);
+    if (dL_dcolor) dL_dcolor[idx] = acc1.z;
+    if (dL_dinvdepth) dL_dinvdepth[idx] = acc1.w;
+    if (dL_dall_map) reinterpret_cast<float4*>(dL_dall_map)[idx] = acc2;
+    if (vis && shs) {
+        const float3 dm = sh_to_color_bwd(idx, D, M, mean, make_float3(cam_pos[0], cam_pos[1], cam_pos[2]), shs, clamped,
+                                          acc1.z, dL_dsh);
+        dmean.x += dm.x; dmean.y += dm.y; dmean.z += dm.z;
     }
     dL_dopacity[idx] = dopac;
     dL_dmean3D[3 * idx] = dmean.x; dL_dmean3D[3 * idx + 1] = dmean.y; dL_dmean3D[3 * idx + 2] = dmean.z;
