@@ -559,6 +559,117 @@ int cgs_sample_curves_forward(int B, int m, const float* curve_points, const flo
     return CGS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- fused per-view path
+// One view of the training configuration, curve parameters in, image out (and back): the per-splat chains are fused
+// (view.hip), the rasterizer is the sync-free single-pass bucket pipeline of cgs_rasterize_forward_static.
+int cgs_view_forward(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
+                     float eps, double* norms, const float* opacity_logit, const float* mask_logit, float mask_thr,
+                     const float* colors_precomp, void* geometry_buffer, void* binning_buffer, size_t binning_bytes,
+                     void* image_buffer, uint32_t bucket_capacity, const float* background, int width_px, int height_px,
+                     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                     float* out_color, float* out_invdepth, float* out_all_map, int* radii, float* xyz, float* rotation,
+                     float* scaling, void* stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    const int P = B * m;
+    if (B <= 0 || m <= 0 || m > 32 || width_px <= 0 || height_px <= 0 || !curve_points || !width || !coef || !norms ||
+        !opacity_logit || !geometry_buffer || !binning_buffer || !image_buffer || bucket_capacity == 0 || !background ||
+        !viewmatrix || !projmatrix || !cam_pos || !out_color || !out_invdepth || !out_all_map || !radii ||
+        (xyz && (!rotation || !scaling)) || !aligned16(curve_points) || !aligned16(coef) || !aligned16(rotation)) {
+        set_error("cgs_view_forward: invalid argument (B=%d m=%d W=%d H=%d, NULL / misaligned pointer or zero capacity)", B, m,
+                  width_px, height_px);
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    const int gx = (width_px + TILE - 1) / TILE, gy = (height_px + TILE - 1) / TILE;
+    const int tiles = gx * gy;
+    const uint64_t cap = bucket_capacity;
+    if (cap > bucket_cap_limit() || cap * (uint64_t)tiles >= (1ull << 31) ||
+        binning_bytes < cgs_binning_bytes((int64_t)(cap * tiles))) {
+        set_error("cgs_view_forward: bucket capacity %u needs %zu binning bytes (got %zu; limit %u per tile)", bucket_capacity,
+                  cgs_binning_bytes((int64_t)(cap * tiles)), binning_bytes, bucket_cap_limit());
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    const size_t npix = (size_t)width_px * height_px;
+    const float focal_y = height_px / (2.0f * tan_fovy);
+    const float focal_x = width_px / (2.0f * tan_fovx);
+    char* gchunk = (char*)geometry_buffer;
+    char* bchunk = (char*)binning_buffer;
+    char* ichunk = (char*)image_buffer;
+    GeomState geom = geom_from_chunk(gchunk, (size_t)P);
+    BinState bin = bin_from_chunk(bchunk, (size_t)(cap * tiles));
+    ImageState img = image_from_chunk(ichunk, npix, (size_t)tiles);
+    const size_t clear_bytes = (size_t)((char*)(img.total + TOTAL_WORDS) - (char*)img.tile_count);
+    // all five grid-wide sums (forward norms AND the backward's two) start from zero here: one launch per view
+    if (zero_async(norms, (size_t)sample_norm_words() * sizeof(double), s) != hipSuccess) {
+        set_error("zero_async(norms) failed");
+        return CGS_ERR_HIP;
+    }
+    launch_sample_norms(s, B, m, curve_points, is_bezier, coef, norms);
+    launch_view_forward(s, B, m, curve_points, width, is_bezier, coef, eps, norms, opacity_logit, mask_logit, mask_thr,
+                        colors_precomp, cam_pos, viewmatrix, projmatrix, tan_fovx, tan_fovy, focal_x, focal_y, width_px,
+                        height_px, gx, gy, xyz, rotation, scaling, radii, geom.rec, geom.grad_acc, img.tile_count,
+                        clear_bytes / sizeof(uint32_t));
+    const bool defer_big = hints_load(P, width_px, height_px).big > 0;
+    launch_scatter_bucket(s, P, radii, geom.rec, gx, gy, img.tile_count, bin.keys, (uint32_t)cap, 1, img.total + 3,
+                          defer_big ? img.tile_cursor : nullptr, (uint32_t)tiles);
+    if (render_fwd_can_sort((uint32_t)cap) && fuse_sort()) {
+        launch_render_fwd_sorting(s, true, tiles, img.tile_count, bin.keys, (uint32_t)cap, img.ranges, img.total,
+                                  bin.point_list, width_px, height_px, gx, geom.rec, img.final_T, img.n_contrib, background,
+                                  out_color, out_invdepth, out_all_map);
+    } else {
+        launch_tile_sort_bucket(s, tiles, img.tile_count, img.ranges, img.total, bin.keys, bin.point_list, (uint32_t)cap);
+        launch_render_fwd(s, true, tiles, img.ranges, bin.point_list, width_px, height_px, gx, geom.rec, img.final_T,
+                          img.n_contrib, background, out_color, out_invdepth, out_all_map);
+    }
+    if (!check_launch("view_forward", false, s)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
+
+size_t cgs_view_backward_scratch_floats(int B, int m) { return (size_t)(B > 0 ? B : 0) * (size_t)(m > 0 ? m : 0) * 15; }
+
+int cgs_view_backward(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
+                      float eps, double* norms, const float* opacity_logit, const float* mask_logit, float mask_thr,
+                      void* geometry_buffer, const void* binning_buffer, const void* image_buffer, const float* background,
+                      int width_px, int height_px, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                      float tan_fovx, float tan_fovy, const int* radii, const float* dL_dout_color,
+                      const float* dL_drotation_extra, float* dL_dmeans2D, float* dL_dcurve_points, float* dL_dwidth,
+                      float* dL_dopacity_logit, float* dL_dmask_logit, float* scratch, void* stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    const int P = B * m;
+    if (B <= 0 || m <= 0 || m > 32 || width_px <= 0 || height_px <= 0 || !curve_points || !width || !coef || !norms ||
+        !opacity_logit || !geometry_buffer || !binning_buffer || !image_buffer || !background || !viewmatrix || !projmatrix ||
+        !cam_pos || !radii || !dL_dout_color || !dL_dmeans2D || !dL_dcurve_points || !dL_dwidth || !dL_dopacity_logit ||
+        !scratch || (mask_logit && !dL_dmask_logit) || !aligned16(curve_points) || !aligned16(coef) ||
+        !aligned16(dL_drotation_extra) || !aligned16(dL_dcurve_points)) {
+        set_error("cgs_view_backward: invalid argument");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    const int gx = (width_px + TILE - 1) / TILE, gy = (height_px + TILE - 1) / TILE;
+    const int tiles = gx * gy;
+    const size_t npix = (size_t)width_px * height_px;
+    const float focal_y = height_px / (2.0f * tan_fovy);
+    const float focal_x = width_px / (2.0f * tan_fovx);
+    char* gchunk = (char*)geometry_buffer;
+    char* bchunk = (char*)binning_buffer;
+    char* ichunk = (char*)image_buffer;
+    GeomState geom = geom_from_chunk(gchunk, (size_t)P);
+    BinState bin = bin_from_chunk(bchunk, 1);
+    ImageState img = image_from_chunk(ichunk, npix, (size_t)tiles);
+    float* gv = scratch;                       // [P,9] dL/d{v0,v1,v2}
+    float* g_xyz = scratch + (size_t)P * 9;    // [P,3]
+    float* g_scl = scratch + (size_t)P * 12;   // [P,3]
+    // training configuration: only dL/dcolour flows in, unit colours need no colour gradient
+    launch_render_bwd(s, false, false, false, tiles, img.ranges, bin.point_list, width_px, height_px, gx, background, geom.rec,
+                      img.final_T, img.n_contrib, dL_dout_color, nullptr, nullptr, geom.grad_acc);
+    launch_view_backward(s, B, m, curve_points, width, is_bezier, coef, eps, norms, opacity_logit, mask_logit, mask_thr,
+                         cam_pos, viewmatrix, projmatrix, tan_fovx, tan_fovy, focal_x, focal_y, width_px, height_px, radii,
+                         geom.rec, geom.grad_acc, dL_drotation_extra, dL_dmeans2D, dL_dopacity_logit, dL_dmask_logit, g_xyz,
+                         g_scl, gv);
+    launch_sample_backward_pass3(s, B, m, curve_points, width, is_bezier, coef, eps, norms, g_xyz, gv, g_scl,
+                                 dL_dcurve_points, dL_dwidth, gv);
+    if (!check_launch("view_backward", false, s)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
+
 int cgs_sample_curves_backward(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier,
                                const float* coef, float eps, double* norms, const float* dL_dxyz,
                                const float* dL_drotation, const float* dL_dscaling, float* dL_dcurve_points,

@@ -77,6 +77,7 @@ __device__ __forceinline__ void stage_consts(const SampleCoef* __restrict__ coef
     }
     __syncthreads();
 }
+constexpr int SAMPLE_BLOCK = 256;   // threads per block of the kernels whose blocks hold whole curves
 constexpr int MAX_M = 32;  // samples per curve supported by the LDS table (reference default 12)
 
 // block-wide sums of N quantities -> one f64 atomic each on this block's slot of quantities q0, q0+1, ...

@@ -70,7 +70,6 @@ __global__ void __launch_bounds__(256) k_sample_f3(int B, int m, const float* __
 // PASS 1: the two global sums D2 and A (one pass, see NORM layout);  PASS 3: write dL/dcurve_points, dL/dwidth.
 // Blocks hold CURVES_PER_BLOCK whole curves (CURVES_PER_BLOCK * m threads are active); pass 3 reduces the per-sample
 // contributions to the 13 per-curve outputs through LDS.
-constexpr int SAMPLE_BLOCK = 256;
 template <int PASS>
 __global__ void __launch_bounds__(SAMPLE_BLOCK) k_sample_bwd(int B, int m, int curves_per_block,
                                                              const float* __restrict__ cp,
@@ -323,6 +322,20 @@ void launch_attrs_backward(hipStream_t s, int B, int m, const float* rot_raw, co
     hipLaunchKernelGGL(k_attrs_bwd, dim3((B + cpb - 1) / cpb), dim3(SAMPLE_BLOCK), 0, s, B, m, cpb, rot_raw, xyz, opacity_logit, mask_logit,
                        mask_thr, scaling, campos, vm, g_rot_n, g_opac, g_scl_out, g_all_map, g_rot_raw, g_opacity_logit,
                        g_mask_logit, g_scaling);
+}
+
+void launch_sample_norms(hipStream_t s, int B, int m, const float* cp, const uint8_t* is_bezier, const void* coef, double* norms) {
+    ProfScope p("sample_f12", s);
+    hipLaunchKernelGGL(k_sample_f12, dim3(std::max((B * m + 255) / 256, 1)), dim3(256), 0, s, B, m, cp, is_bezier,
+                       reinterpret_cast<const SampleCoef*>(coef), norms);
+}
+void launch_sample_backward_pass3(hipStream_t s, int B, int m, const float* cp, const float* width, const uint8_t* is_bezier,
+                                  const void* coef, float eps, double* norms, const float* g_xyz, const float* g_rot,
+                                  const float* g_scaling, float* g_cp, float* g_width, float* gv_cache) {
+    const int cpb = SAMPLE_BLOCK / m;
+    ProfScope p("sample_b3", s);
+    hipLaunchKernelGGL(k_sample_bwd<3>, dim3((B + cpb - 1) / cpb), dim3(SAMPLE_BLOCK), 0, s, B, m, cpb, cp, width, is_bezier,
+                       reinterpret_cast<const SampleCoef*>(coef), eps, norms, g_xyz, g_rot, g_scaling, g_cp, g_width, gv_cache);
 }
 
 int sample_norm_words() { return NORM_WORDS; }

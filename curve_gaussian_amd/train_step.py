@@ -148,9 +148,12 @@ class GraphedTrainStep(TrainStep):
     ``step()`` returns the graph's static loss tensor: it is overwritten by the next step (copy or ``float()`` it
     to keep a value).  Call ``finish()`` before reading the model from outside or editing its topology."""
 
-    def __init__(self, *args, cap_margin=1.5, direct=True, collectives=None, **kw):
+    def __init__(self, *args, cap_margin=1.5, direct=True, collectives=None, fused_view=True, **kw):
         kw["fused"] = True
         super().__init__(*args, **kw)
+        # direct body only: cgs_view_forward / cgs_view_backward (the per-splat chains fused, csrc/view.hip) instead of the
+        # sampling -> attributes -> rasterizer calls one by one; same results, five launches fewer per iteration
+        self.fused_view = bool(fused_view)
         # View-parallel runs (world > 1; `collectives=True` forces the same code path on a single-rank group): the graph
         # ends before the optimizer; the host then all-reduces the flat gradient buffer and the overflow flag (max) and
         # launches the Adam kernel.  Overflow handling is made deterministic across ranks by looking at the flag of
@@ -264,6 +267,7 @@ class GraphedTrainStep(TrainStep):
         b["g_m2d"], b["g_conic"], b["g_opac"] = f(P, 3), f(P, 2, 2), f(P, 1)
         b["g_m3d"], b["g_cov"], b["g_scl"], b["g_rotn"], b["g_amap"] = f(P, 3), f(P, 6), f(P, 3), f(P, 4), f(P, 4)
         b["g_rot_raw"], b["g_scaling"], b["gv"] = f(P, 4), f(P, 3), f(P, 9)
+        b["view_scratch"] = f(int(lib.cgs_view_backward_scratch_floats(B, m)))
         b["reg_ws"] = torch.zeros(int(lib.cgs_curve_regularizers_workspace_bytes()), dtype=torch.uint8, device=dev)
         b["reg_loss"] = torch.zeros((), dtype=torch.float32, device=dev)
         b["r_rot"], b["r_op"], b["r_w"] = f(P, 4), f(B, 1), f(B, 1)
@@ -289,6 +293,8 @@ class GraphedTrainStep(TrainStep):
         cam = self._cam
         tanx, tany = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
         chk = L.check
+        if self.fused_view:
+            return self._body_direct_fused(lib, b, cam, cp, wl, ol, mask, grads, tanx, tany, s)
         # ---- forward: curves -> splats -> per-view attributes -> rasterizer (sync-free) -> loss
         chk(lib.cgs_sample_curves_forward(B, m, p(cp), p(wl), p(b["isb"]), p(b["coef"]), cf(1e-8), p(b["norms"]),
                                           p(b["xyz"]), p(b["rot"]), p(b["scl"]), s), "sample_curves_forward")
@@ -345,6 +351,56 @@ class GraphedTrainStep(TrainStep):
             grads.view("mask").add_(sg * (1 - sg), alpha=self.lambda_mask / mask.numel())
         status = b["status"]
         if not self._collective:     # view-parallel: the all-reduce sits between the backward and the optimizer
+            g.optimizer.step_dev(zero_grad=True, skip_flag=status[2:3])
+        self.last = dict(radii=b["radii"], dL_dmeans2D=b["g_m2d"], render=b["color"], depth=b["invd"], all_map=b["omap"])
+        return loss, status
+
+    def _body_direct_fused(self, lib, b, cam, cp, wl, ol, mask, grads, tanx, tany, s):
+        """The direct body on the fused per-view entry points: 8 launches for render + its backward instead of 13."""
+        import ctypes as C
+        from . import _lib as L
+        g = self.g
+        B, P, m, H, W = b["B"], b["P"], b["m"], b["H"], b["W"]
+        p, cf, chk = L.ptr, C.c_float, L.check
+        chk(lib.cgs_view_forward(
+            B, m, p(cp), p(wl), p(b["isb"]), p(b["coef"]), cf(1e-8), p(b["norms"]), p(ol), p(mask), cf(self.mask_threshold),
+            None, p(b["geom"]), p(b["bin"]), b["nbin"], p(b["img"]), self._cap, p(b["bg"]), W, H,
+            p(cam.world_view_transform), p(cam.full_proj_transform), p(cam.camera_center), tanx, tany, p(b["color"]),
+            p(b["invd"]), p(b["omap"]), p(b["radii"]), p(b["xyz"]), p(b["rot"]), p(b["scl"]), s), "view_forward")
+        a = self.lambda_mse * (1.0 - self.lambda_dssim)
+        bb = self.lambda_mse * self.lambda_dssim
+        chk(lib.cgs_photometric_loss_indexed(H, W, p(b["color"]), p(self._gt_stack), p(self._view_idx), cf(0.1),
+                                             p(self._npos_table), cf(a), cf(bb), 1, p(b["photo_ws"]), p(b["g_img"]),
+                                             p(b["loss"]), s), "photometric_loss_indexed")
+        loss = b["loss"]
+        extra = None
+        if self.regularisers:   # needs only forward quantities: runs before the backward and hands it dL/drotation_raw
+            chk(lib.cgs_curve_regularizers(B, m, p(b["rot"]), p(ol), p(wl), p(b["radii"]), cf(self.opacity_loss_weight),
+                                           p(self._opa_gate), cf(self.lambda_curve_smo), cf(self.lambda_width), cf(0.005),
+                                           p(b["reg_ws"]), p(b["reg_loss"]), p(b["r_rot"]), p(b["r_op"]), p(b["r_w"]), s),
+                "curve_regularizers")
+            extra = b["r_rot"]
+            loss = loss + b["reg_loss"]
+        chk(lib.cgs_view_backward(
+            B, m, p(cp), p(wl), p(b["isb"]), p(b["coef"]), cf(1e-8), p(b["norms"]), p(ol), p(mask), cf(self.mask_threshold),
+            p(b["geom"]), p(b["bin"]), p(b["img"]), p(b["bg"]), W, H, p(cam.world_view_transform),
+            p(cam.full_proj_transform), p(cam.camera_center), tanx, tany, p(b["radii"]), p(b["g_img"]), p(extra),
+            p(b["g_m2d"]), p(grads.view("curve_points")), p(grads.view("width")), p(grads.view("opacity")),
+            p(grads.view("mask")) if mask is not None else None, p(b["view_scratch"]), s), "view_backward")
+        if self.regularisers:
+            grads.view("opacity").add_(b["r_op"])
+            grads.view("width").add_(b["r_w"])
+            if self._use_conn:
+                chk(lib.cgs_endpoint_connection_loss(B, p(cp), cf(0.05), cf(self.lambda_points_conn), p(b["conn_ws"]),
+                                                     p(b["conn_loss"]), p(grads.view("curve_points")), 1, s),
+                    "endpoint_connection_loss")
+                loss = loss + b["conn_loss"]
+        if self._use_mask:      # train.py:110-111: lambda_mask * mean(sigmoid(mask)), gradient added by hand
+            sg = torch.sigmoid(mask)
+            loss = loss + self.lambda_mask * sg.mean()
+            grads.view("mask").add_(sg * (1 - sg), alpha=self.lambda_mask / mask.numel())
+        status = b["status"]
+        if not self._collective:
             g.optimizer.step_dev(zero_grad=True, skip_flag=status[2:3])
         self.last = dict(radii=b["radii"], dL_dmeans2D=b["g_m2d"], render=b["color"], depth=b["invd"], all_map=b["omap"])
         return loss, status

@@ -127,6 +127,39 @@ size_t cgs_image_bytes(int width, int height);
 size_t cgs_binning_bytes(int64_t R);
 
 /* ------------------------------------------------------------------------------------------------
+ * Fused per-view path of the training configuration (no counterpart in the reference, which runs ~45 PyTorch kernels and
+ * three extension calls for the same work): curve parameters in, image out, and back to curve-parameter gradients.
+ * Equivalent to  cgs_sample_curves_forward -> cgs_splat_attrs_forward -> cgs_rasterize_forward_static  (and their
+ * backwards in reverse) with scales + rotations, precomputed colours (NULL = all ones), scale_modifier 1, no
+ * antialiasing, render_geo on -- i.e. gaussian_renderer/__init__.py:18-157 as train.py calls it -- but the per-splat
+ * tensors between those calls (xyz, rotation, scaling, opacity, all_map and their gradients) never leave registers:
+ * 8 kernel launches per view and direction pair instead of 13.
+ *   cgs_view_forward: arguments as the three calls it replaces; xyz / rotation / scaling may be NULL (all three) when the
+ *     caller does not need the model's derived splat tensors.  Status words as cgs_rasterize_forward_static.
+ *   cgs_view_backward: valid ONCE per cgs_view_forward (it consumes scratch sums the forward zeroed).  Only dL/dcolour
+ *     flows in (train.py's loss reads `render` only); dL_drotation_extra [P,4] or NULL is added to the gradient of the
+ *     raw splat rotations before it is pulled back to the curves (the curve-smoothness regulariser enters there).
+ *     Outputs: dL_dmeans2D [P,3] (NDC-scaled, feeds add_densification_stats), dL_dcurve_points [B,4,3], dL_dwidth [B,1],
+ *     dL_dopacity_logit [B,1], dL_dmask_logit [P] (required iff mask_logit).  scratch:
+ *     cgs_view_backward_scratch_floats(B, m) floats.
+ * ------------------------------------------------------------------------------------------------ */
+int cgs_view_forward(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
+                     float eps, double* norms, const float* opacity_logit, const float* mask_logit, float mask_thr,
+                     const float* colors_precomp, void* geometry_buffer, void* binning_buffer, size_t binning_bytes,
+                     void* image_buffer, uint32_t bucket_capacity, const float* background, int width_px, int height_px,
+                     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                     float* out_color, float* out_invdepth, float* out_all_map, int* radii, float* xyz, float* rotation,
+                     float* scaling, void* stream);
+size_t cgs_view_backward_scratch_floats(int B, int m);
+int cgs_view_backward(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
+                      float eps, double* norms, const float* opacity_logit, const float* mask_logit, float mask_thr,
+                      void* geometry_buffer, const void* binning_buffer, const void* image_buffer, const float* background,
+                      int width_px, int height_px, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                      float tan_fovx, float tan_fovy, const int* radii, const float* dL_dout_color,
+                      const float* dL_drotation_extra, float* dL_dmeans2D, float* dL_dcurve_points, float* dL_dwidth,
+                      float* dL_dopacity_logit, float* dL_dmask_logit, float* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Curve -> Gaussian sampling.  Replaces GaussianCurveModel.prepare_scaling_rot
  * (/root/reference/scene/gaussian_curve_model.py:180-198 with get_curve_gaussians :70-78, get_curve_tangent :80-89 and
  * rot_to_quat_batch, utils/general_utils.py:33-86) and its autograd backward.

@@ -79,7 +79,7 @@ def test_edge_aware_loss_matches_reference_golden():
     val = edge_aware_loss(img, torch.tensor(d["gt"], device=DEV))
     (3.0 * val).backward()
     np.testing.assert_allclose(float(val), d["value"], rtol=1e-5)
-    np.testing.assert_allclose(img.grad.cpu().numpy(), 3.0 * d["grad"], rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(img.grad.cpu().numpy(), 3.0 * d["grad"], rtol=1e-4, atol=2e-6)
     # multi-channel + degenerate gt (no edges at all)
     g = torch.Generator().manual_seed(2)
     im3, gt3 = torch.rand(3, 33, 47, generator=g), torch.zeros(3, 33, 47)
@@ -90,7 +90,7 @@ def test_edge_aware_loss_matches_reference_golden():
     v = edge_aware_loss(x, gt3.to(DEV))
     v.backward()
     np.testing.assert_allclose(float(v), float(ref), rtol=1e-5)
-    np.testing.assert_allclose(x.grad.cpu().numpy(), ref_in.grad.numpy(), rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), ref_in.grad.numpy(), rtol=1e-4, atol=2e-6)
 
 
 def test_train_step_reduces_loss_and_keeps_layout():
@@ -255,7 +255,7 @@ def test_photometric_loss_equals_composition(clamp):
         val = photometric_loss(b, gt_d, 10.0, 0.1, clamp=clamp)
         (2.0 * val).backward()
         np.testing.assert_allclose(float(val), float(ref), rtol=1e-5)
-        np.testing.assert_allclose(b.grad.cpu().numpy(), 2.0 * a.grad.cpu().numpy(), rtol=1e-4, atol=1e-9)
+        np.testing.assert_allclose(b.grad.cpu().numpy(), 2.0 * a.grad.cpu().numpy(), rtol=1e-4, atol=2e-6)
     if clamp:
         outside = ((img < 0) | (img > 1)).numpy()
         assert outside.any() and (b.grad.cpu().numpy()[outside] == 0).all()
@@ -432,6 +432,33 @@ def test_graphed_train_step_autograd_body_matches_direct_body(regs):
         np.testing.assert_allclose(getattr(gb, n).detach().cpu().numpy(), getattr(ga, n).detach().cpu().numpy(),
                                    rtol=1e-3, atol=1e-5, err_msg=n)
     assert sb.last["radii"].shape[0] == gb._curve_points.shape[0] * 12 and torch.isfinite(sb.last["dL_dmeans2D"]).all()
+
+
+@pytest.mark.parametrize("regs", [False, True])
+def test_fused_view_entry_points_match_the_separate_calls(regs):
+    """cgs_view_forward / cgs_view_backward (per-splat chains fused, csrc/view.hip) against the same iteration built from
+    cgs_sample_curves_* / cgs_splat_attrs_* / cgs_rasterize_*: identical trajectories, through the mask phase
+    (densify_until_iter = 5) and with straight segments in the model."""
+    from curve_gaussian_amd.train_step import GraphedTrainStep
+    torch.manual_seed(0); ga, cams, gts = _train_fixture()
+    torch.manual_seed(0); gb, _, _ = _train_fixture()
+    assert not bool(ga.is_bezier.all())
+    sa = GraphedTrainStep(ga, cams, gts, seed=8, fused_view=False, regularisers=regs, densify_until_iter=5)
+    sb = GraphedTrainStep(gb, cams, gts, seed=8, fused_view=True, regularisers=regs, densify_until_iter=5)
+    for it in range(9):
+        la, lb = sa.step()[0], sb.step()[0]
+        if it in (0, 3, 8):
+            np.testing.assert_allclose(float(lb), float(la), rtol=2e-5)
+            np.testing.assert_allclose(sb.last["dL_dmeans2D"].cpu().numpy(), sa.last["dL_dmeans2D"].cpu().numpy(), rtol=1e-4, atol=2e-6)
+            assert torch.equal(sb.last["radii"], sa.last["radii"])
+            # first iteration: same parameters, same image; later the two Adam trajectories differ in the last bits
+            # (atomics order, divide / sqrt rounding of the two builds) and a few alpha < 1/255 tests flip
+            assert_close("render", sb.last["render"].cpu().numpy(), sa.last["render"].cpu().numpy(), rel=2e-5 if it == 0 else 1e-4,
+                         outlier_frac=0.0 if it == 0 else 5e-3)
+    sa.finish(); sb.finish()
+    for n in ("_curve_points", "_width", "_opacity", "_mask"):
+        np.testing.assert_allclose(getattr(gb, n).detach().cpu().numpy(), getattr(ga, n).detach().cpu().numpy(),
+                                   rtol=2e-4, atol=2e-6, err_msg=n)
 
 
 def test_graphed_train_step_crosses_the_mask_phase():
