@@ -102,6 +102,9 @@ def main():
                     help="N > 1 only: also time the view-parallel training iteration (GraphedTrainStep in collective mode: "
                          "every rank renders one view, ONE all-reduce of the flat gradients, identical Adam step on all "
                          "ranks).  Off by default: the scaling run measures the raster throughput only")
+    ap.add_argument("--autograd-view", action="store_true",
+                    help="view mode graphs: capture the drop-in Python API (sample_curves / splat_attributes / "
+                         "rasterize_gaussians autograd Functions) instead of the autograd-free fused entry points")
     ap.add_argument("--no-pingpong", action="store_true",
                     help="view mode: one set of per-stream gradient buffers (the streams drain at every step boundary) "
                          "instead of two used by alternate steps")
@@ -216,6 +219,41 @@ def main():
         if collect:
             stats["visible"] += int((radii > 0).sum())
 
+    # ---- autograd-free per-view body on the fused entry points (cgs_view_forward / cgs_view_backward): what the hipGraph
+    # of a stream replays -- 8 library kernels per view, no torch kernels; the curve-parameter gradients are ADDED into the
+    # stream's flat buffer by the backward itself (accumulate = 1), bucket overflows are counted in a sticky status word
+    import ctypes as C
+
+    def make_direct_view(flat, cap):
+        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        u8 = lambda n: torch.zeros(int(n), dtype=torch.uint8, device=dev)
+        f32 = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+        d = dict(coef=curve_sampling.sample_coefficients(m, dev), norms=torch.empty(384, dtype=torch.float64, device=dev),
+                 geom=u8(lib.cgs_geometry_bytes(P)), nbin=int(lib.cgs_binning_bytes(cap * tiles)), img=u8(lib.cgs_image_bytes(W, H)),
+                 color=f32(1, H, W), invd=f32(1, H, W), omap=f32(4, H, W), radii=torch.empty(P, dtype=torch.int32, device=dev),
+                 g_m2d=f32(P, 3), scratch=f32(int(lib.cgs_view_backward_scratch_floats(B, m))))
+        d["bin"] = u8(d["nbin"])
+        off = int(lib.cgs_image_status_offset(W, H)) + 4 * int(lib.cgs_status_words())
+        d["sticky"] = d["img"][off:off + 4].view(torch.int32)
+        g_cp, g_w, g_op = flat[0:12 * B], flat[12 * B:13 * B], flat[13 * B:14 * B]
+        cp0, w0, op0 = base
+        isb_u8 = curve_sampling._bezier_mask(isb, dev)
+        pt, cf = L.ptr, C.c_float
+
+        def body(cam):
+            st = L.raw_stream(dev)
+            L.check(lib.cgs_view_forward(B, m, pt(cp0), pt(w0), pt(isb_u8), pt(d["coef"]), cf(1e-8), pt(d["norms"]), pt(op0), None,
+                                         cf(0.01), None, pt(d["geom"]), pt(d["bin"]), d["nbin"], pt(d["img"]), cap, pt(bg), W, H,
+                                         pt(cam.world_view_transform), pt(cam.full_proj_transform), pt(cam.camera_center),
+                                         tanx, tany, pt(d["color"]), pt(d["invd"]), pt(d["omap"]), pt(d["radii"]), None, None,
+                                         None, st), "cgs_view_forward")
+            L.check(lib.cgs_view_backward(B, m, pt(cp0), pt(w0), pt(isb_u8), pt(d["coef"]), cf(1e-8), pt(d["norms"]), pt(op0), None,
+                                          cf(0.01), pt(d["geom"]), pt(d["bin"]), pt(d["img"]), pt(bg), W, H,
+                                          pt(cam.world_view_transform), pt(cam.full_proj_transform), pt(cam.camera_center),
+                                          tanx, tany, pt(d["radii"]), pt(dL_dcolor), None, pt(d["g_m2d"]), pt(g_cp), pt(g_w),
+                                          pt(g_op), None, pt(d["scratch"]), 1, st), "cgs_view_backward")
+        return body, d
+
     # One optimizer step's view batch per rank: `views_per_step` independent views, up to `streams` of them in flight,
     # gradients summed in flat_grads, then ONE all-reduce over the ranks.  (--streams 1 --views-per-step 1 is the
     # reference's one-view-per-iteration schedule.)
@@ -237,6 +275,7 @@ def main():
     # ---- hipGraph mode: one captured per-view pipeline per stream (sync-free forward with fixed-capacity buckets),
     # replayed for any view after a 140-byte camera copy; the host cost per view drops from ~0.4 ms to ~0.02 ms
     view_graphs = None
+    direct_bufs = []
     overflow_acc = torch.zeros(1, dtype=torch.int32, device=dev)
     if args.mode == "view" and not args.no_graph:
         import ctypes
@@ -259,12 +298,19 @@ def main():
                 for si in range(vstreams.n):
                     scam = StaticCamera(my_cams[0], dev)
                     scam.load(packs[id(my_cams[0])])
-                    sink = []
+                    if args.autograd_view:      # the drop-in Python API inside the graph (3 autograd Functions per view)
+                        sink = []
 
-                    def body(scam=scam, leaves=leaf_sets[q][si], sink=sink):
-                        del sink[:]
-                        step_view(scam, leaves, False, cap, sink)
-                        overflow_acc.add_(sink[0][2:3])   # sticky bucket-overflow flag, checked after the timed region
+                        def body(scam=scam, leaves=leaf_sets[q][si], sink=sink):
+                            del sink[:]
+                            step_view(scam, leaves, False, cap, sink)
+                            overflow_acc.add_(sink[0][2:3])   # sticky bucket-overflow flag, checked after the timed region
+                    else:
+                        direct, dbufs = make_direct_view(flat_sets[q][si], cap)
+                        direct_bufs.append(dbufs)
+
+                        def body(scam=scam, direct=direct):
+                            direct(scam)
 
                     st = vstreams.streams[si] if vstreams.streams else torch.cuda.Stream()
                     graph, _ = capture_graph(body, st)
@@ -273,6 +319,8 @@ def main():
                 for f in flats:
                     f.zero_()
             overflow_acc.zero_()
+            for dbufs in direct_bufs:
+                dbufs["sticky"].zero_()
             torch.cuda.synchronize()
         except Exception as e:   # capture is an optimisation: fall back to eager launches
             print(f"bench: hipGraph capture unavailable ({e}); using eager launches", file=sys.stderr)
@@ -312,6 +360,9 @@ def main():
             for j, cam in enumerate(view_list[g0:g0 + G]):
                 if use_graphs[0] and not collect:
                     replay_view(j, cam, q)
+                elif collect and prof_direct[0] is not None:   # per-kernel timing of the headline (fused direct) body
+                    prof_direct[0](cam)
+                    stats["visible"] += int((prof_direct[1]["radii"] > 0).sum())
                 else:
                     vstreams.run(j, step_view, cam, leaves[j % vstreams.n], collect)
             vstreams.join()     # (events only: the main stream waits, the view streams run on into the next step)
@@ -327,6 +378,10 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    prof_direct = [None, None]
+    if view_graphs is not None and not args.autograd_view:
+        prof_direct = list(make_direct_view(torch.zeros_like(flat_grads), cap))
 
     use_graphs = [view_graphs is not None]
     if world > 1 or os.environ.get("CGS_BENCH_FORCE_DIST"):   # (the env switch exercises RCCL with a single rank)
@@ -370,6 +425,8 @@ def main():
         return timed() if reps[0] > 1 else pilot
 
     elapsed = timed_long()
+    for dbufs in direct_bufs:   # sticky overflow counters of the direct bodies
+        overflow_acc.add_(dbufs["sticky"])
     if dist is not None:   # every rank takes the same decision (the re-timing below contains collectives)
         dist.all_reduce(overflow_acc, op=dist.ReduceOp.MAX)
     if int(overflow_acc.item()) != 0:   # a tile list outgrew its bucket on some rank: graph results invalid
@@ -500,7 +557,7 @@ def main():
                    "instances_per_view_R": round(R_mean, 1), "visible_per_view": round(vis_mean, 1),
                    "step": f"{G} view(s) per rank, gradients summed" + (", one RCCL all-reduce" if world > 1 else ""),
                    "views_per_rank": views_timed, "views_per_step_per_rank": G, "views_in_flight_per_gpu": vstreams.n,
-                   "launch": "hipGraph replay per view" if use_graphs[0] else "eager",
+                   "launch": ("hipGraph replay per view (" + ("autograd body" if args.autograd_view else "fused direct body: cgs_view_forward / cgs_view_backward") + ")") if use_graphs[0] else "eager",
                    "step_boundary": "double-buffered gradient sets (reduction/all-reduce of step s overlaps the views of "
                                     "step s+1)" if n_sets > 1 else "join per step",
                    "parallelism": f"view-parallel x{world}"},

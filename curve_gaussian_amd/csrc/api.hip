@@ -632,7 +632,7 @@ int cgs_view_backward(int B, int m, const float* curve_points, const float* widt
                       int width_px, int height_px, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                       float tan_fovx, float tan_fovy, const int* radii, const float* dL_dout_color,
                       const float* dL_drotation_extra, float* dL_dmeans2D, float* dL_dcurve_points, float* dL_dwidth,
-                      float* dL_dopacity_logit, float* dL_dmask_logit, float* scratch, void* stream_) {
+                      float* dL_dopacity_logit, float* dL_dmask_logit, float* scratch, int accumulate, void* stream_) {
     hipStream_t s = (hipStream_t)stream_;
     const int P = B * m;
     if (B <= 0 || m <= 0 || m > 32 || width_px <= 0 || height_px <= 0 || !curve_points || !width || !coef || !norms ||
@@ -663,9 +663,9 @@ int cgs_view_backward(int B, int m, const float* curve_points, const float* widt
     launch_view_backward(s, B, m, curve_points, width, is_bezier, coef, eps, norms, opacity_logit, mask_logit, mask_thr,
                          cam_pos, viewmatrix, projmatrix, tan_fovx, tan_fovy, focal_x, focal_y, width_px, height_px, radii,
                          geom.rec, geom.grad_acc, dL_drotation_extra, dL_dmeans2D, dL_dopacity_logit, dL_dmask_logit, g_xyz,
-                         g_scl, gv);
+                         g_scl, gv, accumulate);
     launch_sample_backward_pass3(s, B, m, curve_points, width, is_bezier, coef, eps, norms, g_xyz, gv, g_scl,
-                                 dL_dcurve_points, dL_dwidth, gv);
+                                 dL_dcurve_points, dL_dwidth, gv, accumulate);
     if (!check_launch("view_backward", false, s)) return CGS_ERR_HIP;
     return CGS_OK;
 }

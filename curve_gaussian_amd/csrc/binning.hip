@@ -177,7 +177,10 @@ __device__ __forceinline__ uint2 bucket_range(const uint32_t* __restrict__ tile_
             uint32_t* part = total + 4 + 2 * (blockIdx.x % TOTAL_PARTS);
             atomicAdd(&part[0], n);
             atomicMax(&part[1], cnt);  // > cap  <=>  this bucket overflowed
-            if (cnt > cap) total[2] = 1u;  // device-visible overflow flag (read by sync-free consumers)
+            if (cnt > cap) {               // device-visible overflow flag (read by sync-free consumers)
+                total[2] = 1u;
+                atomicAdd(&total[TOTAL_WORDS], 1u);   // sticky: survives the next forward's clear (caller resets it)
+            }
         }
     }
     return make_uint2(base, base + n);

@@ -70,7 +70,7 @@ static inline ImageState image_from_chunk(char*& chunk, size_t npix, size_t tile
     carve(chunk, s.ranges, tiles);
     carve(chunk, s.tile_count, tiles);
     carve(chunk, s.tile_cursor, tiles);
-    carve(chunk, s.total, TOTAL_WORDS);
+    carve(chunk, s.total, TOTAL_WORDS + 32);   // + 32 words the library never clears: [TOTAL_WORDS] = sticky overflow count
     return s;
 }
 static inline BinState bin_from_chunk(char*& chunk, size_t R) {
@@ -81,12 +81,18 @@ static inline BinState bin_from_chunk(char*& chunk, size_t R) {
 }
 
 // ---------------------------------------------------------------- device math shared by fwd and bwd
+// Contraction is OFF in the projection / covariance chain: a*b+c fused or not changes the last bits, the 2D covariance
+// inverse amplifies them (~40 ulp in the conic), and the same splat would get different alpha-threshold decisions in the
+// general and in the fused kernels (different inlining contexts contract differently).  Separate roundings are also
+// what the C oracle (-ffp-contract=off) and the reference's host-side expectations are written against.
 #ifdef __HIPCC__
 __device__ __forceinline__ float3 xform4x3(const float3 p, const float* __restrict__ m) {
+#pragma clang fp contract(off)
     return make_float3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
                        m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]);
 }
 __device__ __forceinline__ float4 xform4x4(const float3 p, const float* __restrict__ m) {
+#pragma clang fp contract(off)
     return make_float4(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
                        m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14], m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15]);
 }
@@ -104,6 +110,7 @@ __device__ __forceinline__ void get_rect(float px, float py, int max_radius, int
 // Rotation of the UN-normalised quaternion q = (r,x,y,z), rows R[0..2] (reference forward.cu:127-138: its glm
 // matrix is the transpose of this one).
 __device__ __forceinline__ void quat_rows(const float4 q, float R[3][3]) {
+#pragma clang fp contract(off)
     const float r = q.x, x = q.y, y = q.z, z = q.w;
     R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
     R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
@@ -111,6 +118,7 @@ __device__ __forceinline__ void quat_rows(const float4 q, float R[3][3]) {
 }
 // Sigma = Rq diag(s^2) Rq^T, packed upper triangle (reference forward.cu:118-152)
 __device__ __forceinline__ void cov3d_from_scale_rot(const float3 scale, float mod, const float4 q, float cov[6]) {
+#pragma clang fp contract(off)
     float R[3][3];
     quat_rows(q, R);
     const float s[3] = {mod * scale.x, mod * scale.y, mod * scale.z};
@@ -127,6 +135,7 @@ __device__ __forceinline__ void cov3d_from_scale_rot(const float3 scale, float m
 __device__ __forceinline__ void cov2d_terms(const float3 mean, float fx, float fy, float tan_fovx, float tan_fovy,
                                             const float cov3D[6], const float* __restrict__ vm, float3& t,
                                             float Mt[2][3], float3& cov, float& txtz, float& tytz) {
+#pragma clang fp contract(off)
     t = xform4x3(mean, vm);
     const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
     txtz = t.x / t.z;

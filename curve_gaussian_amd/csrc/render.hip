@@ -178,7 +178,10 @@ __global__ void __launch_bounds__(256) k_render_fwd(const uint2* __restrict__ ra
                 uint32_t* part = bs.total + 4 + 2 * (g.tile % TOTAL_PARTS);
                 atomicAdd(&part[0], n);
                 atomicMax(&part[1], cnt);
-                if (cnt > bs.cap) bs.total[2] = 1u;
+                if (cnt > bs.cap) {
+                    bs.total[2] = 1u;
+                    atomicAdd(&bs.total[TOTAL_WORDS], 1u);   // sticky: survives the next forward's clear
+                }
             }
         }
         if (n > 0) {   // block-uniform

@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_sample_bwd(int B, int m, int c
                                                              const float* __restrict__ g_rot,
                                                              const float* __restrict__ g_scaling,
                                                              float* __restrict__ g_cp, float* __restrict__ g_width,
-                                                             float* __restrict__ gv_cache) {
+                                                             float* __restrict__ gv_cache, int accumulate = 0) {
     __shared__ float s_part[PASS == 3 ? 13 : 1][SAMPLE_BLOCK + 1];
     __shared__ SampleCoef s_coef[MAX_M];
     __shared__ BlockConst s_bc;
@@ -205,8 +205,8 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_sample_bwd(int B, int m, int c
             if (bb >= B) continue;
             float sum = 0.f;
             for (int q = 0; q < m; q++) sum += s_part[f][c2 * m + q];
-            if (f < 12) g_cp[(size_t)bb * 12 + f] = sum;
-            else g_width[bb] = sum;
+            float* dst = f < 12 ? g_cp + (size_t)bb * 12 + f : g_width + bb;
+            *dst = accumulate ? *dst + sum : sum;
         }
     }
 }
@@ -331,11 +331,12 @@ void launch_sample_norms(hipStream_t s, int B, int m, const float* cp, const uin
 }
 void launch_sample_backward_pass3(hipStream_t s, int B, int m, const float* cp, const float* width, const uint8_t* is_bezier,
                                   const void* coef, float eps, double* norms, const float* g_xyz, const float* g_rot,
-                                  const float* g_scaling, float* g_cp, float* g_width, float* gv_cache) {
+                                  const float* g_scaling, float* g_cp, float* g_width, float* gv_cache, int accumulate) {
     const int cpb = SAMPLE_BLOCK / m;
     ProfScope p("sample_b3", s);
     hipLaunchKernelGGL(k_sample_bwd<3>, dim3((B + cpb - 1) / cpb), dim3(SAMPLE_BLOCK), 0, s, B, m, cpb, cp, width, is_bezier,
-                       reinterpret_cast<const SampleCoef*>(coef), eps, norms, g_xyz, g_rot, g_scaling, g_cp, g_width, gv_cache);
+                       reinterpret_cast<const SampleCoef*>(coef), eps, norms, g_xyz, g_rot, g_scaling, g_cp, g_width, gv_cache,
+                       accumulate);
 }
 
 int sample_norm_words() { return NORM_WORDS; }

@@ -27,6 +27,7 @@ struct SplatGeom {                   // forward result for one visible splat
 // empty tile rectangle.
 __device__ __forceinline__ bool splat_geometry(const float3 p_orig, const float cov3D[6], const ViewParams& v,
                                                int antialiasing, SplatGeom& g) {
+#pragma clang fp contract(off)
     const float3 p_view = xform4x3(p_orig, v.vm);
     if (p_view.z <= 0.2f) return false;  // near cull only, auxiliary.h:166
     const float4 p_hom = xform4x4(p_orig, v.pm);

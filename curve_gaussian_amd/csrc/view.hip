@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_view_bwd(
     const float* __restrict__ campos, ViewParams vp, const int* __restrict__ radii, const SplatRec* __restrict__ rec,
     float* __restrict__ grad_acc, const float* __restrict__ g_rot_raw_extra, float* __restrict__ dL_dmean2D,
     float* __restrict__ g_opacity_logit, float* __restrict__ g_mask_logit, float* __restrict__ g_xyz,
-    float* __restrict__ g_scaling, float* __restrict__ gv_cache) {
+    float* __restrict__ g_scaling, float* __restrict__ gv_cache, int accumulate) {
     __shared__ SampleCoef s_coef[MAX_M];
     __shared__ BlockConst s_bc;
     __shared__ float s_go[SAMPLE_BLOCK];
@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_view_bwd(
         const AttrsBwd ab = attrs_backward(q, s.xyz, opacity_logit[b], has_mask, ml, mask_thr, cam, vp.vm, o.drot, true, acc2,
                                            o.dopac, has_mask, gs, scl);
         g_op_term = ab.g_op_term;
-        if (g_mask_logit) g_mask_logit[p] = ab.g_mask_logit;
+        if (g_mask_logit) g_mask_logit[p] = accumulate ? g_mask_logit[p] + ab.g_mask_logit : ab.g_mask_logit;
         float4 grr = ab.g_rot_raw;
         if (g_rot_raw_extra) {   // e.g. the curve-smoothness regulariser's gradient on the raw rotation
             const float4 e = reinterpret_cast<const float4*>(g_rot_raw_extra)[p];
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_view_bwd(
     if (valid && i == 0) {
         float sum = 0.f;
         for (int k = 0; k < m; k++) sum += s_go[threadIdx.x + k];
-        g_opacity_logit[b] = sum;
+        g_opacity_logit[b] = accumulate ? g_opacity_logit[b] + sum : sum;
     }
 }
 
@@ -172,14 +172,15 @@ void launch_view_backward(hipStream_t s, int B, int m, const float* cp, const fl
                           float mask_thr, const float* campos, const float* viewmatrix, const float* projmatrix,
                           float tan_fovx, float tan_fovy, float focal_x, float focal_y, int W, int H, const int* radii,
                           const SplatRec* rec, float* grad_acc, const float* g_rot_raw_extra, float* dL_dmean2D,
-                          float* g_opacity_logit, float* g_mask_logit, float* g_xyz, float* g_scaling, float* gv_cache) {
+                          float* g_opacity_logit, float* g_mask_logit, float* g_xyz, float* g_scaling, float* gv_cache,
+                          int accumulate) {
     ProfScope p("view_bwd", s);
     const int cpb = SAMPLE_BLOCK / m;
     const ViewParams vp{viewmatrix, projmatrix, tan_fovx, tan_fovy, focal_x, focal_y, W, H, 0, 0};
     hipLaunchKernelGGL(k_view_bwd, dim3((B + cpb - 1) / cpb), dim3(SAMPLE_BLOCK), 0, s, B, m, cpb, cp, width, is_bezier,
                        reinterpret_cast<const SampleCoef*>(coef), eps, norms, opacity_logit, mask_logit, mask_thr, campos, vp,
                        radii, rec, grad_acc, g_rot_raw_extra, dL_dmean2D, g_opacity_logit, g_mask_logit, g_xyz, g_scaling,
-                       gv_cache);
+                       gv_cache, accumulate);
 }
 
 }  // namespace cgs

@@ -386,7 +386,7 @@ class GraphedTrainStep(TrainStep):
             p(b["geom"]), p(b["bin"]), p(b["img"]), p(b["bg"]), W, H, p(cam.world_view_transform),
             p(cam.full_proj_transform), p(cam.camera_center), tanx, tany, p(b["radii"]), p(b["g_img"]), p(extra),
             p(b["g_m2d"]), p(grads.view("curve_points")), p(grads.view("width")), p(grads.view("opacity")),
-            p(grads.view("mask")) if mask is not None else None, p(b["view_scratch"]), s), "view_backward")
+            p(grads.view("mask")) if mask is not None else None, p(b["view_scratch"]), 0, s), "view_backward")
         if self.regularisers:
             grads.view("opacity").add_(b["r_op"])
             grads.view("width").add_(b["r_w"])

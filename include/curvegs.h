@@ -140,7 +140,8 @@ size_t cgs_binning_bytes(int64_t R);
  *     flows in (train.py's loss reads `render` only); dL_drotation_extra [P,4] or NULL is added to the gradient of the
  *     raw splat rotations before it is pulled back to the curves (the curve-smoothness regulariser enters there).
  *     Outputs: dL_dmeans2D [P,3] (NDC-scaled, feeds add_densification_stats), dL_dcurve_points [B,4,3], dL_dwidth [B,1],
- *     dL_dopacity_logit [B,1], dL_dmask_logit [P] (required iff mask_logit).  scratch:
+ *     dL_dopacity_logit [B,1], dL_dmask_logit [P] (required iff mask_logit) -- overwritten, or added to when `accumulate`
+ *     is non-zero (several views summed into one gradient buffer without extra kernels).  scratch:
  *     cgs_view_backward_scratch_floats(B, m) floats.
  * ------------------------------------------------------------------------------------------------ */
 int cgs_view_forward(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
@@ -157,7 +158,7 @@ int cgs_view_backward(int B, int m, const float* curve_points, const float* widt
                       int width_px, int height_px, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                       float tan_fovx, float tan_fovy, const int* radii, const float* dL_dout_color,
                       const float* dL_drotation_extra, float* dL_dmeans2D, float* dL_dcurve_points, float* dL_dwidth,
-                      float* dL_dopacity_logit, float* dL_dmask_logit, float* scratch, void* stream);
+                      float* dL_dopacity_logit, float* dL_dmask_logit, float* scratch, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Curve -> Gaussian sampling.  Replaces GaussianCurveModel.prepare_scaling_rot
@@ -321,6 +322,9 @@ int cgs_set_tile_culling(int on);
  *   [3]: number of splats whose tile rectangle exceeds 96 tiles (near-camera splats of room-scale scenes).  When a
  *       previous cgs_rasterize_forward of the same (P, width, height) saw any, such splats are binned by a second kernel, one workgroup
  *       each, instead of inside the wave that owns them (cgs_reset_binning_hints clears that memory too).
+ *   word [cgs_status_words()] (right behind the status words) is a STICKY count of overflowed tile lists: the library only
+ *       ever adds to it, so a caller that zeroes the image buffer once can replay many views and check one word at the
+ *       end instead of one flag per view.
  * The backward is cgs_rasterize_backward with R = 1.
  * ------------------------------------------------------------------------------------------------ */
 int cgs_rasterize_forward_static(void* geometry_buffer, void* binning_buffer, size_t binning_bytes, void* image_buffer,
