@@ -65,7 +65,14 @@ __global__ void __launch_bounds__(256) k_view_fwd(
 
 // Blocks hold whole curves (curves_per_block * m active threads), as k_attrs_bwd / k_sample_bwd<3> do: the per-curve
 // opacity-logit gradient is the sample-ordered sum of its m per-splat terms.
-__global__ void __launch_bounds__(SAMPLE_BLOCK) k_view_bwd(
+// 7 waves per SIMD = 72 VGPRs, the allocation of the compositors this kernel shares the GPU with when several views are
+// in flight: at its natural 115 VGPRs its waves only fit a SIMD once several compositor waves have drained, and the
+// kernel (18 us alone) stretched to 102 us inside the overlapped schedule.  The 45 spilled values cost 2 % serially and
+// buy 5 % of view throughput (0.406 -> 0.385 ms per view at cfg3, three views in flight).
+#ifndef CGS_VIEW_BWD_WAVES
+#define CGS_VIEW_BWD_WAVES 7
+#endif
+__global__ void __launch_bounds__(SAMPLE_BLOCK, CGS_VIEW_BWD_WAVES) k_view_bwd(
     int B, int m, int curves_per_block, const float* __restrict__ cp, const float* __restrict__ width,
     const uint8_t* __restrict__ is_bezier, const SampleCoef* __restrict__ coef, float eps, double* __restrict__ norms,
     const float* __restrict__ opacity_logit, const float* __restrict__ mask_logit, float mask_thr,
