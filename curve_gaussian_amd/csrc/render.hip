@@ -16,6 +16,7 @@
 // (quadrant, splat, field) -- no LDS atomics, no per-pixel global atomics (the reference issues 12 per pixel pair,
 // backward.cu:613-672).
 #include "kernels.h"
+#include "p2_mfma.h"
 #include <stdlib.h>
 
 namespace cgs {
@@ -324,6 +325,230 @@ __global__ void __launch_bounds__(256) k_render_fwd(const uint2* __restrict__ ra
     if (g.inside) {
         const size_t HW = (size_t)H * W;
         const float T = cA > -0x1p120f ? Tw : T_dead;   // live: Tw; terminated: the transmittance it stopped at
+        final_T[g.pix_id] = T;
+        n_contrib[g.pix_id] = last_contributor;
+        out_color[g.pix_id] = C + T * bg_color[0];
+        out_invdepth[g.pix_id] = Dacc;
+        if (GEO) {
+            out_all_map[g.pix_id] = A0;
+            out_all_map[HW + g.pix_id] = A1;
+            out_all_map[2 * HW + g.pix_id] = A2;
+            out_all_map[3 * HW + g.pix_id] = A3;
+        } else {
+            out_all_map[g.pix_id] = 0.f;
+            out_all_map[HW + g.pix_id] = 0.f;
+            out_all_map[2 * HW + g.pix_id] = 0.f;
+            out_all_map[3 * HW + g.pix_id] = 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward, v3
+// Same per-pixel arithmetic after the exponent, but the exponent itself -- log2(alpha) of every (pixel, splat) pair, a
+// quadratic polynomial in the pixel coordinates -- comes from the matrix cores (p2_mfma.h): two bf16 MFMAs evaluate it for
+// 16 splats x 64 pixels, at f32-class accuracy, beside the vector ALU instead of on it.  Per pair that removes the seven
+// VALU instructions of the quadratic form, the opacity multiply and 24 of the 48 bytes every lane used to pull out of LDS
+// (the kernel is bound by exactly those two: VALU issue and LDS return traffic).  Each wave compacts the staged entries
+// its quadrant accepted into a private list and walks it in groups of 16.
+constexpr int GROUP = 16;
+// 6 waves per SIMD (80 VGPRs, a dozen spills): 136 us at the natural 104 VGPRs / 4 waves, 124 at 5, 122 at 6, 128 at 7
+#ifndef CGS_FWD3_WAVES
+#define CGS_FWD3_WAVES 6
+#endif
+constexpr float L2_NEVER = -1000.f;   // log2 "opacity" of the padding entry: alpha = exp2(-1000) = 0
+
+constexpr uint32_t PAD_OFF = (BATCH + 1) * 16;
+
+template <bool GEO, bool SORT>
+__global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2* __restrict__ ranges,
+                                                     const uint32_t* __restrict__ point_list, int W, int H, int grid_x,
+                                                     const SplatRec* __restrict__ rec, float* __restrict__ final_T,
+                                                     uint32_t* __restrict__ n_contrib, const float* __restrict__ bg_color,
+                                                     float* __restrict__ out_color, float* __restrict__ out_invdepth,
+                                                     float* __restrict__ out_all_map, BucketSort bs) {
+    // staged entry j of the batch lives at index j + 1 (offset 0 = "nothing blended yet"); index BATCH + 1 is the padding
+    // entry (never blended, and behind every real one: the list offsets stay sorted)
+    __shared__ float4 s_geo[BATCH + 2];   // {cx, cy, A2, B2}
+    __shared__ float4 s_at[BATCH + 2];    // {colour, 1/depth, C2, log2 opacity}
+    __shared__ float4 s_c[GEO ? BATCH + 2 : 1];
+    __shared__ uint64_t s_qmask[4][4];
+    __shared__ __attribute__((aligned(16))) uint16_t s_list[4][BATCH + GROUP];   // per wave: 16 * (staged index + 1)
+    __shared__ uint32_t s_ord[SORT ? RANK_MAX + RANK_U : 1];
+    __shared__ uint32_t s_si[SORT ? RANK_MAX : 1];
+    __shared__ uint32_t s_hist[SORT ? RANK_NB : 1], s_start[SORT ? RANK_NB + 1 : 1], s_mm[8];
+    if (threadIdx.x == 0) {
+        s_geo[BATCH + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_at[BATCH + 1] = make_float4(0.f, 0.f, 0.f, L2_NEVER);
+        if (GEO) s_c[GEO ? BATCH + 1 : 0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const TileGeom g = tile_geom(W, H, grid_x);
+    const int lane = g.lane;
+    const float X0 = (float)(g.tx * TILE), Y0 = (float)(g.ty * TILE);
+    uint2 range;
+    if (SORT) {
+        const uint32_t tid = threadIdx.x;
+        const uint32_t cnt = bs.tile_count[g.tile];
+        const uint32_t n = min(cnt, bs.cap);
+        const uint32_t base = g.tile * bs.cap;
+        range = make_uint2(base, base + n);
+        if (tid == 0) {
+            bs.ranges[g.tile] = range;
+            if (cnt) {
+                uint32_t* part = bs.total + 4 + 2 * (g.tile % TOTAL_PARTS);
+                atomicAdd(&part[0], n);
+                atomicMax(&part[1], cnt);
+                if (cnt > bs.cap) {
+                    bs.total[2] = 1u;
+                    atomicAdd(&bs.total[TOTAL_WORDS], 1u);   // sticky: survives the next forward's clear
+                }
+            }
+        }
+        if (n > 0) {   // block-uniform
+            uint32_t rank[4], idx[4];
+            tile_rank_sort<4>(bs.keys + base, n, RankScratch{s_ord, s_si, s_hist, s_start, s_mm}, rank, idx);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t i = tid + 256u * q;
+                if (i < n) {
+                    s_ord[rank[q]] = idx[q];
+                    bs.point_list[base + rank[q]] = idx[q];
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        range = ranges[g.tile];
+    }
+    const int total = (int)(range.y - range.x);
+    const int rounds = (total + BATCH - 1) / BATCH;
+    const StepConsts k = step_consts();
+    float T_dead = 0.0f;
+    float Tw = 1.0f;
+    float cA = g.inside ? k.cA : -0x1p126f;
+    uint32_t last_contributor = 0;
+    float C = 0.f, Dacc = 0.f;
+    float A0 = 0.f, A1 = 0.f, A2 = 0.f, A3 = 0.f;
+    bool wave_done = ballot64(cA > -0x1p120f) == 0ull;
+    // matrix-core operands: this lane's pixel monomials (loop invariant), and what its splat-side row stands for
+    const P2Frag pix = p2_pixel_operand(lane);
+    const int row_splat = p2_row_splat(lane);
+    const float hx = X0 + (float)((g.wave & 1) << 3) + 3.5f;
+    const float hy = Y0 + (float)((g.wave >> 1) << 3) + 4.f * (float)p2_row_half(lane) + 1.5f;
+    uint16_t* const list = s_list[g.wave];
+    const char* const geo_bytes = reinterpret_cast<const char*>(s_geo);
+    const char* const at_bytes = reinterpret_cast<const char*>(s_at);
+    const char* const c_bytes = reinterpret_cast<const char*>(s_c);
+
+    for (int i = 0; i < rounds; i++) {
+        if (!__syncthreads_or(!wave_done)) break;
+        const int progress = i * BATCH + threadIdx.x;
+        uint32_t qm = 0;
+        if (progress < total) {
+            const uint32_t id = SORT ? s_ord[progress] : point_list[range.x + progress];
+            const SplatRec* r = rec + id;
+            const float4 a = r->a, b = r->b;
+            float4 sa, sb;
+            stage_splat(a, b, sa, sb);
+            s_geo[threadIdx.x + 1] = sa;
+            s_at[threadIdx.x + 1] = make_float4(sb.z, sb.w, sb.x, __builtin_amdgcn_logf(sb.y));   // v_log_f32 = log2
+            if (GEO) s_c[threadIdx.x + 1] = r->c;
+            qm = quadrant_mask(a, b, r->d.z, X0, Y0);   // (0 unless opacity >= 1/255: the log is finite for every listed entry)
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint64_t bal = ballot64((qm >> q) & 1u);
+            if (lane == 0) s_qmask[q][g.wave] = bal;
+        }
+        __syncthreads();
+        if (wave_done) continue;
+        // ---- this wave's list: the staged entries its quadrant accepted, in list order, padded to a multiple of 16
+        int n = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint64_t m = uniform64(s_qmask[g.wave][c]);
+            if ((m >> lane) & 1ull) {
+                const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                list[pos] = (uint16_t)((c * 64 + lane + 1) * 16);
+            }
+            n += __builtin_popcountll(m);
+        }
+        if (lane < GROUP) list[n + lane] = (uint16_t)PAD_OFF;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t last_off = 0;   // byte offset (16 * (staged index + 1)) of the last splat this pixel blended in this batch
+        for (int g0 = 0; g0 < n; g0 += GROUP) {
+            // exponents of the group's 16 splats at this wave's 64 pixels.  (Issuing the NEXT group's MFMAs before this
+            // group's blends was tried: 16 more live registers, 122 -> 135 us.)
+            f32x16 P;
+            {
+                const uint32_t joff = list[g0 + row_splat];
+                const float4 ge = *reinterpret_cast<const float4*>(geo_bytes + joff);
+                const float2 cl = *reinterpret_cast<const float2*>(at_bytes + joff + 8);
+                P = p2_mfma(p2_splat_operand(lane, ge.x, ge.y, ge.z, ge.w, cl.x, cl.y, hx, hy), pix);
+            }
+            const int cnt = min(GROUP, n - g0);
+            uint2 w4 = make_uint2(0u, 0u);   // four list offsets at a time, same in every lane
+#pragma unroll
+            for (int s = 0; s < GROUP; s += 2) {
+                if (s < cnt) {                                                  // wave-uniform
+                if ((s & 3) == 0) w4 = *reinterpret_cast<const uint2*>(list + g0 + s);
+                const uint32_t wpair = (s & 2) ? w4.y : w4.x;
+                const uint32_t j0 = wpair & 0xffffu, j1 = wpair >> 16;
+                const float2 t0 = *reinterpret_cast<const float2*>(at_bytes + j0);
+                const float2 t1 = *reinterpret_cast<const float2*>(at_bytes + j1);
+                float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
+                if (GEO) {
+                    c0 = *reinterpret_cast<const float4*>(c_bytes + j0);
+                    c1 = *reinterpret_cast<const float4*>(c_bytes + j1);
+                }
+                // alpha = min(0.99, opacity * G) = min(0.99, exp2(P)); reference: alpha < 1/255 -> skip
+                const float al0 = fminf(0.99f, __builtin_amdgcn_exp2f(P[s]));
+                const float al1 = fminf(0.99f, __builtin_amdgcn_exp2f(P[s + 1]));
+                const float a0 = al0 * sat01(fmaf(al0, k.big, cA));
+                const float a1 = al1 * sat01(fmaf(al1, k.big, cA));
+                // two splats blended together, one termination test (see k_render_fwd)
+                float wa = a0 * Tw;
+                float T1 = fmaf(-Tw, a0, Tw);
+                float wb = a1 * T1;
+                float T2 = fmaf(-T1, a1, T1);
+                if (__builtin_expect(ballot64(T2 < 0.0001f) != 0ull, 0)) {
+                    const bool d0 = T1 < 0.0001f;
+                    T_dead = d0 ? Tw : T_dead;
+                    wa = d0 ? 0.f : wa;
+                    T1 = d0 ? 1.0f : T1;
+                    const float a1e = d0 ? 0.f : a1;
+                    wb = a1e * T1;
+                    T2 = fmaf(-T1, a1e, T1);
+                    const bool d1 = T2 < 0.0001f;
+                    T_dead = d1 ? T1 : T_dead;
+                    wb = d1 ? 0.f : wb;
+                    T2 = d1 ? 1.0f : T2;
+                    cA = (d0 || d1) ? -0x1p126f : cA;
+                }
+                Tw = T2;
+                C = fmaf(t0.x, wa, C);
+                Dacc = fmaf(t0.y, wa, Dacc);
+                if (GEO) { A0 = fmaf(c0.x, wa, A0); A1 = fmaf(c0.y, wa, A1); A2 = fmaf(c0.z, wa, A2); A3 = fmaf(c0.w, wa, A3); }
+                C = fmaf(t1.x, wb, C);
+                Dacc = fmaf(t1.y, wb, Dacc);
+                if (GEO) { A0 = fmaf(c1.x, wb, A0); A1 = fmaf(c1.y, wb, A1); A2 = fmaf(c1.z, wb, A2); A3 = fmaf(c1.w, wb, A3); }
+                // the offsets grow along the list and w > 0 exactly when a splat was blended (its bit pattern then
+                // exceeds any offset): the median of the three keeps the offset of the last blended splat
+                last_off = max(min(last_off, j0), min(max(last_off, j0), __float_as_uint(wa)));   // v_med3_u32
+                last_off = max(min(last_off, j1), min(max(last_off, j1), __float_as_uint(wb)));
+            }
+            }
+            if (ballot64(cA > -0x1p120f) == 0ull) {   // every pixel of the quadrant has terminated
+                wave_done = true;
+                break;
+            }
+        }
+        if (last_off) last_contributor = (uint32_t)(i * BATCH) + (last_off >> 4);   // 1-based list position
+    }
+    if (g.inside) {
+        const size_t HW = (size_t)H * W;
+        const float T = cA > -0x1p120f ? Tw : T_dead;
         final_T[g.pix_id] = T;
         n_contrib[g.pix_id] = last_contributor;
         out_color[g.pix_id] = C + T * bg_color[0];
@@ -779,6 +1004,9 @@ __global__ void __launch_bounds__(256) k_render_bwd2(
                 const float4 a = *reinterpret_cast<const float4*>(sa_bytes + joff);
 #ifdef CGS_X_NOB
                 const float4 b = make_float4(a.z, 0.6f, 1.0f, 0.f);
+#elif defined(CGS_X_B32)
+                const float opv = *reinterpret_cast<const float*>(sb_bytes + joff + 4);
+                const float4 b = make_float4(a.z, opv, 1.0f, 0.f);
 #else
                 const float4 b = *reinterpret_cast<const float4*>(sb_bytes + joff);
 #endif
@@ -954,6 +1182,16 @@ void launch_render_fwd(hipStream_t s, bool geo, int tiles, const uint2* ranges, 
                        int H, int grid_x, const SplatRec* rec, float* final_T, uint32_t* n_contrib,
                        const float* bg_color, float* out_color, float* out_invdepth, float* out_all_map) {
     ProfScope p("render_fwd", s);
+    static const bool v2 = getenv("CGS_FWD_V2") && getenv("CGS_FWD_V2")[0] == '1';   // A/B: exponent on the vector ALU
+    if (!v2) {
+        if (geo)
+            hipLaunchKernelGGL((k_render_fwd3<true, false>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H, grid_x, rec,
+                               final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, BucketSort{});
+        else
+            hipLaunchKernelGGL((k_render_fwd3<false, false>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H, grid_x, rec,
+                               final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, BucketSort{});
+        return;
+    }
     if (geo)
         hipLaunchKernelGGL((k_render_fwd<true, false>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H, grid_x, rec,
                            final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, BucketSort{});
@@ -968,6 +1206,16 @@ void launch_render_fwd_sorting(hipStream_t s, bool geo, int tiles, const uint32_
                                const float* bg_color, float* out_color, float* out_invdepth, float* out_all_map) {
     ProfScope p("render_fwd", s);
     BucketSort bs{tile_count, keys, point_list, ranges, total, cap};
+    static const bool v2 = getenv("CGS_FWD_V2") && getenv("CGS_FWD_V2")[0] == '1';
+    if (!v2) {
+        if (geo)
+            hipLaunchKernelGGL((k_render_fwd3<true, true>), dim3(tiles), dim3(256), 0, s, nullptr, nullptr, W, H, grid_x, rec,
+                               final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, bs);
+        else
+            hipLaunchKernelGGL((k_render_fwd3<false, true>), dim3(tiles), dim3(256), 0, s, nullptr, nullptr, W, H, grid_x, rec,
+                               final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, bs);
+        return;
+    }
     if (geo)
         hipLaunchKernelGGL((k_render_fwd<true, true>), dim3(tiles), dim3(256), 0, s, nullptr, nullptr, W, H, grid_x, rec,
                            final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, bs);
