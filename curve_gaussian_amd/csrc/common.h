@@ -22,7 +22,7 @@ struct __attribute__((aligned(64))) SplatRec {
 
 // Packed per-splat gradient accumulators filled by the backward compositor (raw sums; the per-splat linear maps to
 // dL/dmean2D, dL/dconic are applied once per splat in k_preprocess_bwd).  One 64-byte line per splat:
-//   [0] Sg = sum G dL/dalpha (= dL/dopacity)   [1] Sx = sum g dx   [2] Sy = sum g dy
+//   [0] Sg = sum g, g = opacity G dL/dalpha (dL/dopacity = Sg / opacity)   [1] Sx = sum g dx   [2] Sy = sum g dy
 //   [3] Sxx  [4] Sxy  [5] Syy   [6] colour   [7] inv-depth   [8..11] all_map   [12..15] unused
 constexpr int ACC_STRIDE = 16;
 constexpr int ACC_COL = 6, ACC_INVD = 7, ACC_MAP = 8;

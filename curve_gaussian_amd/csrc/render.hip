@@ -40,7 +40,6 @@ __device__ __forceinline__ StepConsts step_consts() {
     return k;
 }
 constexpr int SLOTS = 8;          // accepted splats buffered per wave between two splat-parallel moment passes
-constexpr int SLOT_STRIDE = 65;   // +1 pad: lane (s,q) reads s_g[s][16q+p] -> bank (s + 16q + p) % 32, conflict-free
 
 struct TileGeom {
     uint32_t tile, tx, ty;
@@ -355,9 +354,13 @@ constexpr int GROUP = 16;
 #ifndef CGS_FWD3_WAVES
 #define CGS_FWD3_WAVES 6
 #endif
+// backward: 100 VGPRs unconstrained (5 waves); at 80 (6 waves, no spills) it shares SIMDs evenly with the forward when
+// several views overlap: 0.380 -> 0.366 ms per view with three views in flight
+#ifndef CGS_BWD3_WAVES
+#define CGS_BWD3_WAVES 6
+#endif
+constexpr uint32_t PAD_OFF = (BATCH + 1) * 16;   // byte offset of the padding entry in the staged arrays
 constexpr float L2_NEVER = -1000.f;   // log2 "opacity" of the padding entry: alpha = exp2(-1000) = 0
-
-constexpr uint32_t PAD_OFF = (BATCH + 1) * 16;
 
 template <bool GEO, bool SORT>
 __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2* __restrict__ ranges,
@@ -599,34 +602,57 @@ __device__ __forceinline__ float rows_sum2(float a, float b) {     // -> [a, b, 
     return __uint_as_float(s[0]) + __uint_as_float(s[1]);
 }
 
-// Per (pixel, splat) pair the backward needs, with g := G * dL/dalpha, the seven sums
-//   Sg = sum g, Sx = sum g dx, Sy = sum g dy, Sxx = sum g dx dx, Sxy = sum g dx dy, Syy = sum g dy dy, Sc = sum alpha T dL/dC
-// from which (reference backward.cu:655-672, linear in the sums):
-//   dL/dmean2D = -op (A Sx + B Sy) W/2, -op (C Sy + B Sx) H/2;  dL/dconic = -op/2 (Sxx, Sxy, Syy);  dL/dopacity = Sg
+// ------------------------------------------------------------------------------------------------ backward
+// Per (pixel, splat) pair the backward needs, with g := alpha_u dL/dalpha (alpha_u = opacity * G, the unclamped alpha), the
+// sums  Sg = sum g, Sx = sum g dx, Sy = sum g dy, Sxx = sum g dx dx, Sxy = sum g dx dy, Syy = sum g dy dy  over the pixels,
+// from which (reference backward.cu:655-672, linear in the sums; applied once per splat in splat_math.h::splat_backward):
+//   dL/dmean2D = -(A Sx + B Sy) W/2, -(C Sy + B Sx) H/2;   dL/dconic = -1/2 (Sxx, Sxy, Syy);   dL/dopacity = Sg / opacity.
+//
+// Structure (the kernel is bound by vector issue and by the bytes every lane pulls out of LDS, profiles/r02_*):
+//   * log2(alpha_u) of 16 splats x 64 pixels comes from two bf16 MFMAs (p2_mfma.h), as in k_render_fwd3: per pair that
+//     leaves exp2, the alpha tests and the transmittance / colour-behind recurrences on the vector ALU, and ONE dword (the
+//     splat's colour) to read from LDS instead of seven;
+//   * each wave compacts the staged entries its quadrant accepted (and that lie before the last splat any of its pixels
+//     blended) into a private list and walks it as a counted loop -- no scalar bit walk, no per-pair slot bookkeeping;
+//   * phase 1 (pixel-parallel) parks one scalar g per (pixel, splat) in a per-wave LDS slot buffer, eight splats at a time;
+//     phase 2 (splat-parallel): lane (slot, pixel row) folds its 8 pixels into the six moments about the row's first pixel
+//     and shifts them to the splat centre, the 8 row results of a slot are summed through LDS by the (slot, field) lanes,
+//     which issue the global f32 atomics -- 8 consecutive floats per splat = one L2 request (the reference issues 12 atomics
+//     per PIXEL pair, backward.cu:613-672);
+//   * the "power > 0" skip (backward.cu:583-585) is not evaluated: for a positive-definite conic it can only fire on
+//     rounding noise at pixels where G = 1 to 1e-6 (deviations).
+constexpr int LSTRIDE = 68;   // floats per slot row: 64 pixels + 4 (16-byte aligned rows; (slot * 68 + x) % 32 banks spread)
+
 template <bool GEO, bool INVD, bool COLG>
-__global__ void __launch_bounds__(256) k_render_bwd(
+__global__ void __launch_bounds__(256, CGS_BWD3_WAVES) k_render_bwd3(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int grid_x,
     const float* __restrict__ bg_color, const SplatRec* __restrict__ rec, const float* __restrict__ final_Ts,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
     const float* __restrict__ dL_dout_invdepth, const float* __restrict__ dL_dout_all_map,
     float* __restrict__ grad_acc) {
-    constexpr int NF = GEO ? 12 : 8;       // fields of the packed per-splat accumulator record that can be non-zero
-    __shared__ float4 s_a[BATCH];
-    __shared__ float4 s_b[BATCH];
-    __shared__ float4 s_c[GEO ? BATCH : 1];
-    __shared__ uint32_t s_id[BATCH];
-    __shared__ float s_t[4][SLOTS][16];    // per wave: slot sums laid out [slot][field] for the transposed atomic flush
-    __shared__ float s_g[4][SLOTS][SLOT_STRIDE];  // per wave: g = G dL/dalpha of the last <=16 accepted splats x 64 pixels
+    // staged entry j of the batch lives at index j + 1; index BATCH + 1 is the padding entry (alpha = 0)
+    __shared__ float4 s_geo[BATCH + 2];   // {cx, cy, A2, B2}
+    __shared__ float4 s_at[BATCH + 2];    // {colour, 1/depth, C2, log2 opacity}
+    __shared__ float4 s_c[GEO ? BATCH + 2 : 1];
+    __shared__ uint32_t s_id[BATCH + 2];
     __shared__ uint64_t s_qmask[4][4];
+    __shared__ __attribute__((aligned(16))) uint16_t s_list[4][BATCH + GROUP];   // per wave: 16 * (staged index + 1)
+    __shared__ __attribute__((aligned(16))) float s_g[4][SLOTS * LSTRIDE];       // per wave: g of 8 slots x 64 pixels; then the row sums
+    __shared__ float s_x[4][SLOTS][8];                                           // per wave: colour / inv-depth / all_map sums per slot
     const TileGeom g = tile_geom(W, H, grid_x);
     const int lane = g.lane;
-    const float pixfx = (float)g.px, pixfy = (float)g.py;
     const float X0 = (float)(g.tx * TILE), Y0 = (float)(g.ty * TILE);
     const uint2 range = ranges[g.tile];
     const int total = (int)(range.y - range.x);
     if (total == 0) return;
     const int rounds = (total + BATCH - 1) / BATCH;
     const size_t HW = (size_t)H * W;
+    if (threadIdx.x == 0) {
+        s_geo[BATCH + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_at[BATCH + 1] = make_float4(0.f, 0.f, 0.f, L2_NEVER);
+        if (GEO) s_c[GEO ? BATCH + 1 : 0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_id[BATCH + 1] = 0u;
+    }
 
     const float T_final = g.inside ? final_Ts[g.pix_id] : 0.f;
     float T = T_final;
@@ -652,6 +678,21 @@ __global__ void __launch_bounds__(256) k_render_bwd(
     const float nTf_bg = -T_final * (bg_color[0] * dL_dpixel);             // backward.cu:649-652
     float Tp = T_final * dL_dpixel;                                        // T dL/dpixel (single-channel configurations)
     const int col = lane & 15;
+    uint16_t* const list = s_list[g.wave];
+    float* const sg = s_g[g.wave];
+    const char* const geo_bytes = reinterpret_cast<const char*>(s_geo);
+    const char* const at_bytes = reinterpret_cast<const char*>(s_at);
+    const char* const c_bytes = reinterpret_cast<const char*>(s_c);
+    // matrix-core operands (see k_render_fwd3)
+    const P2Frag pix = p2_pixel_operand(lane);
+    const int row_splat = p2_row_splat(lane);
+    const float qx0 = (float)(g.tx * TILE + ((g.wave & 1) << 3));
+    const float hx = qx0 + 3.5f;
+    const float hy = Y0 + (float)((g.wave >> 1) << 3) + 4.f * (float)p2_row_half(lane) + 1.5f;
+    // flush roles: lane (sl, q) folds pixel row q of slot sl; lane (fs, ff) sums field ff of slot fs over the rows
+    const int sl = lane & (SLOTS - 1), q = lane >> 3;
+    const int fs = lane >> 3, ff = lane & 7;
+    const float qyr = (float)(g.ty * TILE + ((g.wave >> 1) << 3) + q);
 
     for (int i = 0; i < rounds; i++) {
         if (i > 0) __syncthreads();  // every wave is done with the previous batch's staged data
@@ -663,291 +704,10 @@ __global__ void __launch_bounds__(256) k_render_bwd(
             const float4 a = r->a, b = r->b;
             float4 sa, sb;
             stage_splat(a, b, sa, sb);
-            s_id[threadIdx.x] = id;
-            s_a[threadIdx.x] = sa;
-            s_b[threadIdx.x] = sb;
-            if (GEO) s_c[threadIdx.x] = r->c;
-            qm = quadrant_mask(a, b, r->d.z, X0, Y0);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint64_t bal = ballot64((qm >> q) & 1u);
-            if (lane == 0) s_qmask[q][g.wave] = bal;
-        }
-        __syncthreads();
-        // staged index J (0..255) of batch i sits at 0-based list position  pos = total-1-(i*256+J); it can matter to
-        // this wave only if pos < wave_last  <=>  J >= total-wave_last-i*256
-        const int first_J = total - (int)wave_last - i * BATCH;
-        // Phase 1 (pixel-parallel): walk this quadrant's accepted splats back to front; every lane keeps its pixel's
-        // recurrences and emits ONE scalar g = G dL/dalpha per (pixel, splat) into the wave's slot buffer.
-        // Phase 2 (splat-parallel, every SLOTS accepted splats): lane (s = lane & 15, q = lane >> 4) owns slot s and
-        // the 16 pixels of quadrant rows 2q, 2q+1 and accumulates the six moments of g there with plain FMAs -- no
-        // 64-lane reduction per field; a 4-way cross-row sum (v_permlane swaps) finishes it.
-        int nslot = 0;
-        int slot_j = 0;   // lane s: staged index of the splat parked in slot s (v_writelane per pair, one bpermute per flush)
-        float t_c = 0.f, t_invd = 0.f, t_m0 = 0.f, t_m1 = 0.f, t_m2 = 0.f, t_m3 = 0.f;  // extras: DPP-reduced, column = slot
-        auto flush_slots = [&](int n) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            constexpr int QG = 64 / SLOTS;        // lane groups per slot (4 or 8)
-            constexpr int RPL = 8 / QG;           // quadrant rows per lane (2 or 1)
-            const int sl = lane & (SLOTS - 1), q = lane / SLOTS;
-            const int j = __builtin_amdgcn_ds_bpermute(4 * (sl < n ? sl : 0), slot_j);
-            const float4 sa = s_a[j];
-            const float dx0 = sa.x - (float)(g.tx * TILE + ((g.wave & 1) << 3));             // minus column c
-            const float dy0 = sa.y - (float)(g.ty * TILE + ((g.wave >> 1) << 3) + RPL * q);  // minus row r
-            // Moments of the row's 8 values about the row's first pixel (weights 0..7 and 0,1,4,..49 are instruction
-            // constants), then shifted to the splat centre: sum g (d-c) = d M0 - M1, sum g (d-c)^2 = d (d M0 - 2 M1) + M2.
-            // 19 + 3 instructions per row instead of 16 (the d-c, (d-c)^2 tables) + 24.
-            float Sg, Sx, Sy, Sxx, Sxy, Syy;
-            const float* gp = &s_g[g.wave][sl][8 * RPL * q];
-#pragma unroll
-            for (int r = 0; r < RPL; r++) {
-                const float dyr = dy0 - (float)r;
-                float M0 = gp[8 * r], M1 = gp[8 * r + 1], M2 = M1;
-                M0 += M1;
-#pragma unroll
-                for (int c = 2; c < 8; c++) {
-                    const float gv = gp[8 * r + c];
-                    M0 += gv; M1 = fmaf(gv, (float)c, M1); M2 = fmaf(gv, (float)(c * c), M2);
-                }
-                const float Rx = fmaf(dx0, M0, -M1);
-                const float Rxx = fmaf(dx0, Rx - M1, M2);
-                if (r == 0) {
-                    Sg = M0; Sx = Rx; Sxx = Rxx;
-                    Sy = dyr * M0; Sxy = dyr * Rx; Syy = (dyr * dyr) * M0;
-                } else {
-                    Sg += M0; Sx += Rx; Sxx += Rxx;
-                    Sy = fmaf(dyr, M0, Sy); Sxy = fmaf(dyr, Rx, Sxy); Syy = fmaf(dyr * dyr, M0, Syy);
-                }
-            }
-            if (SLOTS == 8) {  // lanes l and l^8 hold the two half-row groups of the same slot: fold them first
-                Sg += dpp_row_ror8(Sg); Sx += dpp_row_ror8(Sx); Sy += dpp_row_ror8(Sy);
-                Sxx += dpp_row_ror8(Sxx); Sxy += dpp_row_ror8(Sxy); Syy += dpp_row_ror8(Syy);
-            }
-            // Sum over the four 16-lane rows, TRANSPOSING on the way: one v_permlane16_swap + add halves the rows of two
-            // quantities at once, one v_permlane32_swap + add finishes four -- row r of U ends up holding field r
-            // (Sg, Sx, Sy, Sxx) and rows 0/1 of V fields 4/5 (Sxy, Syy): 5 swaps + 5 adds for the six moments instead
-            // of 12 + 12 (+ the register copies a swap of a value with itself needs).
-            const float U = rows_sum4(Sg, Sx, Sy, Sxx);
-            const float V = rows_sum2(Sxy, Syy);
-            if (COLG) t_c = rows_sum(t_c);
-            if (INVD) t_invd = rows_sum(t_invd);
-            if (GEO) { t_m0 = rows_sum(t_m0); t_m1 = rows_sum(t_m1); t_m2 = rows_sum(t_m2); t_m3 = rows_sum(t_m3); }
-            // Transposed flush: the sums are laid out [slot][field] in LDS and lane (slot = lane >> 3, field = lane & 7)
-            // issues the global f32 atomic, so the 6-8 atomics of one splat hit 8 consecutive floats of its 64-byte
-            // accumulator record and coalesce into ONE L2 request (measured 7x the rate of one-field-per-instruction;
-            // profiles/probes/xcc_probe.hip).
-            {
-                const int row = lane >> 4;
-                if ((lane & 15) < SLOTS && sl < n) {
-                    float* tp = &s_t[g.wave][sl][0];
-                    tp[row] = U;
-                    if (row < 2) tp[4 + row] = V;
-                }
-            }
-            if (lane < n) {
-                float* tp = &s_t[g.wave][lane][0];
-                tp[ACC_COL] = COLG ? t_c : 0.f;
-                tp[ACC_INVD] = INVD ? t_invd : 0.f;
-                if (GEO) { tp[ACC_MAP + 0] = t_m0; tp[ACC_MAP + 1] = t_m1; tp[ACC_MAP + 2] = t_m2; tp[ACC_MAP + 3] = t_m3; }
-                tp[15] = __uint_as_float(s_id[j]);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int pass = 0; pass < (GEO ? 2 : 1); pass++) {
-                const int slot = lane >> 3, f = (lane & 7) + 8 * pass;
-                if (slot < n && f < NF) {
-                    const float v = s_t[g.wave][slot][f];
-                    const uint32_t id = __float_as_uint(s_t[g.wave][slot][15]);
-                    if (v != 0.f)
-                        atomicAdd(grad_acc + (size_t)id * ACC_STRIDE + f, v);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();  // slot buffer may be overwritten from here on
-        };
-#pragma unroll 1
-        for (int c = 0; c < 4; c++) {
-            uint64_t m = uniform64(s_qmask[g.wave][c]);
-            const int lo = first_J - c * 64;
-            if (lo >= 64) m = 0;
-            else if (lo > 0) m &= ~((1ull << lo) - 1ull);
-            while (m) {
-                const int bit = __builtin_ctzll(m);
-                m &= m - 1;
-                const int j = c * 64 + bit;
-                const uint32_t pos = (uint32_t)(total - 1 - (i * BATCH + j));  // contributor after the decrement
-                const float4 a = s_a[j];
-                const float4 b = s_b[j];
-                const float dx = a.x - pixfx, dy = a.y - pixfy;
-                const float p2 = dx * (a.z * dx + a.w * dy) + b.x * dy * dy;
-                const float G = __builtin_amdgcn_exp2f(p2);
-                const float alpha = fminf(0.99f, b.y * G);
-                const bool active = (pos < last_contributor) && !(p2 > 0.0f) && !(alpha < ALPHA_MIN);
-                if (ballot64(active) == 0ull) continue;
-                float v_g = 0.f, v_c = 0.f, v_invd = 0.f, v_m0 = 0.f, v_m1 = 0.f, v_m2 = 0.f, v_m3 = 0.f;
-                if (active) {
-                    // The reference keeps (last_alpha, last_colour) and folds them into the "colour behind" accumulator at
-                    // the start of the next step (backward.cu:605,620,631); folding right after use is the same
-                    // recurrence -- acc' = alpha c + (1 - alpha) acc = acc + alpha (c - acc) -- with one fma per channel
-                    // on the difference the gradient needs anyway, and no register copies (v_mov issues at half rate).
-                    const float rcp_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-                    float dL_dalpha;
-                    if (!INVD && !GEO) {   // one channel: carry Tp = T dL/dpixel instead of T
-                        Tp = Tp * rcp_1ma;
-                        const float d_c = b.z - accum_rec;
-                        accum_rec = fmaf(alpha, d_c, accum_rec);
-                        if (COLG) v_c = alpha * Tp;
-                        dL_dalpha = fmaf(nTf_bg, rcp_1ma, d_c * Tp);
-                    } else {
-                        T = T * rcp_1ma;
-                        const float dchannel_dcolor = alpha * T;
-                        const float d_c = b.z - accum_rec;
-                        accum_rec = fmaf(alpha, d_c, accum_rec);
-                        float sum = d_c * dL_dpixel;
-                        if (COLG) v_c = dchannel_dcolor * dL_dpixel;
-                        if (INVD) {
-                            const float d_i = b.w - accum_invd;
-                            accum_invd = fmaf(alpha, d_i, accum_invd);
-                            sum = fmaf(d_i, dL_invd, sum);
-                            v_invd = dchannel_dcolor * dL_invd;
-                        }
-                        if (GEO) {
-                            const float4 cm = s_c[j];
-                            const float d0 = cm.x - accum_m0, d1 = cm.y - accum_m1, d2 = cm.z - accum_m2, d3 = cm.w - accum_m3;
-                            accum_m0 = fmaf(alpha, d0, accum_m0); accum_m1 = fmaf(alpha, d1, accum_m1);
-                            accum_m2 = fmaf(alpha, d2, accum_m2); accum_m3 = fmaf(alpha, d3, accum_m3);
-                            sum = fmaf(d0, dm0, sum); sum = fmaf(d1, dm1, sum); sum = fmaf(d2, dm2, sum); sum = fmaf(d3, dm3, sum);
-                            v_m0 = dchannel_dcolor * dm0; v_m1 = dchannel_dcolor * dm1;
-                            v_m2 = dchannel_dcolor * dm2; v_m3 = dchannel_dcolor * dm3;
-                        }
-                        dL_dalpha = fmaf(nTf_bg, rcp_1ma, sum * T);
-                    }
-                    v_g = G * dL_dalpha;
-                }
-                s_g[g.wave][nslot][lane] = v_g;
-                // (no clang builtin for v_writelane; gfx9 allows one SGPR per VALU instruction, so the lane select goes
-                // through m0 -- nothing else in this kernel uses m0, and clang rejects it as a clobber: "reserved")
-                asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(slot_j) : "s"(j), "s"(nslot));
-                if (COLG || INVD || GEO) {
-                    const bool mine = col == nslot;
-                    if (COLG) { v_c = row16_sum(v_c); t_c = mine ? v_c : t_c; }
-                    if (INVD) { v_invd = row16_sum(v_invd); t_invd = mine ? v_invd : t_invd; }
-                    if (GEO) {
-                        v_m0 = row16_sum(v_m0); v_m1 = row16_sum(v_m1); v_m2 = row16_sum(v_m2); v_m3 = row16_sum(v_m3);
-                        t_m0 = mine ? v_m0 : t_m0; t_m1 = mine ? v_m1 : t_m1;
-                        t_m2 = mine ? v_m2 : t_m2; t_m3 = mine ? v_m3 : t_m3;
-                    }
-                }
-                if (++nslot == SLOTS) {
-                    flush_slots(SLOTS);
-                    nslot = 0;
-                }
-            }
-        }
-        if (nslot) flush_slots(nslot);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ backward, v2
-// Same mapping and reduction idea as k_render_bwd above, restructured around the fact that the kernel is bound by VALU
-// issue (profiles/r01_pmc.csv: SQ_ACTIVE_INST_VALU = 131.7 M quad-cycles = 514 k cycles per SIMD against 499 k busy
-// cycles) -- every vector instruction and every VGPR-returning LDS read removed from the per-pair path counts:
-//   * each wave compacts the staged indices its quadrant accepted into a private list of LDS byte offsets (one
-//     mbcnt + ds_write_b16 per 64 entries) and walks it as a COUNTED loop, eight entries per trip: no scalar bit walk,
-//     no m0 / v_writelane slot bookkeeping, slot buffers addressed by instruction-immediate offsets;
-//   * the "power > 0" skip (backward.cu:583-585) is dropped from the per-pair path: for a positive-definite conic it
-//     can only fire on rounding noise at pixels where G = 1 to 1e-6 (deviations);
-//   * the 64-pixel moment sums leave the (slot, pixel-row) lanes through LDS (6 ds_write_b32, 2 ds_read_b128 + 7 adds in
-//     the (slot, field) lanes that issue the atomics) instead of 6 DPP adds + 5 permlane swaps + the transposing stores.
-constexpr int LSTRIDE = 68;   // floats per slot row: 64 pixels + 4 (16-byte aligned rows; (slot * 68 + x) % 32 banks spread)
-constexpr uint32_t DUMMY_OFF = BATCH * 16;   // byte offset of the all-zero staged entry (opacity 0: never active)
-
-template <bool GEO, bool INVD, bool COLG>
-__global__ void __launch_bounds__(256) k_render_bwd2(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int grid_x,
-    const float* __restrict__ bg_color, const SplatRec* __restrict__ rec, const float* __restrict__ final_Ts,
-    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
-    const float* __restrict__ dL_dout_invdepth, const float* __restrict__ dL_dout_all_map,
-    float* __restrict__ grad_acc) {
-    constexpr int NF = GEO ? 12 : 8;
-    __shared__ float4 s_a[BATCH + 1];   // entry BATCH: zeros
-    __shared__ float4 s_b[BATCH + 1];
-    __shared__ float4 s_c[GEO ? BATCH + 1 : 1];
-    __shared__ uint32_t s_id[BATCH + 1];
-    __shared__ uint64_t s_qmask[4][4];
-    __shared__ __attribute__((aligned(16))) uint16_t s_list[4][BATCH + 8];   // per wave: byte offsets (16 * staged index)
-    __shared__ __attribute__((aligned(16))) float s_g[4][SLOTS * LSTRIDE];   // per wave: g of 8 slots x 64 pixels; then the row sums
-    __shared__ float s_x[4][SLOTS][8];                                       // per wave: colour / inv-depth / all_map sums per slot
-    const TileGeom g = tile_geom(W, H, grid_x);
-    const int lane = g.lane;
-    const float pixfx = (float)g.px, pixfy = (float)g.py;
-    const float X0 = (float)(g.tx * TILE), Y0 = (float)(g.ty * TILE);
-    const uint2 range = ranges[g.tile];
-    const int total = (int)(range.y - range.x);
-    if (total == 0) return;
-    const int rounds = (total + BATCH - 1) / BATCH;
-    const size_t HW = (size_t)H * W;
-    if (threadIdx.x == 0) {
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        s_a[BATCH] = z;
-        s_b[BATCH] = z;
-        if (GEO) s_c[GEO ? BATCH : 0] = z;
-        s_id[BATCH] = 0u;
-    }
-
-    const float T_final = g.inside ? final_Ts[g.pix_id] : 0.f;
-    float T = T_final;
-    const uint32_t last_contributor = g.inside ? n_contrib[g.pix_id] : 0u;
-    uint32_t wave_last = last_contributor;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, off, 64));
-    wave_last = __builtin_amdgcn_readfirstlane(wave_last);
-
-    float accum_rec = 0.f, accum_invd = 0.f, accum_m0 = 0.f, accum_m1 = 0.f, accum_m2 = 0.f, accum_m3 = 0.f;
-    float dL_dpixel = 0.f, dL_invd = 0.f, dm0 = 0.f, dm1 = 0.f, dm2 = 0.f, dm3 = 0.f;
-    if (g.inside) {
-        dL_dpixel = dL_dpixels[g.pix_id];
-        if (INVD) dL_invd = dL_dout_invdepth[g.pix_id];
-        if (GEO) {
-            dm0 = dL_dout_all_map[g.pix_id];
-            dm1 = dL_dout_all_map[HW + g.pix_id];
-            dm2 = dL_dout_all_map[2 * HW + g.pix_id];
-            dm3 = dL_dout_all_map[3 * HW + g.pix_id];
-        }
-    }
-    const float nTf_bg = -T_final * (bg_color[0] * dL_dpixel);
-    float Tp = T_final * dL_dpixel;
-    const int col = lane & 15;
-    uint16_t* const list = s_list[g.wave];
-    float* const sg = s_g[g.wave];
-    const char* const sa_bytes = reinterpret_cast<const char*>(s_a);
-    const char* const sb_bytes = reinterpret_cast<const char*>(s_b);
-    const char* const sc_bytes = reinterpret_cast<const char*>(s_c);
-    // flush roles: lane (sl, q) folds pixel row q of slot sl; lane (fs, ff) sums field ff of slot fs over the rows
-    const int sl = lane & (SLOTS - 1), q = lane >> 3;
-    const int fs = lane >> 3, ff = lane & 7;
-    const float qx0 = (float)(g.tx * TILE + ((g.wave & 1) << 3));
-    const float qyr = (float)(g.ty * TILE + ((g.wave >> 1) << 3) + q);
-
-    for (int i = 0; i < rounds; i++) {
-        if (i > 0) __syncthreads();
-        const int progress = i * BATCH + threadIdx.x;
-        uint32_t qm = 0;
-        if (progress < total) {
-            const uint32_t id = point_list[range.y - progress - 1];
-            const SplatRec* r = rec + id;
-            const float4 a = r->a, b = r->b;
-            float4 sa, sb;
-            stage_splat(a, b, sa, sb);
-            s_id[threadIdx.x] = id;
-            s_a[threadIdx.x] = sa;
-            s_b[threadIdx.x] = sb;
-            if (GEO) s_c[threadIdx.x] = r->c;
+            s_id[threadIdx.x + 1] = id;
+            s_geo[threadIdx.x + 1] = sa;
+            s_at[threadIdx.x + 1] = make_float4(sb.z, sb.w, sb.x, __builtin_amdgcn_logf(sb.y));   // v_log_f32 = log2
+            if (GEO) s_c[threadIdx.x + 1] = r->c;
             qm = quadrant_mask(a, b, r->d.z, X0, Y0);
         }
 #pragma unroll
@@ -956,8 +716,8 @@ __global__ void __launch_bounds__(256) k_render_bwd2(
             if (lane == 0) s_qmask[qq][g.wave] = bal;
         }
         __syncthreads();
-        // ---- this wave's list: accepted staged indices J >= first_J (everything before is behind the last splat any
-        // pixel of the quadrant blended), in staging order = back to front
+        // ---- this wave's list.  Staged index J (0..255) of batch i sits at 0-based list position
+        // total-1-(i*256+J); it can matter to this wave only if that is < wave_last  <=>  J >= first_J
         const int first_J = total - (int)wave_last - i * BATCH;
         int n = 0;
 #pragma unroll
@@ -968,213 +728,159 @@ __global__ void __launch_bounds__(256) k_render_bwd2(
             else if (lo > 0) m &= ~((1ull << lo) - 1ull);
             if ((m >> lane) & 1ull) {
                 const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                list[pos] = (uint16_t)((c * 64 + lane) * 16);
+                list[pos] = (uint16_t)((c * 64 + lane + 1) * 16);
             }
             n += __builtin_popcountll(m);
         }
-        if (lane < 8) list[n + lane] = (uint16_t)DUMMY_OFF;
-        // lane-private: a staged entry J matters to this pixel iff its list position total-1-(i*256+J) < last_contributor
+        if (lane < GROUP) list[n + lane] = (uint16_t)PAD_OFF;
+        // lane-private: staged entry J matters to this pixel iff its list position < last_contributor  <=>  J >= first_lane
         const int first_lane = total - (int)last_contributor - i * BATCH;
-        const uint32_t jmin_off = (uint32_t)max(first_lane, 0) * 16u;
+        const uint32_t jmin_off = (uint32_t)(max(first_lane, 0) + 1) * 16u;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#ifdef CGS_X_NOWALK
-        n = 0;
-#endif
-        for (int k0 = 0; k0 < n; k0 += SLOTS) {
-            const uint4 w4 = *reinterpret_cast<const uint4*>(list + k0);   // eight offsets, same address in every lane
-            const uint32_t wv[4] = {w4.x, w4.y, w4.z, w4.w};
-            float t_c = 0.f, t_invd = 0.f, t_m0 = 0.f, t_m1 = 0.f, t_m2 = 0.f, t_m3 = 0.f;
-#ifdef CGS_X_PREFETCH
-            // what the flush lanes need (splat centre of slot sl, splat id of slot fs) is requested before the walk, so
-            // the flush does not start with two dependent LDS round trips
-            const uint32_t pf_joff = list[k0 + sl];
-            const float2 pf_cxy = *reinterpret_cast<const float2*>(sa_bytes + pf_joff);
-            const uint32_t pf_id = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_id) + (list[k0 + fs] >> 2));
-#endif
+        for (int g0 = 0; g0 < n; g0 += GROUP) {
+            f32x16 P;   // log2 of the unclamped alpha of the group's 16 splats at this lane's pixel
+            {
+                const uint32_t joff = list[g0 + row_splat];
+                const float4 ge = *reinterpret_cast<const float4*>(geo_bytes + joff);
+                const float2 cl = *reinterpret_cast<const float2*>(at_bytes + joff + 8);
+                P = p2_mfma(p2_splat_operand(lane, ge.x, ge.y, ge.z, ge.w, cl.x, cl.y, hx, hy), pix);
+            }
 #pragma unroll
-            for (int u = 0; u < SLOTS; u++) {
-                const uint32_t joff = (u & 1) ? (wv[u >> 1] >> 16) : (wv[u >> 1] & 0xffffu);
-#ifdef CGS_X_NOLDS
-                const float jf = __uint_as_float(joff | 0x3f800000u);
-                const float4 a = make_float4(X0 + jf, Y0 + jf, -0.01f, 0.001f);
-                const float4 b = make_float4(-0.01f, 0.6f, 1.0f, jf);
-#else
-                const float4 a = *reinterpret_cast<const float4*>(sa_bytes + joff);
-#ifdef CGS_X_NOB
-                const float4 b = make_float4(a.z, 0.6f, 1.0f, 0.f);
-#elif defined(CGS_X_B32)
-                const float opv = *reinterpret_cast<const float*>(sb_bytes + joff + 4);
-                const float4 b = make_float4(a.z, opv, 1.0f, 0.f);
-#else
-                const float4 b = *reinterpret_cast<const float4*>(sb_bytes + joff);
-#endif
-#endif
-                const float dx = a.x - pixfx, dy = a.y - pixfy;
-                const float p2 = dx * (a.z * dx + a.w * dy) + b.x * dy * dy;
-#ifdef CGS_X_NOTRANS
-                const float G = fmaf(p2, 0.01f, 1.0f);
-#else
-                const float G = __builtin_amdgcn_exp2f(p2);
-#endif
-                const float alpha = fminf(0.99f, b.y * G);
-                const bool active = (joff >= jmin_off) && !(alpha < ALPHA_MIN);
-                float v_g = 0.f, v_c = 0.f, v_invd = 0.f, v_m0 = 0.f, v_m1 = 0.f, v_m2 = 0.f, v_m3 = 0.f;
-                if (active) {
-#ifdef CGS_X_NOTRANS
-                    const float rcp_1ma = 1.f + alpha;
-#else
-                    const float rcp_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-#endif
-                    float dL_dalpha;
-                    if (!INVD && !GEO) {
-                        Tp = Tp * rcp_1ma;
-                        const float d_c = b.z - accum_rec;
-                        accum_rec = fmaf(alpha, d_c, accum_rec);
-                        if (COLG) v_c = alpha * Tp;
-                        dL_dalpha = fmaf(nTf_bg, rcp_1ma, d_c * Tp);
-                    } else {
-                        T = T * rcp_1ma;
-                        const float dchannel_dcolor = alpha * T;
-                        const float d_c = b.z - accum_rec;
-                        accum_rec = fmaf(alpha, d_c, accum_rec);
-                        float sum = d_c * dL_dpixel;
-                        if (COLG) v_c = dchannel_dcolor * dL_dpixel;
-                        if (INVD) {
-                            const float d_i = b.w - accum_invd;
-                            accum_invd = fmaf(alpha, d_i, accum_invd);
-                            sum = fmaf(d_i, dL_invd, sum);
-                            v_invd = dchannel_dcolor * dL_invd;
+            for (int half = 0; half < 2; half++) {
+                const int k0 = g0 + half * SLOTS;
+                if (k0 < n) {   // wave-uniform
+                    const uint4 w4 = *reinterpret_cast<const uint4*>(list + k0);   // eight offsets, same address in every lane
+                    const uint32_t wv[4] = {w4.x, w4.y, w4.z, w4.w};
+                    float t_c = 0.f, t_invd = 0.f, t_m0 = 0.f, t_m1 = 0.f, t_m2 = 0.f, t_m3 = 0.f;
+#pragma unroll
+                    for (int u = 0; u < SLOTS; u++) {
+                        const uint32_t joff = (u & 1) ? (wv[u >> 1] >> 16) : (wv[u >> 1] & 0xffffu);
+                        const float alpha_u = __builtin_amdgcn_exp2f(P[half * SLOTS + u]);
+                        const float alpha = fminf(0.99f, alpha_u);
+                        const bool active = (joff >= jmin_off) && !(alpha < ALPHA_MIN);
+                        float v_g = 0.f, v_c = 0.f, v_invd = 0.f, v_m0 = 0.f, v_m1 = 0.f, v_m2 = 0.f, v_m3 = 0.f;
+                        if (active) {
+                            // The reference keeps (last_alpha, last_colour) and folds them into the "colour behind"
+                            // accumulator at the start of the next step (backward.cu:605,620,631); folding right after use
+                            // is the same recurrence -- acc' = acc + alpha (c - acc) -- with one fma per channel.
+                            const float rcp_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                            const float colour = *reinterpret_cast<const float*>(at_bytes + joff);
+                            float dL_dalpha;
+                            if (!INVD && !GEO) {   // one channel: carry Tp = T dL/dpixel instead of T
+                                Tp = Tp * rcp_1ma;
+                                const float d_c = colour - accum_rec;
+                                accum_rec = fmaf(alpha, d_c, accum_rec);
+                                if (COLG) v_c = alpha * Tp;
+                                dL_dalpha = fmaf(nTf_bg, rcp_1ma, d_c * Tp);
+                            } else {
+                                T = T * rcp_1ma;
+                                const float dchannel_dcolor = alpha * T;
+                                const float d_c = colour - accum_rec;
+                                accum_rec = fmaf(alpha, d_c, accum_rec);
+                                float sum = d_c * dL_dpixel;
+                                if (COLG) v_c = dchannel_dcolor * dL_dpixel;
+                                if (INVD) {
+                                    const float d_i = *reinterpret_cast<const float*>(at_bytes + joff + 4) - accum_invd;
+                                    accum_invd = fmaf(alpha, d_i, accum_invd);
+                                    sum = fmaf(d_i, dL_invd, sum);
+                                    v_invd = dchannel_dcolor * dL_invd;
+                                }
+                                if (GEO) {
+                                    const float4 cm = *reinterpret_cast<const float4*>(c_bytes + joff);
+                                    const float d0 = cm.x - accum_m0, d1 = cm.y - accum_m1, d2 = cm.z - accum_m2, d3 = cm.w - accum_m3;
+                                    accum_m0 = fmaf(alpha, d0, accum_m0); accum_m1 = fmaf(alpha, d1, accum_m1);
+                                    accum_m2 = fmaf(alpha, d2, accum_m2); accum_m3 = fmaf(alpha, d3, accum_m3);
+                                    sum = fmaf(d0, dm0, sum); sum = fmaf(d1, dm1, sum); sum = fmaf(d2, dm2, sum); sum = fmaf(d3, dm3, sum);
+                                    v_m0 = dchannel_dcolor * dm0; v_m1 = dchannel_dcolor * dm1;
+                                    v_m2 = dchannel_dcolor * dm2; v_m3 = dchannel_dcolor * dm3;
+                                }
+                                dL_dalpha = fmaf(nTf_bg, rcp_1ma, sum * T);
+                            }
+                            v_g = alpha_u * dL_dalpha;
                         }
+                        sg[u * LSTRIDE + lane] = v_g;
+                        if (COLG || INVD || GEO) {
+                            const bool mine = col == u;
+                            if (COLG) { v_c = row16_sum(v_c); t_c = mine ? v_c : t_c; }
+                            if (INVD) { v_invd = row16_sum(v_invd); t_invd = mine ? v_invd : t_invd; }
+                            if (GEO) {
+                                v_m0 = row16_sum(v_m0); v_m1 = row16_sum(v_m1); v_m2 = row16_sum(v_m2); v_m3 = row16_sum(v_m3);
+                                t_m0 = mine ? v_m0 : t_m0; t_m1 = mine ? v_m1 : t_m1;
+                                t_m2 = mine ? v_m2 : t_m2; t_m3 = mine ? v_m3 : t_m3;
+                            }
+                        }
+                    }
+                    // ---- flush the eight slots
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    float Sg, Sx, Sy, Sxx, Sxy, Syy;
+                    {
+                        const uint32_t joff = list[k0 + sl];
+                        const float2 cxy = *reinterpret_cast<const float2*>(geo_bytes + joff);
+                        const float dx0 = cxy.x - qx0, dyr = cxy.y - qyr;
+                        const float4 g0v = *reinterpret_cast<const float4*>(sg + sl * LSTRIDE + 8 * q);
+                        const float4 g1v = *reinterpret_cast<const float4*>(sg + sl * LSTRIDE + 8 * q + 4);
+                        // moments of the row's 8 values about its first pixel (weights 0..7 and 0,1,4,..49 are instruction
+                        // constants), then shifted to the splat centre: sum g (d-c) = d M0 - M1, sum g (d-c)^2 = d (d M0 - 2 M1) + M2
+                        float M0 = g0v.x + g0v.y, M1 = g0v.y, M2 = g0v.y;
+                        M0 += g0v.z; M1 = fmaf(g0v.z, 2.f, M1); M2 = fmaf(g0v.z, 4.f, M2);
+                        M0 += g0v.w; M1 = fmaf(g0v.w, 3.f, M1); M2 = fmaf(g0v.w, 9.f, M2);
+                        M0 += g1v.x; M1 = fmaf(g1v.x, 4.f, M1); M2 = fmaf(g1v.x, 16.f, M2);
+                        M0 += g1v.y; M1 = fmaf(g1v.y, 5.f, M1); M2 = fmaf(g1v.y, 25.f, M2);
+                        M0 += g1v.z; M1 = fmaf(g1v.z, 6.f, M1); M2 = fmaf(g1v.z, 36.f, M2);
+                        M0 += g1v.w; M1 = fmaf(g1v.w, 7.f, M1); M2 = fmaf(g1v.w, 49.f, M2);
+                        const float Rx = fmaf(dx0, M0, -M1);
+                        const float Rxx = fmaf(dx0, Rx - M1, M2);
+                        Sg = M0; Sx = Rx; Sxx = Rxx;
+                        Sy = dyr * M0; Sxy = dyr * Rx; Syy = (dyr * dyr) * M0;
+                    }
+                    if (COLG) t_c = rows_sum(t_c);
+                    if (INVD) t_invd = rows_sum(t_invd);
+                    if (GEO) { t_m0 = rows_sum(t_m0); t_m1 = rows_sum(t_m1); t_m2 = rows_sum(t_m2); t_m3 = rows_sum(t_m3); }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();   // every lane has read its slot row: the buffer becomes [slot][field][row]
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    {
+                        float* rp = sg + sl * LSTRIDE + q;
+                        rp[0] = Sg; rp[8] = Sx; rp[16] = Sy; rp[24] = Sxx; rp[32] = Sxy; rp[40] = Syy;
+                        if ((COLG || INVD || GEO) && lane < SLOTS) {
+                            float* xp = &s_x[g.wave][lane][0];
+                            xp[0] = COLG ? t_c : 0.f; xp[1] = INVD ? t_invd : 0.f;
+                            if (GEO) { xp[2] = t_m0; xp[3] = t_m1; xp[4] = t_m2; xp[5] = t_m3; }
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    {
+                        const uint32_t joff = list[k0 + fs];
+                        const uint32_t id = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_id) + (joff >> 2));
+                        float v = 0.f;
+                        if (ff < 6) {
+                            const float4 r0 = *reinterpret_cast<const float4*>(sg + fs * LSTRIDE + 8 * ff);
+                            const float4 r1 = *reinterpret_cast<const float4*>(sg + fs * LSTRIDE + 8 * ff + 4);
+                            v = ((r0.x + r0.y) + (r0.z + r0.w)) + ((r1.x + r1.y) + (r1.z + r1.w));
+                        } else if (COLG || INVD || GEO) {
+                            v = s_x[g.wave][fs][ff - 6];
+                        }
+                        // the 6-8 atomics of one splat hit 8 consecutive floats of its 64-byte accumulator record and
+                        // coalesce into ONE L2 request (measured 7x the rate of one field per instruction)
+                        if (v != 0.f) atomicAdd(grad_acc + (size_t)id * ACC_STRIDE + ff, v);
                         if (GEO) {
-                            const float4 cm = *reinterpret_cast<const float4*>(sc_bytes + joff);
-                            const float d0 = cm.x - accum_m0, d1 = cm.y - accum_m1, d2 = cm.z - accum_m2, d3 = cm.w - accum_m3;
-                            accum_m0 = fmaf(alpha, d0, accum_m0); accum_m1 = fmaf(alpha, d1, accum_m1);
-                            accum_m2 = fmaf(alpha, d2, accum_m2); accum_m3 = fmaf(alpha, d3, accum_m3);
-                            sum = fmaf(d0, dm0, sum); sum = fmaf(d1, dm1, sum); sum = fmaf(d2, dm2, sum); sum = fmaf(d3, dm3, sum);
-                            v_m0 = dchannel_dcolor * dm0; v_m1 = dchannel_dcolor * dm1;
-                            v_m2 = dchannel_dcolor * dm2; v_m3 = dchannel_dcolor * dm3;
+                            const float v2 = ff < 4 ? s_x[g.wave][fs][2 + ff] : 0.f;
+                            if (v2 != 0.f) atomicAdd(grad_acc + (size_t)id * ACC_STRIDE + 8 + ff, v2);
                         }
-                        dL_dalpha = fmaf(nTf_bg, rcp_1ma, sum * T);
                     }
-                    v_g = G * dL_dalpha;
-                }
-                sg[u * LSTRIDE + lane] = v_g;
-                if (COLG || INVD || GEO) {
-                    const bool mine = col == u;
-                    if (COLG) { v_c = row16_sum(v_c); t_c = mine ? v_c : t_c; }
-                    if (INVD) { v_invd = row16_sum(v_invd); t_invd = mine ? v_invd : t_invd; }
-                    if (GEO) {
-                        v_m0 = row16_sum(v_m0); v_m1 = row16_sum(v_m1); v_m2 = row16_sum(v_m2); v_m3 = row16_sum(v_m3);
-                        t_m0 = mine ? v_m0 : t_m0; t_m1 = mine ? v_m1 : t_m1;
-                        t_m2 = mine ? v_m2 : t_m2; t_m3 = mine ? v_m3 : t_m3;
-                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();   // the slot buffer may be overwritten from here on
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 }
             }
-#ifdef CGS_X_NOFLUSH
-            continue;
-#endif
-            // ---- flush the eight slots
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            float Sg, Sx, Sy, Sxx, Sxy, Syy;
-            {
-#ifdef CGS_X_PREFETCH
-                const float2 cxy = pf_cxy;
-#else
-                const uint32_t joff = list[k0 + sl];
-                const float2 cxy = *reinterpret_cast<const float2*>(sa_bytes + joff);
-#endif
-                const float dx0 = cxy.x - qx0, dyr = cxy.y - qyr;
-                const float4 g0 = *reinterpret_cast<const float4*>(sg + sl * LSTRIDE + 8 * q);
-                const float4 g1 = *reinterpret_cast<const float4*>(sg + sl * LSTRIDE + 8 * q + 4);
-                // moments of the row's 8 values about its first pixel, then shifted to the splat centre
-#ifdef CGS_X_FB
-                Sg = g0.x + g1.x; Sx = g0.y * dx0; Sxx = g0.z; Sy = g0.w * dyr; Sxy = g1.y; Syy = g1.z + g1.w;
-#else
-                float M0 = g0.x + g0.y, M1 = g0.y, M2 = g0.y;
-                M0 += g0.z; M1 = fmaf(g0.z, 2.f, M1); M2 = fmaf(g0.z, 4.f, M2);
-                M0 += g0.w; M1 = fmaf(g0.w, 3.f, M1); M2 = fmaf(g0.w, 9.f, M2);
-                M0 += g1.x; M1 = fmaf(g1.x, 4.f, M1); M2 = fmaf(g1.x, 16.f, M2);
-                M0 += g1.y; M1 = fmaf(g1.y, 5.f, M1); M2 = fmaf(g1.y, 25.f, M2);
-                M0 += g1.z; M1 = fmaf(g1.z, 6.f, M1); M2 = fmaf(g1.z, 36.f, M2);
-                M0 += g1.w; M1 = fmaf(g1.w, 7.f, M1); M2 = fmaf(g1.w, 49.f, M2);
-                const float Rx = fmaf(dx0, M0, -M1);
-                const float Rxx = fmaf(dx0, Rx - M1, M2);
-                Sg = M0; Sx = Rx; Sxx = Rxx;
-                Sy = dyr * M0; Sxy = dyr * Rx; Syy = (dyr * dyr) * M0;
-#endif
-            }
-            if (COLG) t_c = rows_sum(t_c);
-            if (INVD) t_invd = rows_sum(t_invd);
-            if (GEO) { t_m0 = rows_sum(t_m0); t_m1 = rows_sum(t_m1); t_m2 = rows_sum(t_m2); t_m3 = rows_sum(t_m3); }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();   // every lane has read its slot row: the buffer becomes [slot][field][row]
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#ifdef CGS_X_FC
-            if (Sg == 1.2345e-33f) sg[lane] = Sg + Sx + Sy + Sxx + Sxy + Syy;
-            continue;
-#endif
-            {
-#ifdef CGS_X_FD
-                float* rp = sg + lane;   // [field][lane]: contiguous, conflict-free
-                rp[0] = Sg; rp[72] = Sx; rp[144] = Sy; rp[216] = Sxx; rp[288] = Sxy; rp[360] = Syy;
-#else
-                float* rp = sg + sl * LSTRIDE + q;
-                rp[0] = Sg; rp[8] = Sx; rp[16] = Sy; rp[24] = Sxx; rp[32] = Sxy; rp[40] = Syy;
-#endif
-                if ((COLG || INVD || GEO) && lane < SLOTS) {
-                    float* xp = &s_x[g.wave][lane][0];
-                    xp[0] = COLG ? t_c : 0.f; xp[1] = INVD ? t_invd : 0.f;
-                    if (GEO) { xp[2] = t_m0; xp[3] = t_m1; xp[4] = t_m2; xp[5] = t_m3; }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#ifdef CGS_X_FA
-            continue;
-#endif
-            {
-#ifdef CGS_X_PREFETCH
-                const uint32_t id = pf_id;
-#else
-                const uint32_t joff = list[k0 + fs];
-                const uint32_t id = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_id) + (joff >> 2));
-#endif
-                float v = 0.f;
-                if (ff < 6) {
-#ifdef CGS_X_FD
-                    const float* rr = sg + ff * 72 + fs;   // lane of (slot fs, row r) is fs + 8 r
-                    v = ((rr[0] + rr[8]) + (rr[16] + rr[24])) + ((rr[32] + rr[40]) + (rr[48] + rr[56]));
-#else
-                    const float4 r0 = *reinterpret_cast<const float4*>(sg + fs * LSTRIDE + 8 * ff);
-                    const float4 r1 = *reinterpret_cast<const float4*>(sg + fs * LSTRIDE + 8 * ff + 4);
-                    v = ((r0.x + r0.y) + (r0.z + r0.w)) + ((r1.x + r1.y) + (r1.z + r1.w));
-#endif
-                } else if (COLG || INVD || GEO) {
-                    v = s_x[g.wave][fs][ff - 6];
-                }
-#ifdef CGS_X_NOATOMIC
-                if (v == 1.2345e-33f) grad_acc[(size_t)id * ACC_STRIDE + ff] = v;
-#elif defined(CGS_X_PLAINSTORE)
-                if (v != 0.f) grad_acc[(size_t)id * ACC_STRIDE + ff] = v;
-#else
-                if (v != 0.f) atomicAdd(grad_acc + (size_t)id * ACC_STRIDE + ff, v);
-#endif
-                if (GEO) {
-                    const float v2 = ff < 4 ? s_x[g.wave][fs][2 + ff] : 0.f;
-                    if (v2 != 0.f) atomicAdd(grad_acc + (size_t)id * ACC_STRIDE + 8 + ff, v2);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();   // the slot buffer may be overwritten from here on
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
-    (void)NF;
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -1228,21 +934,8 @@ void launch_render_bwd(hipStream_t s, bool geo, bool invd, bool colg, int tiles,
                        const SplatRec* rec, const float* final_Ts, const uint32_t* n_contrib, const float* dL_dpixels,
                        const float* dL_dout_invdepth, const float* dL_dout_all_map, float* grad_acc) {
     ProfScope p("render_bwd", s);
-    static const bool v1 = getenv("CGS_BWD_V1") && getenv("CGS_BWD_V1")[0] == '1';   // A/B: the round-1 kernel
-    if (!v1) {
-#define CGS_BWD2(G, I, C)                                                                                        \
-    hipLaunchKernelGGL((k_render_bwd2<G, I, C>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H, grid_x, \
-                       bg_color, rec, final_Ts, n_contrib, dL_dpixels, dL_dout_invdepth, dL_dout_all_map, grad_acc)
-        if (geo && invd) CGS_BWD2(true, true, true);
-        else if (geo) CGS_BWD2(true, false, true);
-        else if (invd) CGS_BWD2(false, true, true);
-        else if (colg) CGS_BWD2(false, false, true);
-        else CGS_BWD2(false, false, false);
-#undef CGS_BWD2
-        return;
-    }
-#define CGS_BWD(G, I, C)                                                                                        \
-    hipLaunchKernelGGL((k_render_bwd<G, I, C>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H, grid_x, \
+#define CGS_BWD(G, I, C)                                                                                         \
+    hipLaunchKernelGGL((k_render_bwd3<G, I, C>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H, grid_x, \
                        bg_color, rec, final_Ts, n_contrib, dL_dpixels, dL_dout_invdepth, dL_dout_all_map, grad_acc)
     if (geo && invd) CGS_BWD(true, true, true);        // full-gradient configuration
     else if (geo) CGS_BWD(true, false, true);

@@ -81,7 +81,8 @@ struct SplatGrads {                  // backward result for one splat (all zero 
     float4 drot;                     // raw quaternion gradient (no normalisation Jacobian, backward.cu:391)
 };
 
-// acc0 = {Sg, Sx, Sy, Sxx}, acc1 = {Sxy, Syy, dL/dcolour, dL/dinvdepth}: the compositor's raw per-splat sums
+// acc0 = {Sg, Sx, Sy, Sxx}, acc1 = {Sxy, Syy, dL/dcolour, dL/dinvdepth}: the compositor's raw per-splat sums of
+// g = opacity G dL/dalpha and its first and second moments
 // (common.h, ACC_* layout).  `has_scale`: cov3D came from (sc, q) and their gradients are wanted.
 __device__ __forceinline__ void splat_backward(const float4 acc0, const float4 acc1, bool vis, const float4 ra,
                                                const float4 rb, const float3 mean, const float cov3D[6], const float3 sc,
@@ -96,12 +97,15 @@ __device__ __forceinline__ void splat_backward(const float4 acc0, const float4 a
     o.drot = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!vis) return;
     {
+        // the sums carry the opacity already (g = opacity G dL/dalpha): dL/dG = opacity dL/dalpha of backward.cu:655 is
+        // folded in, and dL/dopacity = sum G dL/dalpha (backward.cu:672) is the opacity-scaled sum divided back once
         const float cA = ra.z, cB = ra.w, cC = rb.x, op = rb.y;
-        o.g2x = -op * (cA * acc0.y + cB * acc0.z) * (float)(0.5 * v.W);  // backward.cu:542-543, 659-664
-        o.g2y = -op * (cC * acc0.z + cB * acc0.y) * (float)(0.5 * v.H);
-        o.dcx = -0.5f * op * acc0.w;                                     // backward.cu:667-669
-        o.dcy = -0.5f * op * acc1.x;
-        o.dcz = -0.5f * op * acc1.y;
+        o.g2x = -(cA * acc0.y + cB * acc0.z) * (float)(0.5 * v.W);  // backward.cu:542-543, 659-664
+        o.g2y = -(cC * acc0.z + cB * acc0.y) * (float)(0.5 * v.H);
+        o.dcx = -0.5f * acc0.w;                                     // backward.cu:667-669
+        o.dcy = -0.5f * acc1.x;
+        o.dcz = -0.5f * acc1.y;
+        o.dopac = op > 0.f ? acc0.x / op : 0.f;
     }
     const float dcx = o.dcx, dcy = o.dcy, dcz = o.dcz;
     float3 t, cov;
