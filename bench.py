@@ -277,7 +277,9 @@ def main():
     view_graphs = None
     direct_bufs = []
     overflow_acc = torch.zeros(1, dtype=torch.int32, device=dev)
-    if args.mode == "view" and not args.no_graph:
+    cap = 0
+    eager_direct = None   # [set][stream] -> body: the fused direct body launched eagerly (--no-graph without --autograd-view)
+    if args.mode == "view":
         import ctypes
         from curve_gaussian_amd.view_parallel import StaticCamera, capture_graph
         longest = 1
@@ -288,8 +290,14 @@ def main():
                 lib.cgs_last_forward_stats(None, ctypes.byref(mlen), None)
                 longest = max(longest, int(mlen.value))
         cap = (int(longest * 1.5) + 64 + 63) // 64 * 64
+        if cap > int(lib.cgs_bucket_capacity_limit()):
+            cap = 0
+    if args.mode == "view" and args.no_graph and not args.autograd_view and cap:
+        eager_direct = [[make_direct_view(flat_sets[q][si], cap) for si in range(vstreams.n)] for q in range(n_sets)]
+        direct_bufs.extend(d for row in eager_direct for _, d in row)
+    if args.mode == "view" and not args.no_graph:
         try:
-            if cap > int(lib.cgs_bucket_capacity_limit()):
+            if not cap:
                 raise RuntimeError(f'tile lists of {longest} entries exceed the bucket limit')
             packs = {id(c): StaticCamera.packed(c) for c in my_cams}
             view_graphs = []      # [set][stream] -> (graph, its static camera, its stream)
@@ -363,6 +371,8 @@ def main():
                 elif collect and prof_direct[0] is not None:   # per-kernel timing of the headline (fused direct) body
                     prof_direct[0](cam)
                     stats["visible"] += int((prof_direct[1]["radii"] > 0).sum())
+                elif eager_direct is not None and not collect:
+                    vstreams.run(j, eager_direct[q][j % vstreams.n][0], cam)
                 else:
                     vstreams.run(j, step_view, cam, leaves[j % vstreams.n], collect)
             vstreams.join()     # (events only: the main stream waits, the view streams run on into the next step)
@@ -380,7 +390,7 @@ def main():
         torch.cuda.synchronize()
 
     prof_direct = [None, None]
-    if view_graphs is not None and not args.autograd_view:
+    if cap and not args.autograd_view and args.mode == "view":
         prof_direct = list(make_direct_view(torch.zeros_like(flat_grads), cap))
 
     use_graphs = [view_graphs is not None]
@@ -557,7 +567,7 @@ def main():
                    "instances_per_view_R": round(R_mean, 1), "visible_per_view": round(vis_mean, 1),
                    "step": f"{G} view(s) per rank, gradients summed" + (", one RCCL all-reduce" if world > 1 else ""),
                    "views_per_rank": views_timed, "views_per_step_per_rank": G, "views_in_flight_per_gpu": vstreams.n,
-                   "launch": ("hipGraph replay per view (" + ("autograd body" if args.autograd_view else "fused direct body: cgs_view_forward / cgs_view_backward") + ")") if use_graphs[0] else "eager",
+                   "launch": ("hipGraph replay per view" if use_graphs[0] else "eager launches") + " (" + ("autograd body: drop-in Python API" if args.autograd_view or (not use_graphs[0] and eager_direct is None) else "fused direct body: cgs_view_forward / cgs_view_backward") + ")",
                    "step_boundary": "double-buffered gradient sets (reduction/all-reduce of step s overlaps the views of "
                                     "step s+1)" if n_sets > 1 else "join per step",
                    "parallelism": f"view-parallel x{world}"},

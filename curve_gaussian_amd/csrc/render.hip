@@ -621,7 +621,14 @@ __device__ __forceinline__ float rows_sum2(float a, float b) {     // -> [a, b, 
 //     per PIXEL pair, backward.cu:613-672);
 //   * the "power > 0" skip (backward.cu:583-585) is not evaluated: for a positive-definite conic it can only fire on
 //     rounding noise at pixels where G = 1 to 1e-6 (deviations).
-constexpr int LSTRIDE = 68;   // floats per slot row: 64 pixels + 4 (16-byte aligned rows; (slot * 68 + x) % 32 banks spread)
+// LDS layouts of the per-wave slot buffer, bank-conflict free for the flush (searched by brute force over strides and row
+// pads against the ds_read_b128 lane groups of MI355X_MICROARCH.md; the plain 8-floats-per-row layout cost 25 % of the
+// kernel's LDS cycles in conflicts):
+//   g values:  slot u, pixel (x, row q)  at  u * SSTRIDE + slot_row(q) + x      (rows 8 floats, 4 floats of pad after rows 1, 5)
+//   row sums:  slot s, field f, row q    at  s * LSTRIDE + sum_field(f) + q     (4 floats of pad after field 3)
+constexpr int SSTRIDE = 80, LSTRIDE = 68;
+__device__ __forceinline__ int slot_row(int q) { return 8 * q + 4 * (q >= 2) + 4 * (q >= 6); }
+__device__ __forceinline__ int sum_field(int f) { return 8 * f + 4 * (f >= 4); }
 
 template <bool GEO, bool INVD, bool COLG>
 __global__ void __launch_bounds__(256, CGS_BWD3_WAVES) k_render_bwd3(
@@ -637,7 +644,7 @@ __global__ void __launch_bounds__(256, CGS_BWD3_WAVES) k_render_bwd3(
     __shared__ uint32_t s_id[BATCH + 2];
     __shared__ uint64_t s_qmask[4][4];
     __shared__ __attribute__((aligned(16))) uint16_t s_list[4][BATCH + GROUP];   // per wave: 16 * (staged index + 1)
-    __shared__ __attribute__((aligned(16))) float s_g[4][SLOTS * LSTRIDE];       // per wave: g of 8 slots x 64 pixels; then the row sums
+    __shared__ __attribute__((aligned(16))) float s_g[4][SLOTS * SSTRIDE];       // per wave: g of 8 slots x 64 pixels; then the row sums
     __shared__ float s_x[4][SLOTS][8];                                           // per wave: colour / inv-depth / all_map sums per slot
     const TileGeom g = tile_geom(W, H, grid_x);
     const int lane = g.lane;
@@ -693,6 +700,7 @@ __global__ void __launch_bounds__(256, CGS_BWD3_WAVES) k_render_bwd3(
     const int sl = lane & (SLOTS - 1), q = lane >> 3;
     const int fs = lane >> 3, ff = lane & 7;
     const float qyr = (float)(g.ty * TILE + ((g.wave >> 1) << 3) + q);
+    const int pix_off = slot_row(lane >> 3) + (lane & 7);   // where this lane's pixel sits inside a slot
 
     for (int i = 0; i < rounds; i++) {
         if (i > 0) __syncthreads();  // every wave is done with the previous batch's staged data
@@ -800,7 +808,7 @@ __global__ void __launch_bounds__(256, CGS_BWD3_WAVES) k_render_bwd3(
                             }
                             v_g = alpha_u * dL_dalpha;
                         }
-                        sg[u * LSTRIDE + lane] = v_g;
+                        sg[u * SSTRIDE + pix_off] = v_g;
                         if (COLG || INVD || GEO) {
                             const bool mine = col == u;
                             if (COLG) { v_c = row16_sum(v_c); t_c = mine ? v_c : t_c; }
@@ -821,8 +829,8 @@ __global__ void __launch_bounds__(256, CGS_BWD3_WAVES) k_render_bwd3(
                         const uint32_t joff = list[k0 + sl];
                         const float2 cxy = *reinterpret_cast<const float2*>(geo_bytes + joff);
                         const float dx0 = cxy.x - qx0, dyr = cxy.y - qyr;
-                        const float4 g0v = *reinterpret_cast<const float4*>(sg + sl * LSTRIDE + 8 * q);
-                        const float4 g1v = *reinterpret_cast<const float4*>(sg + sl * LSTRIDE + 8 * q + 4);
+                        const float4 g0v = *reinterpret_cast<const float4*>(sg + sl * SSTRIDE + slot_row(q));
+                        const float4 g1v = *reinterpret_cast<const float4*>(sg + sl * SSTRIDE + slot_row(q) + 4);
                         // moments of the row's 8 values about its first pixel (weights 0..7 and 0,1,4,..49 are instruction
                         // constants), then shifted to the splat centre: sum g (d-c) = d M0 - M1, sum g (d-c)^2 = d (d M0 - 2 M1) + M2
                         float M0 = g0v.x + g0v.y, M1 = g0v.y, M2 = g0v.y;
@@ -845,7 +853,8 @@ __global__ void __launch_bounds__(256, CGS_BWD3_WAVES) k_render_bwd3(
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     {
                         float* rp = sg + sl * LSTRIDE + q;
-                        rp[0] = Sg; rp[8] = Sx; rp[16] = Sy; rp[24] = Sxx; rp[32] = Sxy; rp[40] = Syy;
+                        rp[sum_field(0)] = Sg; rp[sum_field(1)] = Sx; rp[sum_field(2)] = Sy;
+                        rp[sum_field(3)] = Sxx; rp[sum_field(4)] = Sxy; rp[sum_field(5)] = Syy;
                         if ((COLG || INVD || GEO) && lane < SLOTS) {
                             float* xp = &s_x[g.wave][lane][0];
                             xp[0] = COLG ? t_c : 0.f; xp[1] = INVD ? t_invd : 0.f;
@@ -860,8 +869,8 @@ __global__ void __launch_bounds__(256, CGS_BWD3_WAVES) k_render_bwd3(
                         const uint32_t id = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_id) + (joff >> 2));
                         float v = 0.f;
                         if (ff < 6) {
-                            const float4 r0 = *reinterpret_cast<const float4*>(sg + fs * LSTRIDE + 8 * ff);
-                            const float4 r1 = *reinterpret_cast<const float4*>(sg + fs * LSTRIDE + 8 * ff + 4);
+                            const float4 r0 = *reinterpret_cast<const float4*>(sg + fs * LSTRIDE + sum_field(ff));
+                            const float4 r1 = *reinterpret_cast<const float4*>(sg + fs * LSTRIDE + sum_field(ff) + 4);
                             v = ((r0.x + r0.y) + (r0.z + r0.w)) + ((r1.x + r1.y) + (r1.z + r1.w));
                         } else if (COLG || INVD || GEO) {
                             v = s_x[g.wave][fs][ff - 6];

@@ -9,7 +9,8 @@
 TAG=$1
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --streams 1 --views-per-step 1 --no-graph --no-cpu-baseline --no-kernel-times --no-train-step"
+# serial eager schedule of the headline body (fused direct entry points, one view at a time, no graph)
+B="python $R/bench.py --streams 1 --views-per-step 1 --no-graph --no-cpu-baseline --no-kernel-times --no-train-step --min-seconds 0"
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $B --steps 16 --warmup 2 > $O/trace.log 2>&1
@@ -19,5 +20,5 @@ rocprofv3 --pmc SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INS
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $B --steps 4 --warmup 1 > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $B --steps 4 --warmup 1 > $O/write.log 2>&1
 # the graph-replay schedule of the default bench command, kernel trace only (durations overlap across streams)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_graph -- python $R/bench.py --no-cpu-baseline --no-kernel-times --no-train-step --steps 16 --warmup 2 > $O/trace_graph.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_graph -- python $R/bench.py --no-cpu-baseline --no-kernel-times --no-train-step --steps 4 --warmup 1 --min-seconds 0 > $O/trace_graph.log 2>&1
 find $O -name "*.csv" | wc -l
