@@ -354,11 +354,20 @@ constexpr int GROUP = 16;
 #ifndef CGS_FWD3_WAVES
 #define CGS_FWD3_WAVES 6
 #endif
-// backward: 100 VGPRs unconstrained (5 waves); at 80 (6 waves, no spills) it shares SIMDs evenly with the forward when
-// several views overlap: 0.380 -> 0.366 ms per view with three views in flight
+// backward, training configuration: its 27.3 KB of LDS admit five workgroups per CU = 5 waves per SIMD, 95 VGPRs, no
+// spills (cfg3 serial 176 us, 0.358 ms per view with three views in flight).  Parking only the first 96 list positions
+// of each quadrant (24.3 KB, 6 waves, 80 VGPRs, a few spills) measures the same; the simpler variant is the default.
 #ifndef CGS_BWD3_WAVES
-#define CGS_BWD3_WAVES 6
+#define CGS_BWD3_WAVES 5
 #endif
+#ifndef CGS_BWD3_CAP
+#define CGS_BWD3_CAP 128
+#endif
+#ifndef CGS_BWD3_FLATWALK
+#define CGS_BWD3_FLATWALK 1
+#endif
+constexpr int BWD_BATCH = 128;   // splats staged per round by the backward (its LDS also holds the per-quadrant sums)
+constexpr uint32_t BWD_PAD_OFF = (BWD_BATCH + 1) * 16;
 constexpr uint32_t PAD_OFF = (BATCH + 1) * 16;   // byte offset of the padding entry in the staged arrays
 constexpr float L2_NEVER = -1000.f;   // log2 "opacity" of the padding entry: alpha = exp2(-1000) = 0
 
@@ -631,34 +640,47 @@ __device__ __forceinline__ int slot_row(int q) { return 8 * q + 4 * (q >= 2) + 4
 __device__ __forceinline__ int sum_field(int f) { return 8 * f + 4 * (f >= 4); }
 
 template <bool GEO, bool INVD, bool COLG>
-__global__ void __launch_bounds__(256, CGS_BWD3_WAVES) k_render_bwd3(
+__global__ void __launch_bounds__(256, GEO ? 2 : (INVD || COLG) ? 4 : CGS_BWD3_WAVES) k_render_bwd3(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int grid_x,
     const float* __restrict__ bg_color, const SplatRec* __restrict__ rec, const float* __restrict__ final_Ts,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
     const float* __restrict__ dL_dout_invdepth, const float* __restrict__ dL_dout_all_map,
     float* __restrict__ grad_acc) {
-    // staged entry j of the batch lives at index j + 1; index BATCH + 1 is the padding entry (alpha = 0)
-    __shared__ float4 s_geo[BATCH + 2];   // {cx, cy, A2, B2}
-    __shared__ float4 s_at[BATCH + 2];    // {colour, 1/depth, C2, log2 opacity}
-    __shared__ float4 s_c[GEO ? BATCH + 2 : 1];
-    __shared__ uint32_t s_id[BATCH + 2];
-    __shared__ uint64_t s_qmask[4][4];
-    __shared__ __attribute__((aligned(16))) uint16_t s_list[4][BATCH + GROUP];   // per wave: 16 * (staged index + 1)
-    __shared__ __attribute__((aligned(16))) float s_g[4][SLOTS * SSTRIDE];       // per wave: g of 8 slots x 64 pixels; then the row sums
-    __shared__ float s_x[4][SLOTS][8];                                           // per wave: colour / inv-depth / all_map sums per slot
+    constexpr bool EXTRA = COLG || INVD || GEO;   // sums beyond the six geometric ones
+    constexpr int NF = GEO ? 12 : EXTRA ? 8 : 6;  // fields of the packed per-splat accumulator record that can be non-zero
+    constexpr int BB = BWD_BATCH, NC = BB / 64;
+    constexpr int CAP = EXTRA ? 0 : CGS_BWD3_CAP; // list positions per wave whose sums are combined in LDS (see s_res)
+    // staged entry j of the batch lives at index j + 1; index BB + 1 is the padding entry (alpha = 0)
+    __shared__ float4 s_geo[BB + 2];   // {cx, cy, A2, B2}
+    __shared__ float4 s_at[BB + 2];    // {colour, 1/depth (INVD) or the splat id's bits, C2, log2 opacity}
+    __shared__ float4 s_c[GEO ? BB + 2 : 1];
+    __shared__ uint32_t s_id[INVD ? BB + 2 : 1];
+    __shared__ uint64_t s_qmask[4][NC];   // [quadrant][64-entry chunk]: staged entries whose ellipse reaches the quadrant
+    __shared__ uint64_t s_tmask[4][NC];   // the same, minus the entries behind everything the quadrant blended = its list
+    __shared__ __attribute__((aligned(16))) uint16_t s_list[4][BB + GROUP];   // per wave: 16 * (staged index + 1)
+    __shared__ __attribute__((aligned(16))) float s_g[4][SLOTS * SSTRIDE];    // per wave: g of 8 slots x 64 pixels; then the row sums
+    __shared__ float s_x[EXTRA ? 4 : 1][SLOTS][8];                            // per wave: colour / inv-depth / all_map sums per slot
+    // Per-(quadrant, list position) gradient sums of the batch.  The L2 executes ~20 scattered atomic requests per ns
+    // chip-wide, whatever their scope or width up to a line; one request per (quadrant, splat) pair -- 3.8 M per cfg3 view --
+    // is a 190 us floor (no-atomics experiment: 231 -> 144 us).  The four quadrant waves therefore park their sums here with
+    // plain stores (consecutive list positions = consecutive addresses), and after the batch lane (entry, field) adds the
+    // up-to-four quadrant sums of its entry -- list positions recomputed from the quadrant masks -- and issues ONE request per
+    // tile instance (1.6 M per view).  Adding in LDS with ds_add_f32 instead costs more than it saves (63 us of this kernel).
+    // List positions >= CAP (and the configurations with extra sums) keep the direct one-request-per-pair path.
+    __shared__ __attribute__((aligned(16))) float s_res[4][CAP > 0 ? CAP * NF : 1];
     const TileGeom g = tile_geom(W, H, grid_x);
     const int lane = g.lane;
     const float X0 = (float)(g.tx * TILE), Y0 = (float)(g.ty * TILE);
     const uint2 range = ranges[g.tile];
     const int total = (int)(range.y - range.x);
     if (total == 0) return;
-    const int rounds = (total + BATCH - 1) / BATCH;
+    const int rounds = (total + BB - 1) / BB;
     const size_t HW = (size_t)H * W;
     if (threadIdx.x == 0) {
-        s_geo[BATCH + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
-        s_at[BATCH + 1] = make_float4(0.f, 0.f, 0.f, L2_NEVER);
-        if (GEO) s_c[GEO ? BATCH + 1 : 0] = make_float4(0.f, 0.f, 0.f, 0.f);
-        s_id[BATCH + 1] = 0u;
+        s_geo[BB + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_at[BB + 1] = make_float4(0.f, 0.f, 0.f, L2_NEVER);
+        if (GEO) s_c[GEO ? BB + 1 : 0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (INVD) s_id[BB + 1] = 0u;
     }
 
     const float T_final = g.inside ? final_Ts[g.pix_id] : 0.f;
@@ -687,6 +709,7 @@ __global__ void __launch_bounds__(256, CGS_BWD3_WAVES) k_render_bwd3(
     const int col = lane & 15;
     uint16_t* const list = s_list[g.wave];
     float* const sg = s_g[g.wave];
+    float* const res = s_res[g.wave];
     const char* const geo_bytes = reinterpret_cast<const char*>(s_geo);
     const char* const at_bytes = reinterpret_cast<const char*>(s_at);
     const char* const c_bytes = reinterpret_cast<const char*>(s_c);
@@ -704,45 +727,48 @@ __global__ void __launch_bounds__(256, CGS_BWD3_WAVES) k_render_bwd3(
 
     for (int i = 0; i < rounds; i++) {
         if (i > 0) __syncthreads();  // every wave is done with the previous batch's staged data
-        const int progress = i * BATCH + threadIdx.x;
+        const int progress = i * BB + threadIdx.x;
         uint32_t qm = 0;
-        if (progress < total) {
+        if (threadIdx.x < BB && progress < total) {
             const uint32_t id = point_list[range.y - progress - 1];  // back to front (backward.cu:554)
             const SplatRec* r = rec + id;
             const float4 a = r->a, b = r->b;
             float4 sa, sb;
             stage_splat(a, b, sa, sb);
-            s_id[threadIdx.x + 1] = id;
+            if (INVD) s_id[threadIdx.x + 1] = id;
             s_geo[threadIdx.x + 1] = sa;
-            s_at[threadIdx.x + 1] = make_float4(sb.z, sb.w, sb.x, __builtin_amdgcn_logf(sb.y));   // v_log_f32 = log2
+            s_at[threadIdx.x + 1] = make_float4(sb.z, INVD ? sb.w : __uint_as_float(id), sb.x, __builtin_amdgcn_logf(sb.y));   // v_log_f32 = log2
             if (GEO) s_c[threadIdx.x + 1] = r->c;
             qm = quadrant_mask(a, b, r->d.z, X0, Y0);
         }
+        if (g.wave < NC) {   // (wave-uniform)
 #pragma unroll
-        for (int qq = 0; qq < 4; qq++) {
-            const uint64_t bal = ballot64((qm >> qq) & 1u);
-            if (lane == 0) s_qmask[qq][g.wave] = bal;
+            for (int qq = 0; qq < 4; qq++) {
+                const uint64_t bal = ballot64((qm >> qq) & 1u);
+                if (lane == 0) s_qmask[qq][g.wave] = bal;
+            }
         }
         __syncthreads();
-        // ---- this wave's list.  Staged index J (0..255) of batch i sits at 0-based list position
-        // total-1-(i*256+J); it can matter to this wave only if that is < wave_last  <=>  J >= first_J
-        const int first_J = total - (int)wave_last - i * BATCH;
+        // ---- this wave's list.  Staged index J (0..BB-1) of batch i sits at 0-based list position
+        // total-1-(i*BB+J); it can matter to this wave only if that is < wave_last  <=>  J >= first_J
+        const int first_J = total - (int)wave_last - i * BB;
         int n = 0;
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
+        for (int c = 0; c < NC; c++) {
             uint64_t m = uniform64(s_qmask[g.wave][c]);
             const int lo = first_J - c * 64;
             if (lo >= 64) m = 0;
             else if (lo > 0) m &= ~((1ull << lo) - 1ull);
+            if (CAP > 0 && lane == 0) s_tmask[g.wave][c] = m;
             if ((m >> lane) & 1ull) {
                 const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 list[pos] = (uint16_t)((c * 64 + lane + 1) * 16);
             }
             n += __builtin_popcountll(m);
         }
-        if (lane < GROUP) list[n + lane] = (uint16_t)PAD_OFF;
+        if (lane < GROUP) list[n + lane] = (uint16_t)BWD_PAD_OFF;
         // lane-private: staged entry J matters to this pixel iff its list position < last_contributor  <=>  J >= first_lane
-        const int first_lane = total - (int)last_contributor - i * BATCH;
+        const int first_lane = total - (int)last_contributor - i * BB;
         const uint32_t jmin_off = (uint32_t)(max(first_lane, 0) + 1) * 16u;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -762,6 +788,32 @@ __global__ void __launch_bounds__(256, CGS_BWD3_WAVES) k_render_bwd3(
                     const uint4 w4 = *reinterpret_cast<const uint4*>(list + k0);   // eight offsets, same address in every lane
                     const uint32_t wv[4] = {w4.x, w4.y, w4.z, w4.w};
                     float t_c = 0.f, t_invd = 0.f, t_m0 = 0.f, t_m1 = 0.f, t_m2 = 0.f, t_m3 = 0.f;
+                    if (CGS_BWD3_FLATWALK && !INVD && !GEO && !COLG) {
+                        // Training configuration, branch-free: the per-pair work up to the masked alpha is independent from
+                        // pair to pair (eight exp2 / rcp / colour reads in flight), only the three-instruction recurrence
+                        // (T dL/dpixel, colour behind) is sequential.  With an `if (active)` region per pair every pair paid
+                        // the full latency of its own chain -- the kernel spent half its wave cycles waiting.
+                        float al[SLOTS], au[SLOTS], rc[SLOTS], cl[SLOTS];
+#pragma unroll
+                        for (int u = 0; u < SLOTS; u++) {
+                            const uint32_t joff = (u & 1) ? (wv[u >> 1] >> 16) : (wv[u >> 1] & 0xffffu);
+                            cl[u] = *reinterpret_cast<const float*>(at_bytes + joff);
+                            au[u] = __builtin_amdgcn_exp2f(P[half * SLOTS + u]);
+                            const float a = fminf(0.99f, au[u]);
+                            const bool active = (joff >= jmin_off) && !(a < ALPHA_MIN);
+                            al[u] = active ? a : 0.f;            // inactive: 1 - alpha = 1, rcp = 1, nothing moves
+                            au[u] = active ? au[u] : 0.f;
+                            rc[u] = __builtin_amdgcn_rcpf(1.f - al[u]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < SLOTS; u++) {
+                            Tp = Tp * rc[u];
+                            const float d_c = cl[u] - accum_rec;
+                            accum_rec = fmaf(al[u], d_c, accum_rec);
+                            const float dL_dalpha = fmaf(nTf_bg, rc[u], d_c * Tp);
+                            sg[u * SSTRIDE + pix_off] = au[u] * dL_dalpha;
+                        }
+                    } else
 #pragma unroll
                     for (int u = 0; u < SLOTS; u++) {
                         const uint32_t joff = (u & 1) ? (wv[u >> 1] >> 16) : (wv[u >> 1] & 0xffffu);
@@ -855,8 +907,8 @@ __global__ void __launch_bounds__(256, CGS_BWD3_WAVES) k_render_bwd3(
                         float* rp = sg + sl * LSTRIDE + q;
                         rp[sum_field(0)] = Sg; rp[sum_field(1)] = Sx; rp[sum_field(2)] = Sy;
                         rp[sum_field(3)] = Sxx; rp[sum_field(4)] = Sxy; rp[sum_field(5)] = Syy;
-                        if ((COLG || INVD || GEO) && lane < SLOTS) {
-                            float* xp = &s_x[g.wave][lane][0];
+                        if (EXTRA && lane < SLOTS) {
+                            float* xp = &s_x[EXTRA ? g.wave : 0][lane][0];
                             xp[0] = COLG ? t_c : 0.f; xp[1] = INVD ? t_invd : 0.f;
                             if (GEO) { xp[2] = t_m0; xp[3] = t_m1; xp[4] = t_m2; xp[5] = t_m3; }
                         }
@@ -865,27 +917,68 @@ __global__ void __launch_bounds__(256, CGS_BWD3_WAVES) k_render_bwd3(
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     {
-                        const uint32_t joff = list[k0 + fs];
-                        const uint32_t id = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_id) + (joff >> 2));
                         float v = 0.f;
                         if (ff < 6) {
                             const float4 r0 = *reinterpret_cast<const float4*>(sg + fs * LSTRIDE + sum_field(ff));
                             const float4 r1 = *reinterpret_cast<const float4*>(sg + fs * LSTRIDE + sum_field(ff) + 4);
                             v = ((r0.x + r0.y) + (r0.z + r0.w)) + ((r1.x + r1.y) + (r1.z + r1.w));
-                        } else if (COLG || INVD || GEO) {
-                            v = s_x[g.wave][fs][ff - 6];
+                        } else if (EXTRA) {
+                            v = s_x[EXTRA ? g.wave : 0][fs][ff - 6];
                         }
-                        // the 6-8 atomics of one splat hit 8 consecutive floats of its 64-byte accumulator record and
-                        // coalesce into ONE L2 request (measured 7x the rate of one field per instruction)
-                        if (v != 0.f) atomicAdd(grad_acc + (size_t)id * ACC_STRIDE + ff, v);
-                        if (GEO) {
-                            const float v2 = ff < 4 ? s_x[g.wave][fs][2 + ff] : 0.f;
-                            if (v2 != 0.f) atomicAdd(grad_acc + (size_t)id * ACC_STRIDE + 8 + ff, v2);
+                        if (CAP > 0 && (CAP >= BB || k0 + SLOTS <= CAP)) {   // (wave-uniform) park: 8 slots x NF fields, consecutive
+                            if (ff < NF) res[(k0 + fs) * NF + ff] = v;
+                        } else {
+                            // the 6-8 atomics of one splat hit 8 consecutive floats of its 64-byte accumulator record and
+                            // coalesce into ONE L2 request (measured 7x the rate of one field per instruction)
+                            const uint32_t joff = list[k0 + fs];
+                            const uint32_t id = INVD ? *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_id) + (joff >> 2))
+                                                     : __float_as_uint(*reinterpret_cast<const float*>(at_bytes + joff + 4));
+                            if (v != 0.f) atomicAdd(grad_acc + (size_t)id * ACC_STRIDE + ff, v);
+                            if (GEO) {
+                                const float v2 = ff < 4 ? s_x[g.wave][fs][2 + ff] : 0.f;
+                                if (v2 != 0.f) atomicAdd(grad_acc + (size_t)id * ACC_STRIDE + 8 + ff, v2);
+                            }
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();   // the slot buffer may be overwritten from here on
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+            }
+        }
+        // ---- the batch's per-splat sums leave the workgroup: lane (entry, field) -> consecutive floats of the splat's
+        // 64-byte accumulator record = one L2 request per entry
+        if (CAP > 0) {
+            __syncthreads();
+            const int nb = min(BB, total - i * BB);
+            uint64_t tm[4][NC];
+            int base[4][NC];
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                int acc = 0;
+#pragma unroll
+                for (int c = 0; c < NC; c++) { tm[w][c] = s_tmask[w][c]; base[w][c] = acc; acc += __builtin_popcountll(tm[w][c]); }
+            }
+            const int f = (int)(threadIdx.x & 7);
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int bit = h * 32 + (int)(threadIdx.x >> 3), e = c * 64 + bit;
+                    if (e < nb && f < NF) {
+                        float v = 0.f;
+                        bool any = false;
+#pragma unroll
+                        for (int w = 0; w < 4; w++) {
+                            const uint64_t m = tm[w][c];
+                            const int pos = base[w][c] + __builtin_popcountll(m & ((1ull << bit) - 1ull));
+                            if (((m >> bit) & 1ull) && pos < CAP) { v += s_res[w][pos * NF + f]; any = true; }
+                        }
+                        if (any && v != 0.f) {
+                            const uint32_t id = __float_as_uint(s_at[e + 1].y);
+                            atomicAdd(grad_acc + (size_t)id * ACC_STRIDE + f, v);
+                        }
+                    }
                 }
             }
         }

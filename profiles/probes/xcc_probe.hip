@@ -30,13 +30,15 @@ __global__ void k_tput(float* base, uint32_t region_floats, int iters, int use_x
     }
 }
 // transposed: one wave instruction covers 8 lines x 8 consecutive floats (lane = 8*line + field)
-__global__ void k_tput_t(float* base, uint32_t region_floats, int iters) {
+template <int SCOPE>
+__global__ void k_tput_t(float* base0, uint32_t region_floats, int use_xcc_copy) {
+    float* base = base0 + (size_t)(use_xcc_copy ? xcc_id() : 0) * region_floats;
     uint32_t tid = blockIdx.x * 256 + threadIdx.x;
     uint32_t grp = tid >> 3, f = tid & 7;
     for (int it = 0; it < 8; it++) {   // each thread-group of 8 lanes handles 8 splats -> same total: 256*7/8*8 ... see host
         uint32_t h = (grp * 8 + it) * 2654435761u; h = h * 1664525u + 1013904223u;
         uint32_t slot = (h >> 8) % (region_floats / 8);
-        if (f < 7) __hip_atomic_fetch_add(base + (size_t)slot * 8 + f, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f < 7) __hip_atomic_fetch_add(base + (size_t)slot * 8 + f, 1.0f, __ATOMIC_RELAXED, SCOPE);
     }
 }
 int main() {
@@ -67,12 +69,14 @@ int main() {
             if (rep) printf("mode %d (%s): %.3f ms for %.1fM atomics => %.1f atomics/ns\n", mode, mode == 0 ? "agent scope, 1 copy" : mode == 1 ? "workgroup scope, per-XCC copies" : "agent scope, per-XCC copies", ms, 10000 * 256 * 7 / 1e6, 10000.0 * 256 * 7 / (ms * 1e6));
         }
     }
+    for (int mode = 3; mode < 5; mode++)
     for (int rep = 0; rep < 2; rep++) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k_tput_t, dim3(10000), dim3(256), 0, 0, reg, region, 1);
+        if (mode == 3) hipLaunchKernelGGL((k_tput_t<__HIP_MEMORY_SCOPE_AGENT>), dim3(10000), dim3(256), 0, 0, reg, region, 0);
+        if (mode == 4) hipLaunchKernelGGL((k_tput_t<__HIP_MEMORY_SCOPE_WORKGROUP>), dim3(10000), dim3(256), 0, 0, reg, region, 1);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        if (rep) printf("mode 3 (transposed, 8 lanes per line): %.3f ms for %.1fM atomics => %.1f atomics/ns\n", ms, 10000 * 256 * 7 / 1e6, 10000.0 * 256 * 7 / (ms * 1e6));
+        if (rep) printf("mode %d (transposed, 8 lanes per line, %s): %.3f ms for %.1fM atomics (%.2fM line requests) => %.1f atomics/ns, %.1f requests/ns\n", mode, mode == 3 ? "agent scope, 1 copy" : "workgroup scope, per-XCC copies", ms, 10000 * 256 * 7 / 1e6, 10000 * 256 / 8 / 1e6, 10000.0 * 256 * 7 / (ms * 1e6), 10000.0 * 256 / 8 / (ms * 1e6));
     }
     return 0;
 }
