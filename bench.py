@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--no-kernel-times", action="store_true")
     ap.add_argument("--no-train-step", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=6)
+    ap.add_argument("--torch-cpu-splats", type=int, default=48,
+                    help="cfg1 only: splats of the bounded sample the pure-PyTorch CPU rasterizer (oracle/torch_ref.py) is timed on")
     ap.add_argument("--streams", type=int, default=3,
                     help="view mode: independent views kept in flight per GPU (HIP streams); 1 = strictly serial views")
     ap.add_argument("--no-graph", action="store_true",
@@ -743,6 +745,29 @@ def main():
                                          "sampling + splat attributes + raster + curve-parameter gradients)",
                                "sample": f"{nv} views of the same workload (raster fwd+bwd), oracle/raster_ref.c with "
                                          f"OpenMP ({threads} threads of {cores} host cores), {tc:.1f} s"}
+        if args.config == "cfg1" and args.torch_cpu_splats > 0:
+            # SURVEY 8d / north_star: the "PyTorch-CPU raster fallback" beside the C port, on cfg1.  The reference itself has no
+            # such fallback; this is the oracle's dense pure-PyTorch differentiable restatement, whose cost is
+            # P x H x W whatever the splats' footprints, so a sample of S splats over the full image extrapolates linearly.
+            from oracle import torch_ref as TR
+            S_ = min(P, args.torch_cpu_splats)
+            torch.set_num_threads(threads)
+            cam = my_cams[0]
+            c = lambda t: t.detach().cpu()
+            leaves = [c(t)[:S_].clone().requires_grad_(True) for t in (xyz, opac, scl, rotn, colors)]
+            tp0 = time.perf_counter()
+            col_t, _, _, _ = TR.dense_render(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], c(amaps[id(cam)])[:S_],
+                                             c(cam.world_view_transform), c(cam.full_proj_transform), tanx, tany, H, W, c(bg))
+            tp1 = time.perf_counter()
+            col_t.backward(c(dL_dcolor).reshape(col_t.shape))
+            tp2 = time.perf_counter()
+            out["cpu_baseline"]["torch_cpu_fallback"] = {
+                "value": round(S_ / (tp2 - tp0) / 1e6, 8), "unit": "Msplats/s", "cores": threads,
+                "fwd_ms_per_view_extrapolated": round((tp1 - tp0) / S_ * P * 1e3, 1),
+                "bwd_ms_per_view_extrapolated": round((tp2 - tp1) / S_ * P * 1e3, 1),
+                "sample": f"{S_} of the view's {P} splats over the full {W}x{H} image, oracle/torch_ref.dense_render + autograd "
+                          f"(dense P x H x W: cost per splat does not depend on its footprint), torch.set_num_threads({threads}), "
+                          f"{tp2 - tp0:.1f} s"}
     if dist is not None:
         dist.destroy_process_group()
     try:   # RCCL writes its banner through C stdio: flush that buffer so the JSON line is the LAST line on stdout

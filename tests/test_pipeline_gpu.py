@@ -461,6 +461,71 @@ def test_fused_view_entry_points_match_the_separate_calls(regs):
                                    rtol=2e-4, atol=2e-6, err_msg=n)
 
 
+def test_view_backward_accumulate_flag_adds_to_the_gradient_buffers():
+    """cgs_view_backward(accumulate = 0) overwrites the curve-parameter gradients, accumulate = 1 adds to them (the
+    view-batch schedule of bench.py sums the views of one optimizer step in place): two accumulating calls on zeroed
+    buffers give twice one overwriting call, and an overwriting call forgets what the buffers held."""
+    import ctypes as C
+    from curve_gaussian_amd import _lib as L
+    from curve_gaussian_amd.ops import curve_sampling
+    lib = L.load()
+    gm, c, cam = _model(300, 7)
+    cam = cam.to(DEV)
+    B, m = 300, 12
+    P = B * m
+    H, W = cam.image_height, cam.image_width
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    cap = 1024
+    tfx, tfy = tanfov(cam)
+    u8 = lambda n: torch.zeros(int(n), dtype=torch.uint8, device=DEV)
+    f32 = lambda *sh: torch.zeros(*sh, dtype=torch.float32, device=DEV)
+    cp0, w0, op0 = (gm._curve_points.detach().contiguous(), gm._width.detach().contiguous(), gm._opacity.detach().contiguous())
+    isb = curve_sampling._bezier_mask(gm.is_bezier, DEV)
+    coef = curve_sampling.sample_coefficients(m, DEV)
+    norms = torch.empty(384, dtype=torch.float64, device=DEV)
+    geom, img = u8(lib.cgs_geometry_bytes(P)), u8(lib.cgs_image_bytes(W, H))
+    nbin = int(lib.cgs_binning_bytes(cap * tiles))
+    binb = u8(nbin)
+    color, invd, omap = f32(1, H, W), f32(1, H, W), f32(4, H, W)
+    radii = torch.empty(P, dtype=torch.int32, device=DEV)
+    bg = torch.zeros(3, device=DEV)
+    scratch = f32(int(lib.cgs_view_backward_scratch_floats(B, m)))
+    dimg = torch.randn(1, H, W, generator=torch.Generator().manual_seed(3)).to(DEV)
+    pt, cf = L.ptr, C.c_float
+    st = L.raw_stream(torch.device(DEV))
+    L.check(lib.cgs_view_forward(B, m, pt(cp0), pt(w0), pt(isb), pt(coef), cf(1e-8), pt(norms), pt(op0), None, cf(0.01), None,
+                                 pt(geom), pt(binb), nbin, pt(img), cap, pt(bg), W, H, pt(cam.world_view_transform),
+                                 pt(cam.full_proj_transform), pt(cam.camera_center), tfx, tfy, pt(color), pt(invd), pt(omap),
+                                 pt(radii), None, None, None, st), "cgs_view_forward")
+
+    def backward(g_cp, g_w, g_op, accumulate):
+        g_m2d = f32(P, 3)
+        L.check(lib.cgs_view_backward(B, m, pt(cp0), pt(w0), pt(isb), pt(coef), cf(1e-8), pt(norms), pt(op0), None, cf(0.01),
+                                      pt(geom), pt(binb), pt(img), pt(bg), W, H, pt(cam.world_view_transform),
+                                      pt(cam.full_proj_transform), pt(cam.camera_center), tfx, tfy, pt(radii), pt(dimg), None,
+                                      pt(g_m2d), pt(g_cp), pt(g_w), pt(g_op), None, pt(scratch), accumulate, st),
+                "cgs_view_backward")
+        torch.cuda.synchronize()
+
+    once = [f32(B, 4, 3), f32(B, 1), f32(B, 1)]
+    backward(*once, 0)
+    assert float(once[0].abs().max()) > 0
+    dirty = [f32(B, 4, 3), f32(B, 1), f32(B, 1)]
+    for t in dirty:
+        t.fill_(1e6)                        # overwritten, not added to
+    backward(*dirty, 0)
+    # float atomics in the compositor make two passes differ in the last bits, and the curve-sampling backward amplifies
+    # that (cancellation between the samples of one curve): compare in relative L2, as bench.py does for its step gradient
+    rel_l2 = lambda got, want: float((got - want).norm() / want.norm())
+    for a, b in zip(once, dirty):
+        assert rel_l2(b, a) < 1e-3
+    twice = [f32(B, 4, 3), f32(B, 1), f32(B, 1)]
+    backward(*twice, 1)
+    backward(*twice, 1)
+    for name, a, b in zip(("curve_points", "width", "opacity"), once, twice):
+        assert rel_l2(b, 2.0 * a) < 1e-3, name
+
+
 def test_graphed_train_step_crosses_the_mask_phase():
     """At densify_until_iter the iteration switches to the straight-through curve mask + mask loss (train.py:97,110-111);
     the graphed step re-captures once and keeps following the eager trajectory."""
