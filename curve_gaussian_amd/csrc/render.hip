@@ -384,7 +384,8 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
     __shared__ float4 s_at[BATCH + 2];    // {colour, 1/depth, C2, log2 opacity}
     __shared__ float4 s_c[GEO ? BATCH + 2 : 1];
     __shared__ uint64_t s_qmask[4][4];
-    __shared__ __attribute__((aligned(16))) uint16_t s_list[4][BATCH + GROUP];   // per wave: 16 * (staged index + 1)
+    __shared__ __attribute__((aligned(16))) uint32_t s_list[4][BATCH + GROUP];   // per wave: 16 * (staged index + 1); dwords: a
+                                                                                 // broadcast read hands the walk ready LDS addresses
     __shared__ uint32_t s_ord[SORT ? RANK_MAX + RANK_U : 1];
     __shared__ uint32_t s_si[SORT ? RANK_MAX : 1];
     __shared__ uint32_t s_hist[SORT ? RANK_NB : 1], s_start[SORT ? RANK_NB + 1 : 1], s_mm[8];
@@ -446,7 +447,7 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
     const int row_splat = p2_row_splat(lane);
     const float hx = X0 + (float)((g.wave & 1) << 3) + 3.5f;
     const float hy = Y0 + (float)((g.wave >> 1) << 3) + 4.f * (float)p2_row_half(lane) + 1.5f;
-    uint16_t* const list = s_list[g.wave];
+    uint32_t* const list = s_list[g.wave];
     const char* const geo_bytes = reinterpret_cast<const char*>(s_geo);
     const char* const at_bytes = reinterpret_cast<const char*>(s_at);
     const char* const c_bytes = reinterpret_cast<const char*>(s_c);
@@ -480,11 +481,11 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
             const uint64_t m = uniform64(s_qmask[g.wave][c]);
             if ((m >> lane) & 1ull) {
                 const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                list[pos] = (uint16_t)((c * 64 + lane + 1) * 16);
+                list[pos] = (uint32_t)((c * 64 + lane + 1) * 16);
             }
             n += __builtin_popcountll(m);
         }
-        if (lane < GROUP) list[n + lane] = (uint16_t)PAD_OFF;
+        if (lane < GROUP) list[n + lane] = PAD_OFF;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -500,13 +501,12 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
                 P = p2_mfma(p2_splat_operand(lane, ge.x, ge.y, ge.z, ge.w, cl.x, cl.y, hx, hy), pix);
             }
             const int cnt = min(GROUP, n - g0);
-            uint2 w4 = make_uint2(0u, 0u);   // four list offsets at a time, same in every lane
+            uint4 w4 = make_uint4(0u, 0u, 0u, 0u);   // four list offsets at a time, same in every lane
 #pragma unroll
             for (int s = 0; s < GROUP; s += 2) {
                 if (s < cnt) {                                                  // wave-uniform
-                if ((s & 3) == 0) w4 = *reinterpret_cast<const uint2*>(list + g0 + s);
-                const uint32_t wpair = (s & 2) ? w4.y : w4.x;
-                const uint32_t j0 = wpair & 0xffffu, j1 = wpair >> 16;
+                if ((s & 3) == 0) w4 = *reinterpret_cast<const uint4*>(list + g0 + s);
+                const uint32_t j0 = (s & 2) ? w4.z : w4.x, j1 = (s & 2) ? w4.w : w4.y;
                 const float2 t0 = *reinterpret_cast<const float2*>(at_bytes + j0);
                 const float2 t1 = *reinterpret_cast<const float2*>(at_bytes + j1);
                 float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
@@ -657,7 +657,7 @@ __global__ void __launch_bounds__(256, GEO ? 2 : (INVD || COLG) ? 4 : CGS_BWD3_W
     __shared__ uint32_t s_id[INVD ? BB + 2 : 1];
     __shared__ uint64_t s_qmask[4][NC];   // [quadrant][64-entry chunk]: staged entries whose ellipse reaches the quadrant
     __shared__ uint64_t s_tmask[4][NC];   // the same, minus the entries behind everything the quadrant blended = its list
-    __shared__ __attribute__((aligned(16))) uint16_t s_list[4][BB + GROUP];   // per wave: 16 * (staged index + 1)
+    __shared__ __attribute__((aligned(16))) uint32_t s_list[4][BB + GROUP];   // per wave: 16 * (staged index + 1)
     __shared__ __attribute__((aligned(16))) float s_g[4][SLOTS * SSTRIDE];    // per wave: g of 8 slots x 64 pixels; then the row sums
     __shared__ float s_x[EXTRA ? 4 : 1][SLOTS][8];                            // per wave: colour / inv-depth / all_map sums per slot
     // Per-(quadrant, list position) gradient sums of the batch.  The L2 executes ~20 scattered atomic requests per ns
@@ -686,6 +686,13 @@ __global__ void __launch_bounds__(256, GEO ? 2 : (INVD || COLG) ? 4 : CGS_BWD3_W
     const float T_final = g.inside ? final_Ts[g.pix_id] : 0.f;
     float T = T_final;
     const uint32_t last_contributor = g.inside ? n_contrib[g.pix_id] : 0u;
+    // The reference skips, per pixel, the list entries behind the last one the forward blended (backward.cu:578).  For a
+    // pixel the forward did NOT terminate early that is implied by the alpha test: the forward walked the whole list and
+    // blended exactly the entries with alpha >= 1/255 (same exponent bits here as there).  Early termination needs
+    // T (1 - alpha) < 1e-4 with alpha <= 0.99, i.e. T < 0.01: a quadrant without such a pixel needs no per-lane position
+    // test (two instructions per pair); pixels outside the image carry zero upstream gradients and add nothing.
+    const bool lane_test = ballot64(g.inside && T_final < 0.01f) != 0ull;
+    const StepConsts k = step_consts();
     // largest list position any pixel of this quadrant blended: everything behind it is skipped wave-wide
     uint32_t wave_last = last_contributor;
 #pragma unroll
@@ -707,7 +714,7 @@ __global__ void __launch_bounds__(256, GEO ? 2 : (INVD || COLG) ? 4 : CGS_BWD3_W
     const float nTf_bg = -T_final * (bg_color[0] * dL_dpixel);             // backward.cu:649-652
     float Tp = T_final * dL_dpixel;                                        // T dL/dpixel (single-channel configurations)
     const int col = lane & 15;
-    uint16_t* const list = s_list[g.wave];
+    uint32_t* const list = s_list[g.wave];
     float* const sg = s_g[g.wave];
     float* const res = s_res[g.wave];
     const char* const geo_bytes = reinterpret_cast<const char*>(s_geo);
@@ -762,11 +769,11 @@ __global__ void __launch_bounds__(256, GEO ? 2 : (INVD || COLG) ? 4 : CGS_BWD3_W
             if (CAP > 0 && lane == 0) s_tmask[g.wave][c] = m;
             if ((m >> lane) & 1ull) {
                 const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                list[pos] = (uint16_t)((c * 64 + lane + 1) * 16);
+                list[pos] = (uint32_t)((c * 64 + lane + 1) * 16);
             }
             n += __builtin_popcountll(m);
         }
-        if (lane < GROUP) list[n + lane] = (uint16_t)BWD_PAD_OFF;
+        if (lane < GROUP) list[n + lane] = BWD_PAD_OFF;
         // lane-private: staged entry J matters to this pixel iff its list position < last_contributor  <=>  J >= first_lane
         const int first_lane = total - (int)last_contributor - i * BB;
         const uint32_t jmin_off = (uint32_t)(max(first_lane, 0) + 1) * 16u;
@@ -785,24 +792,35 @@ __global__ void __launch_bounds__(256, GEO ? 2 : (INVD || COLG) ? 4 : CGS_BWD3_W
             for (int half = 0; half < 2; half++) {
                 const int k0 = g0 + half * SLOTS;
                 if (k0 < n) {   // wave-uniform
-                    const uint4 w4 = *reinterpret_cast<const uint4*>(list + k0);   // eight offsets, same address in every lane
-                    const uint32_t wv[4] = {w4.x, w4.y, w4.z, w4.w};
+                    const uint4 wa4 = *reinterpret_cast<const uint4*>(list + k0);      // eight offsets, same address in every lane
+                    const uint4 wb4 = *reinterpret_cast<const uint4*>(list + k0 + 4);
+                    const uint32_t wv[SLOTS] = {wa4.x, wa4.y, wa4.z, wa4.w, wb4.x, wb4.y, wb4.z, wb4.w};
                     float t_c = 0.f, t_invd = 0.f, t_m0 = 0.f, t_m1 = 0.f, t_m2 = 0.f, t_m3 = 0.f;
                     if (CGS_BWD3_FLATWALK && !INVD && !GEO && !COLG) {
                         // Training configuration, branch-free: the per-pair work up to the masked alpha is independent from
                         // pair to pair (eight exp2 / rcp / colour reads in flight), only the three-instruction recurrence
                         // (T dL/dpixel, colour behind) is sequential.  With an `if (active)` region per pair every pair paid
                         // the full latency of its own chain -- the kernel spent half its wave cycles waiting.
+                        // alpha < 1/255 is tested on the unclamped value (0.99 > 1/255: same outcome) so that one select
+                        // feeds both the clamped and the unclamped alpha.
                         float al[SLOTS], au[SLOTS], rc[SLOTS], cl[SLOTS];
+                        if (lane_test) {   // (wave-uniform)
+#pragma unroll
+                            for (int u = 0; u < SLOTS; u++) {
+                                const float e = __builtin_amdgcn_exp2f(P[half * SLOTS + u]);
+                                au[u] = ((wv[u] >= jmin_off) && !(e < ALPHA_MIN)) ? e : 0.f;
+                            }
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < SLOTS; u++) {
+                                const float e = __builtin_amdgcn_exp2f(P[half * SLOTS + u]);
+                                au[u] = e * sat01(fmaf(e, k.big, k.cA));           // 0 below 1/255, e otherwise (two cheap ops)
+                            }
+                        }
 #pragma unroll
                         for (int u = 0; u < SLOTS; u++) {
-                            const uint32_t joff = (u & 1) ? (wv[u >> 1] >> 16) : (wv[u >> 1] & 0xffffu);
-                            cl[u] = *reinterpret_cast<const float*>(at_bytes + joff);
-                            au[u] = __builtin_amdgcn_exp2f(P[half * SLOTS + u]);
-                            const float a = fminf(0.99f, au[u]);
-                            const bool active = (joff >= jmin_off) && !(a < ALPHA_MIN);
-                            al[u] = active ? a : 0.f;            // inactive: 1 - alpha = 1, rcp = 1, nothing moves
-                            au[u] = active ? au[u] : 0.f;
+                            cl[u] = *reinterpret_cast<const float*>(at_bytes + wv[u]);
+                            al[u] = fminf(0.99f, au[u]);            // inactive: 1 - alpha = 1, rcp = 1, nothing moves
                             rc[u] = __builtin_amdgcn_rcpf(1.f - al[u]);
                         }
 #pragma unroll
@@ -816,7 +834,7 @@ __global__ void __launch_bounds__(256, GEO ? 2 : (INVD || COLG) ? 4 : CGS_BWD3_W
                     } else
 #pragma unroll
                     for (int u = 0; u < SLOTS; u++) {
-                        const uint32_t joff = (u & 1) ? (wv[u >> 1] >> 16) : (wv[u >> 1] & 0xffffu);
+                        const uint32_t joff = wv[u];
                         const float alpha_u = __builtin_amdgcn_exp2f(P[half * SLOTS + u]);
                         const float alpha = fminf(0.99f, alpha_u);
                         const bool active = (joff >= jmin_off) && !(alpha < ALPHA_MIN);
@@ -873,6 +891,7 @@ __global__ void __launch_bounds__(256, GEO ? 2 : (INVD || COLG) ? 4 : CGS_BWD3_W
                         }
                     }
                     // ---- flush the eight slots
+                    {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -943,6 +962,7 @@ __global__ void __launch_bounds__(256, GEO ? 2 : (INVD || COLG) ? 4 : CGS_BWD3_W
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();   // the slot buffer may be overwritten from here on
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    }
                 }
             }
         }
