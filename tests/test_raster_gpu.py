@@ -17,10 +17,10 @@ DEV = "cuda:0"
 
 
 def run_hip(sp, cam, bg, grads=None, render_geo=True, antialiasing=False, scale_modifier=1.0, cov3D=None, sh=None,
-            degree=0, debug=True):
+            degree=0, debug=True, colour_grad=True):
     from curve_gaussian_amd.diff_cur_rasterization import GaussianRasterizer
     dev = torch.device(DEV)
-    ins = {k: v.to(dev).clone().requires_grad_(True) for k, v in sp.items()}
+    ins = {k: v.to(dev).clone().requires_grad_(colour_grad or k != "colors") for k, v in sp.items()}
     P = sp["means3D"].shape[0]
     m2d = torch.zeros(P, 3, device=dev, requires_grad=True)
     rast = GaussianRasterizer(hip_settings(cam, bg, dev, render_geo, antialiasing, scale_modifier, degree, debug))
@@ -81,8 +81,8 @@ def assert_radii(got, ref):
         assert (np.abs(got[bad].astype(np.int64) - ref[bad]) == 1).all() and (got[bad] > 0).all() and (ref[bad] > 0).all()
 
 
-def compare(sp, cam, bg, grads, **kw):
-    fw = oracle_forward(sp, cam, bg, **{k: v for k, v in kw.items() if k != "debug"})
+def compare(sp, cam, bg, grads, grad_outlier_frac=None, **kw):
+    fw = oracle_forward(sp, cam, bg, **{k: v for k, v in kw.items() if k not in ("debug", "colour_grad")})
     hip = run_hip(sp, cam, bg, grads, **kw)
     assert_radii(hip["radii"], fw.radii)
     assert_close("color", hip["color"], fw.color)
@@ -92,8 +92,8 @@ def compare(sp, cam, bg, grads, **kw):
         n = lambda t: None if t is None else t.numpy()
         gr = ORA.backward(fw, n(grads[0]), n(grads[1]), n(grads[2]))
         for k, v in hip["g"].items():
-            if k == "dL_dcolors" and kw.get("sh") is not None:
-                continue  # colours come from SH: the precomputed-colour input is unused
+            if k == "dL_dcolors" and (kw.get("sh") is not None or not kw.get("colour_grad", True)):
+                continue  # colours come from SH: the precomputed-colour input is unused / no colour gradient requested
             ref = gr[k]
             if k == "dL_dsh":
                 # Reference quirk 16: the kernel writes P*M floats into the head of a [P,M,3] buffer and autograd
@@ -103,7 +103,10 @@ def compare(sp, cam, bg, grads, **kw):
                 flat[:Pn * Mn] = ref.reshape(-1)
                 ref = flat.reshape(Pn, Mn, 3).sum(-1)
                 v = v.reshape(Pn, Mn)
-            assert_close(k, v, ref, abs_floor=1e-6)
+            if grad_outlier_frac is None:
+                assert_close(k, v, ref, abs_floor=1e-6)
+            else:
+                assert_close(k, v, ref, abs_floor=1e-6, outlier_frac=grad_outlier_frac)
     fw.free()
     return hip
 
@@ -529,6 +532,26 @@ def test_baseline_config_matches_oracle(cfg, P):
     assert _forward_stats()[2] == 1
     for k in ("color", "invdepth", "all_map", "radii"):
         assert np.array_equal(hip[k], again[k]), k
+
+
+@pytest.mark.parametrize("cfg,P", [("cfg2", 50004), ("cfg3", 200004), ("cfg4", 300000), ("cfg5", 1000008)])
+def test_baseline_config_training_instance_matches_oracle(cfg, P):
+    """The kernel instance a TRAINING iteration runs -- only `render` in the loss, unit colours that do not require grad
+    (gaussian_renderer/__init__.py:97; train.py:98-107) -- at full size against the CPU oracle: this is the backward
+    variant with the parked per-quadrant sums and without the per-lane position test in quadrants where no pixel
+    terminated early, which the colour-gradient instances of test_baseline_config_matches_oracle do not exercise."""
+    sp, cam = _curve_splats(cfg)
+    assert sp["means3D"].shape[0] == P
+    g = rand_grads(cam.image_height, cam.image_width, 77, which=(True, False, False))
+    # cfg5 (8 M instances, 0.5 G pixel-splat pairs): ~100 of the million splats own a pair whose alpha sits within rounding
+    # of 1/255 (or whose pixel's T sits within rounding of 1e-4) and lands on the other side of the test than in the
+    # oracle's expf arithmetic; each such flip moves that splat's gradient by a whole pixel's contribution.  Measured
+    # 1.03e-4 of the dL/dopacity elements, identical for every kernel instance and for the round-1 kernels: 2e-4 allowed.
+    compare(sp, cam, torch.zeros(3), g, debug=False, colour_grad=False, grad_outlier_frac=2e-4 if cfg == "cfg5" else None)
+    # grey background: the bg term of dL/dalpha (backward.cu:649-652) at full size.  (Not white: with unit colours the image
+    # would be sum w + T_final = 1 wherever no pixel terminated and every gradient would cancel to rounding noise.)
+    if cfg == "cfg3":
+        compare(sp, cam, torch.tensor([0.4, 0.0, 0.0]), g, debug=False, colour_grad=False)
 
 
 @pytest.mark.parametrize("cfg,P", [("cfg3", 200004), ("cfg4", 300000), ("cfg5", 1000008)])
