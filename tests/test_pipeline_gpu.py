@@ -461,69 +461,145 @@ def test_fused_view_entry_points_match_the_separate_calls(regs):
                                    rtol=2e-4, atol=2e-6, err_msg=n)
 
 
+class _ViewCalls:
+    """cgs_view_forward / cgs_view_backward through ctypes on caller-owned buffers, the way bench.py and GraphedTrainStep
+    call them (no autograd)."""
+
+    def __init__(self, cp, width, opacity, is_bezier, cam, cap):
+        import ctypes as C
+        from curve_gaussian_amd import _lib as L
+        from curve_gaussian_amd.ops import curve_sampling
+        self.L, self.C, self.lib = L, C, L.load()
+        lib = self.lib
+        self.cam = cam.to(DEV)
+        self.B, self.m = cp.shape[0], 12
+        self.P = self.B * self.m
+        self.H, self.W = cam.image_height, cam.image_width
+        tiles = ((self.W + 15) // 16) * ((self.H + 15) // 16)
+        self.cap = cap
+        self.tf = tanfov(cam)
+        u8 = lambda n: torch.zeros(int(n), dtype=torch.uint8, device=DEV)
+        self.f32 = lambda *sh: torch.zeros(*sh, dtype=torch.float32, device=DEV)
+        self.cp, self.w, self.op = (t.detach().to(DEV).contiguous() for t in (cp, width, opacity))
+        self.isb = curve_sampling._bezier_mask(is_bezier.to(DEV), DEV)
+        self.coef = curve_sampling.sample_coefficients(self.m, DEV)
+        self.norms = torch.empty(384, dtype=torch.float64, device=DEV)
+        self.geom, self.img = u8(lib.cgs_geometry_bytes(self.P)), u8(lib.cgs_image_bytes(self.W, self.H))
+        self.nbin = int(lib.cgs_binning_bytes(cap * tiles))
+        self.binb = u8(self.nbin)
+        self.color, self.invd, self.omap = self.f32(1, self.H, self.W), self.f32(1, self.H, self.W), self.f32(4, self.H, self.W)
+        self.radii = torch.empty(self.P, dtype=torch.int32, device=DEV)
+        self.bg = torch.zeros(3, device=DEV)
+        self.scratch = self.f32(int(lib.cgs_view_backward_scratch_floats(self.B, self.m)))
+        off = int(lib.cgs_image_status_offset(self.W, self.H))
+        self.status = self.img[off:off + 4 * int(lib.cgs_status_words())].view(torch.int32)
+
+    def forward(self):
+        L, lib, pt, cf, cam = self.L, self.lib, self.L.ptr, self.C.c_float, self.cam
+        st = L.raw_stream(torch.device(DEV))
+        L.check(lib.cgs_view_forward(self.B, self.m, pt(self.cp), pt(self.w), pt(self.isb), pt(self.coef), cf(1e-8),
+                                     pt(self.norms), pt(self.op), None, cf(0.01), None, pt(self.geom), pt(self.binb),
+                                     self.nbin, pt(self.img), self.cap, pt(self.bg), self.W, self.H,
+                                     pt(cam.world_view_transform), pt(cam.full_proj_transform), pt(cam.camera_center),
+                                     self.tf[0], self.tf[1], pt(self.color), pt(self.invd), pt(self.omap), pt(self.radii),
+                                     None, None, None, st), "cgs_view_forward")
+        torch.cuda.synchronize()
+        assert int(self.status[2]) == 0, "bucket overflow: raise cap"
+
+    def backward(self, dimg, g_cp, g_w, g_op, accumulate):
+        L, lib, pt, cf, cam = self.L, self.lib, self.L.ptr, self.C.c_float, self.cam
+        st = L.raw_stream(torch.device(DEV))
+        g_m2d = self.f32(self.P, 3)
+        L.check(lib.cgs_view_backward(self.B, self.m, pt(self.cp), pt(self.w), pt(self.isb), pt(self.coef), cf(1e-8),
+                                      pt(self.norms), pt(self.op), None, cf(0.01), pt(self.geom), pt(self.binb),
+                                      pt(self.img), pt(self.bg), self.W, self.H, pt(cam.world_view_transform),
+                                      pt(cam.full_proj_transform), pt(cam.camera_center), self.tf[0], self.tf[1],
+                                      pt(self.radii), pt(dimg), None, pt(g_m2d), pt(g_cp), pt(g_w), pt(g_op), None,
+                                      pt(self.scratch), accumulate, st), "cgs_view_backward")
+        torch.cuda.synchronize()
+        return g_m2d
+
+
 def test_view_backward_accumulate_flag_adds_to_the_gradient_buffers():
     """cgs_view_backward(accumulate = 0) overwrites the curve-parameter gradients, accumulate = 1 adds to them (the
     view-batch schedule of bench.py sums the views of one optimizer step in place): two accumulating calls on zeroed
     buffers give twice one overwriting call, and an overwriting call forgets what the buffers held."""
-    import ctypes as C
-    from curve_gaussian_amd import _lib as L
-    from curve_gaussian_amd.ops import curve_sampling
-    lib = L.load()
     gm, c, cam = _model(300, 7)
-    cam = cam.to(DEV)
-    B, m = 300, 12
-    P = B * m
-    H, W = cam.image_height, cam.image_width
-    tiles = ((W + 15) // 16) * ((H + 15) // 16)
-    cap = 1024
-    tfx, tfy = tanfov(cam)
-    u8 = lambda n: torch.zeros(int(n), dtype=torch.uint8, device=DEV)
-    f32 = lambda *sh: torch.zeros(*sh, dtype=torch.float32, device=DEV)
-    cp0, w0, op0 = (gm._curve_points.detach().contiguous(), gm._width.detach().contiguous(), gm._opacity.detach().contiguous())
-    isb = curve_sampling._bezier_mask(gm.is_bezier, DEV)
-    coef = curve_sampling.sample_coefficients(m, DEV)
-    norms = torch.empty(384, dtype=torch.float64, device=DEV)
-    geom, img = u8(lib.cgs_geometry_bytes(P)), u8(lib.cgs_image_bytes(W, H))
-    nbin = int(lib.cgs_binning_bytes(cap * tiles))
-    binb = u8(nbin)
-    color, invd, omap = f32(1, H, W), f32(1, H, W), f32(4, H, W)
-    radii = torch.empty(P, dtype=torch.int32, device=DEV)
-    bg = torch.zeros(3, device=DEV)
-    scratch = f32(int(lib.cgs_view_backward_scratch_floats(B, m)))
-    dimg = torch.randn(1, H, W, generator=torch.Generator().manual_seed(3)).to(DEV)
-    pt, cf = L.ptr, C.c_float
-    st = L.raw_stream(torch.device(DEV))
-    L.check(lib.cgs_view_forward(B, m, pt(cp0), pt(w0), pt(isb), pt(coef), cf(1e-8), pt(norms), pt(op0), None, cf(0.01), None,
-                                 pt(geom), pt(binb), nbin, pt(img), cap, pt(bg), W, H, pt(cam.world_view_transform),
-                                 pt(cam.full_proj_transform), pt(cam.camera_center), tfx, tfy, pt(color), pt(invd), pt(omap),
-                                 pt(radii), None, None, None, st), "cgs_view_forward")
-
-    def backward(g_cp, g_w, g_op, accumulate):
-        g_m2d = f32(P, 3)
-        L.check(lib.cgs_view_backward(B, m, pt(cp0), pt(w0), pt(isb), pt(coef), cf(1e-8), pt(norms), pt(op0), None, cf(0.01),
-                                      pt(geom), pt(binb), pt(img), pt(bg), W, H, pt(cam.world_view_transform),
-                                      pt(cam.full_proj_transform), pt(cam.camera_center), tfx, tfy, pt(radii), pt(dimg), None,
-                                      pt(g_m2d), pt(g_cp), pt(g_w), pt(g_op), None, pt(scratch), accumulate, st),
-                "cgs_view_backward")
-        torch.cuda.synchronize()
-
+    vc = _ViewCalls(gm._curve_points, gm._width, gm._opacity, gm.is_bezier, cam, 1024)
+    B, f32 = vc.B, vc.f32
+    dimg = torch.randn(1, vc.H, vc.W, generator=torch.Generator().manual_seed(3)).to(DEV)
+    vc.forward()
     once = [f32(B, 4, 3), f32(B, 1), f32(B, 1)]
-    backward(*once, 0)
+    vc.backward(dimg, *once, 0)
     assert float(once[0].abs().max()) > 0
     dirty = [f32(B, 4, 3), f32(B, 1), f32(B, 1)]
     for t in dirty:
         t.fill_(1e6)                        # overwritten, not added to
-    backward(*dirty, 0)
+    vc.backward(dimg, *dirty, 0)
     # float atomics in the compositor make two passes differ in the last bits, and the curve-sampling backward amplifies
     # that (cancellation between the samples of one curve): compare in relative L2, as bench.py does for its step gradient
     rel_l2 = lambda got, want: float((got - want).norm() / want.norm())
     for a, b in zip(once, dirty):
         assert rel_l2(b, a) < 1e-3
     twice = [f32(B, 4, 3), f32(B, 1), f32(B, 1)]
-    backward(*twice, 1)
-    backward(*twice, 1)
+    vc.backward(dimg, *twice, 1)
+    vc.backward(dimg, *twice, 1)
     for name, a, b in zip(("curve_points", "width", "opacity"), once, twice):
         assert rel_l2(b, 2.0 * a) < 1e-3, name
+
+
+@pytest.mark.parametrize("cfg", ["cfg1", "cfg3"])
+def test_view_entry_points_match_the_oracle_chain_at_full_size(cfg):
+    """The whole per-view path of a BASELINE config through its two C-ABI calls -- curve tensors in, image out; image
+    gradient in, curve-parameter gradients out -- against the chain of oracles: torch restatement of prepare_scaling_rot /
+    get_rotation / get_opacity / all_map (autograd for their backward) around the C rasterizer oracle's forward and
+    backward.  Image under the rasterizer criterion (1e-4 of max, flip budget); curve-parameter gradients in relative L2
+    (the sampling backward sums 12 samples per curve with cancellation: element-wise noise of a few 1e-4 of max from the
+    compositor's atomics order alone, see test_view_backward_accumulate_flag...)."""
+    curves, cams = S.make_config(cfg, n_views=1)
+    cam = cams[0]
+    H, W = cam.image_height, cam.image_width
+    leaves = [curves[k].clone().requires_grad_(True) for k in ("curve_points", "width", "opacity")]
+    cp, wd, op = leaves
+    xyz, rot, scl = TR.prepare_scaling_rot(cp, wd, curves["is_bezier"])
+    P = xyz.shape[0]
+    rotn = torch.nn.functional.normalize(rot)
+    opac = torch.sigmoid(op).repeat_interleave(12, 0)
+    amap = TR.build_all_map(rot.detach(), xyz.detach(), cam.camera_center, cam.world_view_transform).float().contiguous()
+    tfx, tfy = tanfov(cam)
+    n = lambda t: np.ascontiguousarray(t.detach().numpy())
+    fw = ORA.forward(np.zeros(3, np.float32), n(xyz), np.ones((P, 1), np.float32), n(opac), n(scl), n(rotn), 1.0, None,
+                     n(amap), n(cam.world_view_transform), n(cam.full_proj_transform), tfx, tfy, H, W, None, 0,
+                     n(cam.camera_center))
+    dimg = torch.randn(1, H, W, generator=torch.Generator().manual_seed(17))
+    gr = ORA.backward(fw, dimg.numpy(), None, None)
+    t = lambda a: torch.from_numpy(np.asarray(a, np.float32))
+    chain = ((xyz * t(gr["dL_dmeans3D"])).sum() + (scl * t(gr["dL_dscales"])).sum()
+             + (rotn * t(gr["dL_drotations"])).sum() + (opac * t(gr["dL_dopacity"])).sum())
+    chain.backward()
+    # ---- product
+    vc = _ViewCalls(curves["curve_points"], curves["width"], curves["opacity"], curves["is_bezier"], cam, 1024)
+    vc.forward()
+    assert_close("color", vc.color.cpu().numpy(), fw.color)
+    assert_close("all_map", vc.omap.cpu().numpy(), fw.out_all_map, outlier_frac=2e-4)
+    assert (vc.radii.cpu().numpy() == fw.radii).mean() > 0.9999
+    B = vc.B
+    g = [vc.f32(B, 4, 3), vc.f32(B, 1), vc.f32(B, 1)]
+    g_m2d = vc.backward(dimg.to(DEV), *g, 0)
+    # the rasterizer's inputs are not bit-identical on the two sides (HIP vs torch sampling arithmetic: a few ulp in
+    # means / scales / rotations), so a small fraction of the per-splat screen-space gradients moves by ~1e-3 of max --
+    # same allowance as test_render_matches_oracle_composition; the relative L2 error bounds the rest
+    want = torch.from_numpy(gr["dL_dmeans2D"])
+    assert_close("dL_dmeans2D", g_m2d.cpu().numpy(), gr["dL_dmeans2D"], abs_floor=1e-6, outlier_frac=5e-3)
+    rel = float((g_m2d.cpu() - want).norm() / want.norm())
+    print(f"{cfg}: dL_dmeans2D relative L2 {rel:.2e}")
+    assert rel < 1e-3
+    for name, got, leaf in zip(("curve_points", "width", "opacity"), g, leaves):
+        want = leaf.grad
+        rel = float((got.cpu() - want).norm() / want.norm())
+        print(f"{cfg}: dL/d{name} relative L2 {rel:.2e}")
+        assert rel < 1e-3, f"dL/d{name}: relative L2 error {rel:.2e}"
+    fw.free()
 
 
 def test_graphed_train_step_crosses_the_mask_phase():
