@@ -192,10 +192,6 @@ __device__ __forceinline__ uint2 bucket_range(const uint32_t* __restrict__ tile_
 // useful -- the bucket scatter was bound by VALU issue, not by its atomics.  Here a wave walks FOUR splats per step:
 // lane group g = lane / 16 takes the g-th pending splat, lane % 16 is the tile inside its rect (16 tiles per step and
 // group), and the per-splat constants reach the group through ds_bpermute.
-#ifndef CGS_QW_SPW
-#define CGS_QW_SPW 64
-#endif
-constexpr int QW_SPW = CGS_QW_SPW;  // splats per wave
 struct SplatWalk {                  // per-lane: this lane's own splat; fetch(): the splat of lane `src`
     uint32_t x0, y0, w, nt;
     float cx, cy, A, B, C, tau2;
@@ -247,47 +243,26 @@ __device__ __forceinline__ void quad_walk(const SplatWalk& me, int grid_x, int c
         for (uint32_t base = 0; __ballot(base < nt) != 0ull; base += 16) {
             const uint32_t t = base + (uint32_t)sub;
             bool pass = false;
-            uint32_t tile = 0;
+            uint32_t tile = 0, gx_ = 0, gy_ = 0;
             if (t < nt) {
                 const uint32_t ty = t / sp.w, tx = t - ty * sp.w;
                 const uint32_t gxx = sp.x0 + tx, gyy = sp.y0 + ty;
                 pass = !cull || tile_reach_det(sp.cx, sp.cy, sp.A, sp.B, sp.C, sp.tau2, (float)(gxx * TILE), (float)(gyy * TILE));
                 tile = gyy * (uint32_t)grid_x + gxx;
+                gx_ = gxx; gy_ = gyy;
             }
-            fn(pass, tile, ((uint64_t)sp.khi << 32) | sp.klo);
+            fn(pass, tile, ((uint64_t)sp.khi << 32) | sp.klo, gx_, gy_);
         }
     }
 }
-__global__ void __launch_bounds__(256) k_scatter_quad(int P, const int* __restrict__ radii,
-                                                      const SplatRec* __restrict__ rec, int grid_x, int grid_y,
-                                                      uint32_t* __restrict__ tile_count, uint64_t* __restrict__ keys,
-                                                      uint32_t cap, int cull) {
-    const int lane = threadIdx.x & 63;
-    const int idx = (blockIdx.x * 4 + (threadIdx.x >> 6)) * QW_SPW + lane;
-    const SplatWalk me = load_splat_walk(lane < QW_SPW, idx, P, radii, rec, grid_x, grid_y);
-    quad_walk(me, grid_x, cull, [&](bool pass, uint32_t tile, uint64_t key) {
-        if (!pass) return;
-        const uint32_t slot = atomicAdd(&tile_count[tile], 1u);
-        if (slot < cap) keys[(size_t)tile * cap + slot] = key;
-    });
-}
-
 // ---------------------------------------------------------------------------------------- grouped bucket scatter
-// With the walk out of the way the scatter is bound by its returning atomics (the L2 retires ~20-30 atomic
-// line-operations per ns chip-wide: ~50 us for 1.6 M instances).  Consecutive splats lie on the same curve and mostly
-// fall into the same few tiles, so a wave first collects the instances of its GS_SPW splats in LDS, groups them by
-// tile (rank sort on tile << 8 | position, one wave, no workgroup barrier), and then claims a RUN of slots per tile
-// with a single atomic (add = run length) and stores the run's keys to consecutive addresses.
-// Measured on cfg3 (1.64 M instances): one-splat walk 54 us, quad walk 53 us (atomic-bound), quad walk + grouping
-// 45 / 36 / 33 us for 16 / 8 (LCAP 256) / 8 (LCAP 128) splats per wave.
-#ifndef CGS_GS_SPW
-#define CGS_GS_SPW 8
-#endif
-constexpr int GS_SPW = CGS_GS_SPW;          // splats per wave
-#ifndef CGS_GS_LCAP
-#define CGS_GS_LCAP 128
-#endif
-constexpr uint32_t GS_LCAP = CGS_GS_LCAP;           // instances a wave can group (overflow takes the one-atomic-each path)
+// With the walk out of the way the scatter is bound by its returning atomics (the L2 retires ~20 atomic requests per ns
+// chip-wide: ~50 us for 1.6 M instances).  Consecutive splats lie on the same curve and mostly fall into the same few
+// tiles, so a wave first collects the instances of its GW_SPW splats in LDS, groups them by tile, claims a RUN of slots per
+// tile with a single atomic (add = run length) and stores the run's keys behind it.
+// Measured on cfg3 (1.62 M instances): one-splat walk 54 us, quad walk 53 us (atomic-bound); grouping by a per-wave rank
+// sort on tile << 8 | position (round 1) 33 us at ~600 vector instructions per wave; grouping through the window table
+// below 26 us at ~60 (cfg5: 159 -> 109 us).  4 / 16 / 32 splats per wave: 30 / 40 / 52 us.
 __device__ __forceinline__ void wave_lds_fence() {  // same-wave LDS hand-off: the LDS queue is in order per wave, so
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // only the compiler has to be kept from reordering
     __builtin_amdgcn_wave_barrier();
@@ -298,80 +273,91 @@ __device__ __forceinline__ void wave_lds_fence() {  // same-wave LDS hand-off: t
 // so a wave tends to hold eight of them: the kernel's tail (54 us at cfg4 for 165 k instances).  They are counted in
 // big_count and, when the caller passes a queue, deferred to k_scatter_big (one workgroup per splat).
 constexpr uint32_t BIG_TILES = 96;
-__global__ void __launch_bounds__(256) k_scatter_grouped(int P, const int* __restrict__ radii,
-                                                         const SplatRec* __restrict__ rec, int grid_x, int grid_y,
-                                                         uint32_t* __restrict__ tile_count, uint64_t* __restrict__ keys,
-                                                         uint32_t cap, int cull, uint32_t* __restrict__ big_count,
-                                                         uint32_t* __restrict__ big_queue, uint32_t big_cap) {
-    __shared__ uint32_t s_sk[4][GS_LCAP + RANK_U];
-    __shared__ uint64_t s_key[4][GS_LCAP];
+// The splats of a wave are neighbours on a curve, so their tiles fall into a small window of the tile grid.  A WIN x WIN table of counters in LDS, anchored at the smallest tile coordinates of the wave's rects,
+// groups the instances without sorting them: a returning LDS add hands every instance its rank inside its (wave, tile)
+// cell, one lane per non-empty cell claims the cell's run of bucket slots with ONE global atomic, and every instance stores
+// its key at run base + rank.  Instances outside the window (and beyond the list capacity) take one global atomic each.
+#ifndef CGS_GW_SPW
+#define CGS_GW_SPW 8
+#endif
+constexpr int GW_SPW = CGS_GW_SPW;
+constexpr uint32_t GW_WIN = 16, GW_CELLS = GW_WIN * GW_WIN;
+#ifndef CGS_GW_LCAP
+#define CGS_GW_LCAP 192
+#endif
+constexpr uint32_t GW_LCAP = CGS_GW_LCAP;
+__global__ void __launch_bounds__(256) k_scatter_window(int P, const int* __restrict__ radii,
+                                                        const SplatRec* __restrict__ rec, int grid_x, int grid_y,
+                                                        uint32_t* __restrict__ tile_count, uint64_t* __restrict__ keys,
+                                                        uint32_t cap, int cull, uint32_t* __restrict__ big_count,
+                                                        uint32_t* __restrict__ big_queue, uint32_t big_cap) {
+    __shared__ uint32_t s_cell[4][GW_CELLS];   // per wave: instances per window cell; then the cell's first bucket slot
+    __shared__ uint16_t s_ent[4][GW_LCAP];     // per wave and instance: cell | rank inside the cell << 8
+    __shared__ uint64_t s_key[4][GW_LCAP];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t* wsk = s_sk[wave];
+    uint32_t* wcell = s_cell[wave];
+    uint16_t* went = s_ent[wave];
     uint64_t* wkey = s_key[wave];
-    const int idx = (blockIdx.x * 4 + (int)wave) * GS_SPW + (int)lane;
-    SplatWalk me = load_splat_walk((int)lane < GS_SPW, idx, P, radii, rec, grid_x, grid_y);
+    const int idx = (blockIdx.x * 4 + (int)wave) * GW_SPW + (int)lane;
+    SplatWalk me = load_splat_walk((int)lane < GW_SPW, idx, P, radii, rec, grid_x, grid_y);
     if (me.nt > BIG_TILES) {
-        const uint32_t q = atomicAdd(big_count, 1u);       // (also the statistic that switches the queue on, see api.hip)
+        const uint32_t q = atomicAdd(big_count, 1u);
         if (big_queue && q < big_cap) {
             big_queue[q] = (uint32_t)idx;
             me.nt = 0u;                                    // handled by k_scatter_big
         }
     }
-    // ---- A: collect the (tile, key) instances of this wave's splats (cnt stays wave-uniform)
+    if (__ballot(me.nt > 0) == 0ull) return;
+    // window origin: smallest tile coordinates over the wave's rects
+    uint32_t wx0 = me.nt > 0 ? me.x0 : 0xFFFFFFFFu, wy0 = me.nt > 0 ? me.y0 : 0xFFFFFFFFu;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        wx0 = min(wx0, (uint32_t)__shfl_xor((int)wx0, off, 64));
+        wy0 = min(wy0, (uint32_t)__shfl_xor((int)wy0, off, 64));
+    }
+    wx0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wx0);
+    wy0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wy0);
+#pragma unroll
+    for (uint32_t q = 0; q < GW_CELLS / 64; q++) wcell[lane + 64 * q] = 0u;
+    wave_lds_fence();
+    // ---- A: collect the instances, rank them inside their window cell (cnt stays wave-uniform)
     uint32_t cnt = 0;
-    quad_walk(me, grid_x, cull, [&](bool pass, uint32_t tile, uint64_t key) {
-        const uint64_t bal = __ballot(pass);
+    quad_walk(me, grid_x, cull, [&](bool pass, uint32_t tile, uint64_t key, uint32_t gxx, uint32_t gyy) {
+        const uint32_t dx = gxx - wx0, dy = gyy - wy0;
+        const bool inwin = pass && dx < GW_WIN && dy < GW_WIN;
+        const uint64_t bal = __ballot(inwin);
         const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        if (pass) {
-            if (pos < GS_LCAP) {
-                wsk[pos] = (tile << 8) | pos;
-                wkey[pos] = key;
-            } else {  // list full: one atomic per instance, as in k_scatter_quad
-                const uint32_t slot = atomicAdd(&tile_count[tile], 1u);
-                if (slot < cap) keys[(size_t)tile * cap + slot] = key;
-            }
+        if (inwin && pos < GW_LCAP) {
+            const uint32_t cell = dy * GW_WIN + dx;
+            const uint32_t r = atomicAdd(&wcell[cell], 1u);          // ds_add_rtn_u32: rank inside the cell (< GW_SPW)
+            went[pos] = (uint16_t)(cell | (r << 8));
+            wkey[pos] = key;
+        } else if (pass) {  // outside the window / list full: one atomic per instance
+            const uint32_t slot = atomicAdd(&tile_count[tile], 1u);
+            if (slot < cap) keys[(size_t)tile * cap + slot] = key;
         }
         cnt += (uint32_t)__builtin_popcountll(bal);
     });
-    const uint32_t n = min(cnt, GS_LCAP);
+    const uint32_t n = min(cnt, GW_LCAP);
     if (n == 0) return;
-    // ---- B: group by tile (keys tile << 8 | position are unique: rank = sorted position)
-    if (lane < RANK_U) wsk[n + lane] = ~0u;
     wave_lds_fence();
-    uint32_t mine_sk[4], rank[4] = {0, 0, 0, 0};
-    uint64_t mine_key[4];
+    // ---- B: one atomic per non-empty cell claims its run of bucket slots
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const uint32_t i = lane + 64u * q;
-        mine_sk[q] = i < n ? wsk[i] : ~0u;
-        mine_key[q] = i < n ? wkey[i] : 0ull;
-    }
-    rank_dispatch((int)((n + 63) / 64), wsk, n, mine_sk, rank);
-    wave_lds_fence();
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const uint32_t i = lane + 64u * q;
-        if (i < n) { wsk[rank[q]] = mine_sk[q]; wkey[rank[q]] = mine_key[q]; }
+    for (uint32_t q = 0; q < GW_CELLS / 64; q++) {
+        const uint32_t cell = lane + 64 * q;
+        const uint32_t c = wcell[cell];
+        if (c) {
+            const uint32_t tile = (wy0 + cell / GW_WIN) * (uint32_t)grid_x + wx0 + cell % GW_WIN;
+            wcell[cell] = atomicAdd(&tile_count[tile], c);
+        }
     }
     wave_lds_fence();
-    // ---- C: one atomic per run of equal tiles (runs are cut at 64-entry chunk boundaries), coalesced key stores
-    for (uint32_t c0 = 0; c0 < n; c0 += 64) {
-        const uint32_t j = c0 + lane;
-        const bool valid = j < n;
-        const uint32_t tile = valid ? (wsk[j] >> 8) : 0xFFFFFFu;
-        const uint32_t prev = (uint32_t)__shfl_up((int)tile, 1, 64);
-        const bool head = valid && (lane == 0 || prev != tile);
-        const uint64_t H = __ballot(head), V = __ballot(valid);
-        const uint64_t mask_le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
-        const uint64_t below = H & mask_le;
-        const uint32_t hl = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
-        const uint64_t above = H & ~mask_le;
-        const uint32_t next = above ? (uint32_t)__builtin_ctzll(above) : (uint32_t)__builtin_popcountll(V);
-        uint32_t base = 0;
-        if (head) base = atomicAdd(&tile_count[tile], next - lane);
-        base = (uint32_t)__shfl((int)base, (int)hl, 64);
-        const uint32_t slot = base + (lane - hl);
-        if (valid && slot < cap) keys[(size_t)tile * cap + slot] = wkey[j];
+    // ---- C: every instance stores its key at run base + rank
+    for (uint32_t j = lane; j < n; j += 64) {
+        const uint32_t e = went[j], cell = e & 255u;
+        const uint32_t slot = wcell[cell] + (e >> 8);
+        const uint32_t tile = (wy0 + cell / GW_WIN) * (uint32_t)grid_x + wx0 + cell % GW_WIN;
+        if (slot < cap) keys[(size_t)tile * cap + slot] = wkey[j];
     }
 }
 
@@ -510,16 +496,11 @@ void launch_scatter_bucket(hipStream_t s, int P, const int* radii, const SplatRe
                            uint32_t* tile_count, uint64_t* keys, uint32_t cap, int cull, uint32_t* big_count,
                            uint32_t* big_queue, uint32_t big_cap) {
     ProfScope p("scatter", s);
-    if ((int64_t)grid_x * grid_y < (1 << 24)) {  // the grouping key packs the tile index into 24 bits
-        hipLaunchKernelGGL(k_scatter_grouped, dim3((P + 4 * GS_SPW - 1) / (4 * GS_SPW)), dim3(256), 0, s, P, radii, rec,
-                           grid_x, grid_y, tile_count, keys, cap, cull, big_count, big_queue, big_cap);
-        if (big_queue)
-            hipLaunchKernelGGL(k_scatter_big, dim3(512), dim3(256), 0, s, big_count, big_queue, big_cap, radii, rec, grid_x,
-                               grid_y, tile_count, keys, cap, cull);
-        return;
-    }
-    hipLaunchKernelGGL(k_scatter_quad, dim3((P + 4 * QW_SPW - 1) / (4 * QW_SPW)), dim3(256), 0, s, P, radii, rec, grid_x,
-                       grid_y, tile_count, keys, cap, cull);
+    hipLaunchKernelGGL(k_scatter_window, dim3((P + 4 * GW_SPW - 1) / (4 * GW_SPW)), dim3(256), 0, s, P, radii, rec, grid_x,
+                       grid_y, tile_count, keys, cap, cull, big_count, big_queue, big_cap);
+    if (big_queue)
+        hipLaunchKernelGGL(k_scatter_big, dim3(512), dim3(256), 0, s, big_count, big_queue, big_cap, radii, rec, grid_x,
+                           grid_y, tile_count, keys, cap, cull);
 }
 void launch_tile_sort_bucket(hipStream_t s, int tiles, const uint32_t* tile_count, uint2* ranges, uint32_t* total,
                              uint64_t* keys, uint32_t* point_list, uint32_t cap) {
