@@ -354,17 +354,16 @@ constexpr int GROUP = 16;
 #ifndef CGS_FWD3_WAVES
 #define CGS_FWD3_WAVES 6
 #endif
-// backward, training configuration: its 27.3 KB of LDS admit five workgroups per CU = 5 waves per SIMD, 95 VGPRs, no
-// spills (cfg3 serial 176 us, 0.358 ms per view with three views in flight).  Parking only the first 96 list positions
-// of each quadrant (24.3 KB, 6 waves, 80 VGPRs, a few spills) measures the same; the simpler variant is the default.
+// backward, training configuration: 6 waves per SIMD like the forward (80 VGPRs, 5 spills; 26.2 KB of LDS with the first 104
+// list positions of each quadrant parked).  Alone it runs as fast with 5 waves, 95 VGPRs and all 128 positions parked
+// (176 us); with three views in flight the matching footprints let forward and backward workgroups of neighbouring views
+// share CUs evenly: 567 -> 597 Msplats/s.  (A branch-free walk -- eight pairs' exp2 / rcp / colour reads in flight before
+// the sequential recurrence -- was 8 us faster at 5 waves, but needs 32 more live registers: 589 at 6 waves with spills.)
 #ifndef CGS_BWD3_WAVES
-#define CGS_BWD3_WAVES 5
+#define CGS_BWD3_WAVES 6
 #endif
 #ifndef CGS_BWD3_CAP
-#define CGS_BWD3_CAP 128
-#endif
-#ifndef CGS_BWD3_FLATWALK
-#define CGS_BWD3_FLATWALK 1
+#define CGS_BWD3_CAP 104
 #endif
 constexpr int BWD_BATCH = 128;   // splats staged per round by the backward (its LDS also holds the per-quadrant sums)
 constexpr uint32_t BWD_PAD_OFF = (BWD_BATCH + 1) * 16;
@@ -686,13 +685,6 @@ __global__ void __launch_bounds__(256, GEO ? 2 : (INVD || COLG) ? 4 : CGS_BWD3_W
     const float T_final = g.inside ? final_Ts[g.pix_id] : 0.f;
     float T = T_final;
     const uint32_t last_contributor = g.inside ? n_contrib[g.pix_id] : 0u;
-    // The reference skips, per pixel, the list entries behind the last one the forward blended (backward.cu:578).  For a
-    // pixel the forward did NOT terminate early that is implied by the alpha test: the forward walked the whole list and
-    // blended exactly the entries with alpha >= 1/255 (same exponent bits here as there).  Early termination needs
-    // T (1 - alpha) < 1e-4 with alpha <= 0.99, i.e. T < 0.01: a quadrant without such a pixel needs no per-lane position
-    // test (two instructions per pair); pixels outside the image carry zero upstream gradients and add nothing.
-    const bool lane_test = ballot64(g.inside && T_final < 0.01f) != 0ull;
-    const StepConsts k = step_consts();
     // largest list position any pixel of this quadrant blended: everything behind it is skipped wave-wide
     uint32_t wave_last = last_contributor;
 #pragma unroll
@@ -796,42 +788,6 @@ __global__ void __launch_bounds__(256, GEO ? 2 : (INVD || COLG) ? 4 : CGS_BWD3_W
                     const uint4 wb4 = *reinterpret_cast<const uint4*>(list + k0 + 4);
                     const uint32_t wv[SLOTS] = {wa4.x, wa4.y, wa4.z, wa4.w, wb4.x, wb4.y, wb4.z, wb4.w};
                     float t_c = 0.f, t_invd = 0.f, t_m0 = 0.f, t_m1 = 0.f, t_m2 = 0.f, t_m3 = 0.f;
-                    if (CGS_BWD3_FLATWALK && !INVD && !GEO && !COLG) {
-                        // Training configuration, branch-free: the per-pair work up to the masked alpha is independent from
-                        // pair to pair (eight exp2 / rcp / colour reads in flight), only the three-instruction recurrence
-                        // (T dL/dpixel, colour behind) is sequential.  With an `if (active)` region per pair every pair paid
-                        // the full latency of its own chain -- the kernel spent half its wave cycles waiting.
-                        // alpha < 1/255 is tested on the unclamped value (0.99 > 1/255: same outcome) so that one select
-                        // feeds both the clamped and the unclamped alpha.
-                        float al[SLOTS], au[SLOTS], rc[SLOTS], cl[SLOTS];
-                        if (lane_test) {   // (wave-uniform)
-#pragma unroll
-                            for (int u = 0; u < SLOTS; u++) {
-                                const float e = __builtin_amdgcn_exp2f(P[half * SLOTS + u]);
-                                au[u] = ((wv[u] >= jmin_off) && !(e < ALPHA_MIN)) ? e : 0.f;
-                            }
-                        } else {
-#pragma unroll
-                            for (int u = 0; u < SLOTS; u++) {
-                                const float e = __builtin_amdgcn_exp2f(P[half * SLOTS + u]);
-                                au[u] = e * sat01(fmaf(e, k.big, k.cA));           // 0 below 1/255, e otherwise (two cheap ops)
-                            }
-                        }
-#pragma unroll
-                        for (int u = 0; u < SLOTS; u++) {
-                            cl[u] = *reinterpret_cast<const float*>(at_bytes + wv[u]);
-                            al[u] = fminf(0.99f, au[u]);            // inactive: 1 - alpha = 1, rcp = 1, nothing moves
-                            rc[u] = __builtin_amdgcn_rcpf(1.f - al[u]);
-                        }
-#pragma unroll
-                        for (int u = 0; u < SLOTS; u++) {
-                            Tp = Tp * rc[u];
-                            const float d_c = cl[u] - accum_rec;
-                            accum_rec = fmaf(al[u], d_c, accum_rec);
-                            const float dL_dalpha = fmaf(nTf_bg, rc[u], d_c * Tp);
-                            sg[u * SSTRIDE + pix_off] = au[u] * dL_dalpha;
-                        }
-                    } else
 #pragma unroll
                     for (int u = 0; u < SLOTS; u++) {
                         const uint32_t joff = wv[u];

@@ -13,7 +13,7 @@ from .fused_ssim import fused_ssim
 from .gaussian_renderer import PipelineParams, render
 from .ops.losses import edge_aware_loss, photometric_loss, unit_grad
 from .ops.optim import FlatAdam
-from .view_parallel import FlatGrads, StaticCamera as _StaticCamera
+from .view_parallel import FlatGrads, StaticCamera as _StaticCamera, no_gc
 
 
 class TrainStep:
@@ -476,7 +476,7 @@ class GraphedTrainStep(TrainStep):
         # capture on the warm-up stream: the gradient accumulators created there then share the capture stream, and the
         # captured backward stays single-stream (a cross-stream AccumulateGrad inside the capture lets the allocator
         # recycle blocks the other stream still uses -- later replays then read clobbered intermediates)
-        with torch.cuda.graph(graph, stream=side):
+        with no_gc(), torch.cuda.graph(graph, stream=side):
             self._loss, self._status = self._body()
         opt.flat.copy_(snap[0]); opt.exp_avg.copy_(snap[1]); opt.exp_avg_sq.copy_(snap[2])
         opt.step_count = snap[3]

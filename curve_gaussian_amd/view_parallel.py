@@ -115,9 +115,29 @@ def capture_graph(fn, stream, warmup=2):
             fn()
     torch.cuda.current_stream().wait_stream(stream)
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=stream):
+    with no_gc(), torch.cuda.graph(graph, stream=stream):
         out = fn()
     return graph, out
+
+
+class no_gc:
+    """Keeps Python's cyclic collector from running inside a stream capture.  A collection that happens to start while the
+    stream is capturing (observed inside the autograd thread of a captured backward) finalises whatever garbage is around --
+    retired graphs, events, tensors -- and their HIP destroy / free calls are illegal during capture: the process aborts.
+    torch.cuda.graph collects once on entry; this closes the window until exit."""
+
+    def __enter__(self):
+        import gc
+        self._was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        return self
+
+    def __exit__(self, *a):
+        import gc
+        if self._was:
+            gc.enable()
+        return False
 
 
 class FlatGrads:

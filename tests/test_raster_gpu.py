@@ -538,8 +538,8 @@ def test_baseline_config_matches_oracle(cfg, P):
 def test_baseline_config_training_instance_matches_oracle(cfg, P):
     """The kernel instance a TRAINING iteration runs -- only `render` in the loss, unit colours that do not require grad
     (gaussian_renderer/__init__.py:97; train.py:98-107) -- at full size against the CPU oracle: this is the backward
-    variant with the parked per-quadrant sums and without the per-lane position test in quadrants where no pixel
-    terminated early, which the colour-gradient instances of test_baseline_config_matches_oracle do not exercise."""
+    variant with the parked per-quadrant sums, which the colour-gradient instances of
+    test_baseline_config_matches_oracle do not exercise."""
     sp, cam = _curve_splats(cfg)
     assert sp["means3D"].shape[0] == P
     g = rand_grads(cam.image_height, cam.image_width, 77, which=(True, False, False))
