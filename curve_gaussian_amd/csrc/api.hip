@@ -608,17 +608,19 @@ int cgs_view_forward(int B, int m, const float* curve_points, const float* width
                         colors_precomp, cam_pos, viewmatrix, projmatrix, tan_fovx, tan_fovy, focal_x, focal_y, width_px,
                         height_px, gx, gy, xyz, rotation, scaling, radii, geom.rec, geom.grad_acc, img.tile_count,
                         clear_bytes / sizeof(uint32_t));
+    // k_view_fwd writes unit colours (no colors_precomp) and all_map[3] = 1 itself: the compositor derives both sums from T
+    const bool unit = colors_precomp == nullptr;
     const bool defer_big = hints_load(P, width_px, height_px).big > 0;
     launch_scatter_bucket(s, P, radii, geom.rec, gx, gy, img.tile_count, bin.keys, (uint32_t)cap, 1, img.total + 3,
                           defer_big ? img.tile_cursor : nullptr, (uint32_t)tiles);
     if (render_fwd_can_sort((uint32_t)cap) && fuse_sort()) {
         launch_render_fwd_sorting(s, true, tiles, img.tile_count, bin.keys, (uint32_t)cap, img.ranges, img.total,
                                   bin.point_list, width_px, height_px, gx, geom.rec, img.final_T, img.n_contrib, background,
-                                  out_color, out_invdepth, out_all_map);
+                                  out_color, out_invdepth, out_all_map, unit);
     } else {
         launch_tile_sort_bucket(s, tiles, img.tile_count, img.ranges, img.total, bin.keys, bin.point_list, (uint32_t)cap);
         launch_render_fwd(s, true, tiles, img.ranges, bin.point_list, width_px, height_px, gx, geom.rec, img.final_T,
-                          img.n_contrib, background, out_color, out_invdepth, out_all_map);
+                          img.n_contrib, background, out_color, out_invdepth, out_all_map, unit);
     }
     if (!check_launch("view_forward", false, s)) return CGS_ERR_HIP;
     return CGS_OK;

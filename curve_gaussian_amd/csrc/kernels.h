@@ -45,12 +45,14 @@ void launch_tile_sort_big(hipStream_t s, int tiles, const uint2* ranges, uint64_
 // render.hip
 void launch_render_fwd(hipStream_t s, bool geo, int tiles, const uint2* ranges, const uint32_t* point_list, int W,
                        int H, int grid_x, const SplatRec* rec, float* final_T, uint32_t* n_contrib,
-                       const float* bg_color, float* out_color, float* out_invdepth, float* out_all_map);
+                       const float* bg_color, float* out_color, float* out_invdepth, float* out_all_map,
+                       bool unit = false);   // unit: colour == 1 and all_map[3] == 1 for every splat (render.hip, UNIT)
 bool render_fwd_can_sort(uint32_t cap);
 void launch_render_fwd_sorting(hipStream_t s, bool geo, int tiles, const uint32_t* tile_count, const uint64_t* keys,
                                uint32_t cap, uint2* ranges, uint32_t* total, uint32_t* point_list, int W, int H,
                                int grid_x, const SplatRec* rec, float* final_T, uint32_t* n_contrib,
-                               const float* bg_color, float* out_color, float* out_invdepth, float* out_all_map);
+                               const float* bg_color, float* out_color, float* out_invdepth, float* out_all_map,
+                               bool unit = false);
 void launch_render_bwd(hipStream_t s, bool geo, bool invd, bool colg, int tiles, const uint2* ranges,
                        const uint32_t* point_list, int W, int H, int grid_x, const float* bg_color,
                        const SplatRec* rec, const float* final_Ts, const uint32_t* n_contrib, const float* dL_dpixels,

@@ -370,7 +370,10 @@ constexpr uint32_t BWD_PAD_OFF = (BWD_BATCH + 1) * 16;
 constexpr uint32_t PAD_OFF = (BATCH + 1) * 16;   // byte offset of the padding entry in the staged arrays
 constexpr float L2_NEVER = -1000.f;   // log2 "opacity" of the padding entry: alpha = exp2(-1000) = 0
 
-template <bool GEO, bool SORT>
+// UNIT: the caller guarantees colour == 1 and all_map[3] == 1 for every splat (the view entry point builds both itself:
+// unit features, gaussian_renderer/__init__.py:97,104).  Then sum w c = sum w = 1 - T (w_i = T_i - T_{i+1} telescopes), and
+// the two accumulators are not carried through the walk -- two of the six fmas per pair.
+template <bool GEO, bool SORT, bool UNIT = false>
 __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2* __restrict__ ranges,
                                                      const uint32_t* __restrict__ point_list, int W, int H, int grid_x,
                                                      const SplatRec* __restrict__ rec, float* __restrict__ final_T,
@@ -538,12 +541,12 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
                     cA = (d0 || d1) ? -0x1p126f : cA;
                 }
                 Tw = T2;
-                C = fmaf(t0.x, wa, C);
+                if (!UNIT) C = fmaf(t0.x, wa, C);
                 Dacc = fmaf(t0.y, wa, Dacc);
-                if (GEO) { A0 = fmaf(c0.x, wa, A0); A1 = fmaf(c0.y, wa, A1); A2 = fmaf(c0.z, wa, A2); A3 = fmaf(c0.w, wa, A3); }
-                C = fmaf(t1.x, wb, C);
+                if (GEO) { A0 = fmaf(c0.x, wa, A0); A1 = fmaf(c0.y, wa, A1); A2 = fmaf(c0.z, wa, A2); if (!UNIT) A3 = fmaf(c0.w, wa, A3); }
+                if (!UNIT) C = fmaf(t1.x, wb, C);
                 Dacc = fmaf(t1.y, wb, Dacc);
-                if (GEO) { A0 = fmaf(c1.x, wb, A0); A1 = fmaf(c1.y, wb, A1); A2 = fmaf(c1.z, wb, A2); A3 = fmaf(c1.w, wb, A3); }
+                if (GEO) { A0 = fmaf(c1.x, wb, A0); A1 = fmaf(c1.y, wb, A1); A2 = fmaf(c1.z, wb, A2); if (!UNIT) A3 = fmaf(c1.w, wb, A3); }
                 // the offsets grow along the list and w > 0 exactly when a splat was blended (its bit pattern then
                 // exceeds any offset): the median of the three keeps the offset of the last blended splat
                 last_off = max(min(last_off, j0), min(max(last_off, j0), __float_as_uint(wa)));   // v_med3_u32
@@ -562,6 +565,7 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
         const float T = cA > -0x1p120f ? Tw : T_dead;
         final_T[g.pix_id] = T;
         n_contrib[g.pix_id] = last_contributor;
+        if (UNIT) C = A3 = 1.f - T;
         out_color[g.pix_id] = C + T * bg_color[0];
         out_invdepth[g.pix_id] = Dacc;
         if (GEO) {
@@ -964,11 +968,14 @@ __global__ void __launch_bounds__(256, GEO ? 2 : (INVD || COLG) ? 4 : CGS_BWD3_W
 // ------------------------------------------------------------------------------------------------ launchers
 void launch_render_fwd(hipStream_t s, bool geo, int tiles, const uint2* ranges, const uint32_t* point_list, int W,
                        int H, int grid_x, const SplatRec* rec, float* final_T, uint32_t* n_contrib,
-                       const float* bg_color, float* out_color, float* out_invdepth, float* out_all_map) {
+                       const float* bg_color, float* out_color, float* out_invdepth, float* out_all_map, bool unit) {
     ProfScope p("render_fwd", s);
     static const bool v2 = getenv("CGS_FWD_V2") && getenv("CGS_FWD_V2")[0] == '1';   // A/B: exponent on the vector ALU
     if (!v2) {
-        if (geo)
+        if (geo && unit)
+            hipLaunchKernelGGL((k_render_fwd3<true, false, true>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H, grid_x,
+                               rec, final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, BucketSort{});
+        else if (geo)
             hipLaunchKernelGGL((k_render_fwd3<true, false>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H, grid_x, rec,
                                final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, BucketSort{});
         else
@@ -987,12 +994,15 @@ bool render_fwd_can_sort(uint32_t cap) { return cap <= RANK_MAX; }
 void launch_render_fwd_sorting(hipStream_t s, bool geo, int tiles, const uint32_t* tile_count, const uint64_t* keys,
                                uint32_t cap, uint2* ranges, uint32_t* total, uint32_t* point_list, int W, int H,
                                int grid_x, const SplatRec* rec, float* final_T, uint32_t* n_contrib,
-                               const float* bg_color, float* out_color, float* out_invdepth, float* out_all_map) {
+                               const float* bg_color, float* out_color, float* out_invdepth, float* out_all_map, bool unit) {
     ProfScope p("render_fwd", s);
     BucketSort bs{tile_count, keys, point_list, ranges, total, cap};
     static const bool v2 = getenv("CGS_FWD_V2") && getenv("CGS_FWD_V2")[0] == '1';
     if (!v2) {
-        if (geo)
+        if (geo && unit)
+            hipLaunchKernelGGL((k_render_fwd3<true, true, true>), dim3(tiles), dim3(256), 0, s, nullptr, nullptr, W, H, grid_x, rec,
+                               final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, bs);
+        else if (geo)
             hipLaunchKernelGGL((k_render_fwd3<true, true>), dim3(tiles), dim3(256), 0, s, nullptr, nullptr, W, H, grid_x, rec,
                                final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, bs);
         else
