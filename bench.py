@@ -250,7 +250,7 @@ def main():
                                          tanx, tany, pt(d["color"]), pt(d["invd"]), pt(d["omap"]), pt(d["radii"]), None, None,
                                          None, st), "cgs_view_forward")
             L.check(lib.cgs_view_backward(B, m, pt(cp0), pt(w0), pt(isb_u8), pt(d["coef"]), cf(1e-8), pt(d["norms"]), pt(op0), None,
-                                          cf(0.01), pt(d["geom"]), pt(d["bin"]), pt(d["img"]), pt(bg), W, H,
+                                          cf(0.01), None, pt(d["geom"]), pt(d["bin"]), pt(d["img"]), pt(bg), W, H,
                                           pt(cam.world_view_transform), pt(cam.full_proj_transform), pt(cam.camera_center),
                                           tanx, tany, pt(d["radii"]), pt(dL_dcolor), None, pt(d["g_m2d"]), pt(g_cp), pt(g_w),
                                           pt(g_op), None, pt(d["scratch"]), 1, st), "cgs_view_backward")

@@ -26,7 +26,7 @@ SIGNATURES = {
     "cgs_view_forward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _vp, _vp, C.c_size_t, _vp, C.c_uint32,
                               _vp, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cgs_view_backward_scratch_floats": (C.c_size_t, [_i, _i]),
-    "cgs_view_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp,
+    "cgs_view_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp,
                                _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "cgs_image_status_offset": (C.c_size_t, [_i, _i]),
     "cgs_status_words": (_i, []),

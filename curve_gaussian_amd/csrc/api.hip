@@ -630,7 +630,7 @@ size_t cgs_view_backward_scratch_floats(int B, int m) { return (size_t)(B > 0 ? 
 
 int cgs_view_backward(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
                       float eps, double* norms, const float* opacity_logit, const float* mask_logit, float mask_thr,
-                      void* geometry_buffer, const void* binning_buffer, const void* image_buffer, const float* background,
+                      const float* colors_precomp, void* geometry_buffer, const void* binning_buffer, const void* image_buffer, const float* background,
                       int width_px, int height_px, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                       float tan_fovx, float tan_fovy, const int* radii, const float* dL_dout_color,
                       const float* dL_drotation_extra, float* dL_dmeans2D, float* dL_dcurve_points, float* dL_dwidth,
@@ -659,9 +659,10 @@ int cgs_view_backward(int B, int m, const float* curve_points, const float* widt
     float* gv = scratch;                       // [P,9] dL/d{v0,v1,v2}
     float* g_xyz = scratch + (size_t)P * 9;    // [P,3]
     float* g_scl = scratch + (size_t)P * 12;   // [P,3]
-    // training configuration: only dL/dcolour flows in, unit colours need no colour gradient
+    // training configuration: only dL/dcolour flows in, the colours themselves need no gradient; the forward wrote unit
+    // colours unless it was given colors_precomp (same argument here): closed-form dL/dalpha, no recurrences (render.hip, UNIT)
     launch_render_bwd(s, false, false, false, tiles, img.ranges, bin.point_list, width_px, height_px, gx, background, geom.rec,
-                      img.final_T, img.n_contrib, dL_dout_color, nullptr, nullptr, geom.grad_acc);
+                      img.final_T, img.n_contrib, dL_dout_color, nullptr, nullptr, geom.grad_acc, colors_precomp == nullptr);
     launch_view_backward(s, B, m, curve_points, width, is_bezier, coef, eps, norms, opacity_logit, mask_logit, mask_thr,
                          cam_pos, viewmatrix, projmatrix, tan_fovx, tan_fovy, focal_x, focal_y, width_px, height_px, radii,
                          geom.rec, geom.grad_acc, dL_drotation_extra, dL_dmeans2D, dL_dopacity_logit, dL_dmask_logit, g_xyz,

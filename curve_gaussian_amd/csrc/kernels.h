@@ -56,7 +56,8 @@ void launch_render_fwd_sorting(hipStream_t s, bool geo, int tiles, const uint32_
 void launch_render_bwd(hipStream_t s, bool geo, bool invd, bool colg, int tiles, const uint2* ranges,
                        const uint32_t* point_list, int W, int H, int grid_x, const float* bg_color,
                        const SplatRec* rec, const float* final_Ts, const uint32_t* n_contrib, const float* dL_dpixels,
-                       const float* dL_dout_invdepth, const float* dL_dout_all_map, float* grad_acc);
+                       const float* dL_dout_invdepth, const float* dL_dout_all_map, float* grad_acc,
+                       bool unit = false);   // unit: colour == 1 for every splat (render.hip, UNIT)
 
 
 // sampling.hip

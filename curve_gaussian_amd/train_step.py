@@ -383,7 +383,7 @@ class GraphedTrainStep(TrainStep):
             loss = loss + b["reg_loss"]
         chk(lib.cgs_view_backward(
             B, m, p(cp), p(wl), p(b["isb"]), p(b["coef"]), cf(1e-8), p(b["norms"]), p(ol), p(mask), cf(self.mask_threshold),
-            p(b["geom"]), p(b["bin"]), p(b["img"]), p(b["bg"]), W, H, p(cam.world_view_transform),
+            None, p(b["geom"]), p(b["bin"]), p(b["img"]), p(b["bg"]), W, H, p(cam.world_view_transform),
             p(cam.full_proj_transform), p(cam.camera_center), tanx, tany, p(b["radii"]), p(b["g_img"]), p(extra),
             p(b["g_m2d"]), p(grads.view("curve_points")), p(grads.view("width")), p(grads.view("opacity")),
             p(grads.view("mask")) if mask is not None else None, p(b["view_scratch"]), 0, s), "view_backward")

@@ -137,7 +137,8 @@ size_t cgs_binning_bytes(int64_t R);
  *   cgs_view_forward: arguments as the three calls it replaces; xyz / rotation / scaling may be NULL (all three) when the
  *     caller does not need the model's derived splat tensors.  Status words as cgs_rasterize_forward_static.
  *   cgs_view_backward: valid ONCE per cgs_view_forward (it consumes scratch sums the forward zeroed).  Only dL/dcolour
- *     flows in (train.py's loss reads `render` only); dL_drotation_extra [P,4] or NULL is added to the gradient of the
+ *     flows in (train.py's loss reads `render` only); colors_precomp as given to the forward (NULL = unit colours: the
+ *     compositors then use closed forms, sum w = 1 - T and dC/dalpha = (1 - bg) T_final / (1 - alpha)); dL_drotation_extra [P,4] or NULL is added to the gradient of the
  *     raw splat rotations before it is pulled back to the curves (the curve-smoothness regulariser enters there).
  *     Outputs: dL_dmeans2D [P,3] (NDC-scaled, feeds add_densification_stats), dL_dcurve_points [B,4,3], dL_dwidth [B,1],
  *     dL_dopacity_logit [B,1], dL_dmask_logit [P] (required iff mask_logit) -- overwritten, or added to when `accumulate`
@@ -154,7 +155,7 @@ int cgs_view_forward(int B, int m, const float* curve_points, const float* width
 size_t cgs_view_backward_scratch_floats(int B, int m);
 int cgs_view_backward(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
                       float eps, double* norms, const float* opacity_logit, const float* mask_logit, float mask_thr,
-                      void* geometry_buffer, const void* binning_buffer, const void* image_buffer, const float* background,
+                      const float* colors_precomp, void* geometry_buffer, const void* binning_buffer, const void* image_buffer, const float* background,
                       int width_px, int height_px, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                       float tan_fovx, float tan_fovy, const int* radii, const float* dL_dout_color,
                       const float* dL_drotation_extra, float* dL_dmeans2D, float* dL_dcurve_points, float* dL_dwidth,

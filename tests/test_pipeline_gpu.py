@@ -511,7 +511,7 @@ class _ViewCalls:
         st = L.raw_stream(torch.device(DEV))
         g_m2d = self.f32(self.P, 3)
         L.check(lib.cgs_view_backward(self.B, self.m, pt(self.cp), pt(self.w), pt(self.isb), pt(self.coef), cf(1e-8),
-                                      pt(self.norms), pt(self.op), None, cf(0.01), pt(self.geom), pt(self.binb),
+                                      pt(self.norms), pt(self.op), None, cf(0.01), None, pt(self.geom), pt(self.binb),
                                       pt(self.img), pt(self.bg), self.W, self.H, pt(cam.world_view_transform),
                                       pt(cam.full_proj_transform), pt(cam.camera_center), self.tf[0], self.tf[1],
                                       pt(self.radii), pt(dimg), None, pt(g_m2d), pt(g_cp), pt(g_w), pt(g_op), None,
