@@ -539,6 +539,7 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
                     wb = d1 ? 0.f : wb;
                     T2 = d1 ? 1.0f : T2;
                     cA = (d0 || d1) ? -0x1p126f : cA;
+                    if (UNIT) last_off = d0 ? j0 : d1 ? j1 : last_off;   // the splat that terminated the pixel (at most once)
                 }
                 Tw = T2;
                 if (!UNIT) C = fmaf(t0.x, wa, C);
@@ -549,8 +550,14 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
                 if (GEO) { A0 = fmaf(c1.x, wb, A0); A1 = fmaf(c1.y, wb, A1); A2 = fmaf(c1.z, wb, A2); if (!UNIT) A3 = fmaf(c1.w, wb, A3); }
                 // the offsets grow along the list and w > 0 exactly when a splat was blended (its bit pattern then
                 // exceeds any offset): the median of the three keeps the offset of the last blended splat
-                last_off = max(min(last_off, j0), min(max(last_off, j0), __float_as_uint(wa)));   // v_med3_u32
-                last_off = max(min(last_off, j1), min(max(last_off, j1), __float_as_uint(wb)));
+                // UNIT: the backward's position cut only matters for a pixel that TERMINATED (any other pixel blended every
+                // entry that passes the alpha test, and the backward repeats that test on the same exponent bits): the
+                // state then holds the position of the terminating splat instead, recorded in the rare branch above --
+                // entries between the last blended one and it failed the alpha test anyway.
+                if (!UNIT) {
+                    last_off = max(min(last_off, j0), min(max(last_off, j0), __float_as_uint(wa)));   // v_med3_u32
+                    last_off = max(min(last_off, j1), min(max(last_off, j1), __float_as_uint(wb)));
+                }
             }
             }
             if (ballot64(cA > -0x1p120f) == 0ull) {   // every pixel of the quadrant has terminated
@@ -558,8 +565,9 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
                 break;
             }
         }
-        if (last_off) last_contributor = (uint32_t)(i * BATCH) + (last_off >> 4);   // 1-based list position
+        if (last_off) last_contributor = (uint32_t)(i * BATCH) + (last_off >> 4) - (UNIT ? 1u : 0u);   // 1-based list position (UNIT: of the entry before the terminating one)
     }
+    if (UNIT && cA > -0x1p120f) last_contributor = (uint32_t)total;   // never terminated: no cut
     if (g.inside) {
         const size_t HW = (size_t)H * W;
         const float T = cA > -0x1p120f ? Tw : T_dead;
