@@ -13,7 +13,7 @@ config = sys.argv[3] if len(sys.argv) > 3 else "cfg3"
 root = f"gpurun_out/{tag}"
 
 # the bench's one-off parity call runs other template instances than the timed per-view path: keep them apart
-SHORT = [("k_render_bwd3<false, false, true>", "render_bwd_colour_grad"), ("k_render_fwd3<true, false>", "render_fwd_presorted"),
+SHORT = [("k_render_bwd3<false, false, true", "render_bwd_colour_grad"), ("k_render_fwd3<true, false", "render_fwd_presorted"),
          ("k_render_bwd", "render_bwd"), ("k_render_fwd", "render_fwd"), ("k_tile_rank_sort", "tile_sort"),
          ("k_tile_sort", "tile_sort_big"), ("k_scatter", "scatter"), ("k_preprocess_fwd", "preprocess_fwd"),
          ("k_preprocess_bwd", "preprocess_bwd"), ("k_scan_tiles", "scan_tiles"), ("k_sample_f12", "sample_f12"),
