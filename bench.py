@@ -687,13 +687,31 @@ def main():
         gl.finish()
         torch.cuda.synchronize()
         out["train_step_late_phase_ms"] = round((time.perf_counter() - tt0) / n_gs * 1e3, 4)
+        # the iteration with an image-only forward: train.py:98-107 reads `render` alone, inverse depth and all_map are
+        # computed by the reference's kernel but consumed by the TensorBoard report only (train.py:351-364)
+        gm5 = GaussianCurveModel(0, m, device=dev).create_from_curves(curves["curve_points"], curves["width"],
+                                                                      curves["opacity"], curves["mask"],
+                                                                      curves["is_bezier"])
+        gi = GraphedTrainStep(gm5, tcams, gts, aux_outputs=False)
+        for _ in range(3):
+            gi.step()
+        gi.finish()
+        torch.cuda.synchronize()
+        tt0 = time.perf_counter()
+        for _ in range(n_gs):
+            gi.step()
+        gi.finish()
+        torch.cuda.synchronize()
+        out["train_step_image_only_forward_ms"] = round((time.perf_counter() - tt0) / n_gs * 1e3, 4)
         out["train_step_ms"] = round(graph_ms, 4)
         out["train_step_eager_ms"] = round(eager_ms, 4)
         out["train_step_graph_recaptures"] = gs.recaptures
         out["train_step_note"] = ("train_step_ms: GraphedTrainStep (whole iteration = one hipGraph replay); "
                                   "train_step_eager_ms: TrainStep (Python autograd, ~30 launches).  Iteration = lr update + view pick + render (fused attrs + raster) + edge_aware_loss + fused_ssim "
                                   "+ backward + Adam (6 groups) + prepare_scaling_rot; regularisers of train.py:110-146 "
-                                  "excluded (SURVEY 8d)")
+                                  "excluded (SURVEY 8d).  train_step_image_only_forward_ms: the same iteration when the forward "
+                                  "writes `render` only (GraphedTrainStep(aux_outputs=False)); NOT the headline: the reference's "
+                                  "kernel always produces inverse depth and all_map")
 
     # ---------------------------------------------------------------- CPU baseline (oracle port, bounded sample)
     if world == 1 and not args.no_cpu_baseline:

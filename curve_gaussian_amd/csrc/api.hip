@@ -573,8 +573,8 @@ int cgs_view_forward(int B, int m, const float* curve_points, const float* width
     const int P = B * m;
     if (B <= 0 || m <= 0 || m > 32 || width_px <= 0 || height_px <= 0 || !curve_points || !width || !coef || !norms ||
         !opacity_logit || !geometry_buffer || !binning_buffer || !image_buffer || bucket_capacity == 0 || !background ||
-        !viewmatrix || !projmatrix || !cam_pos || !out_color || !out_invdepth || !out_all_map || !radii ||
-        (xyz && (!rotation || !scaling)) || !aligned16(curve_points) || !aligned16(coef) || !aligned16(rotation)) {
+        !viewmatrix || !projmatrix || !cam_pos || !out_color || (!out_invdepth != !out_all_map) ||
+        (!out_all_map && colors_precomp) || !radii || (xyz && (!rotation || !scaling)) || !aligned16(curve_points) || !aligned16(coef) || !aligned16(rotation)) {
         set_error("cgs_view_forward: invalid argument (B=%d m=%d W=%d H=%d, NULL / misaligned pointer or zero capacity)", B, m,
                   width_px, height_px);
         return CGS_ERR_INVALID_ARGUMENT;
@@ -610,16 +610,17 @@ int cgs_view_forward(int B, int m, const float* curve_points, const float* width
                         clear_bytes / sizeof(uint32_t));
     // k_view_fwd writes unit colours (no colors_precomp) and all_map[3] = 1 itself: the compositor derives both sums from T
     const bool unit = colors_precomp == nullptr;
+    const bool aux = out_all_map != nullptr;   // image-only forward (unit colours required) when the caller passes neither map
     const bool defer_big = hints_load(P, width_px, height_px).big > 0;
     launch_scatter_bucket(s, P, radii, geom.rec, gx, gy, img.tile_count, bin.keys, (uint32_t)cap, 1, img.total + 3,
                           defer_big ? img.tile_cursor : nullptr, (uint32_t)tiles);
     if (render_fwd_can_sort((uint32_t)cap) && fuse_sort()) {
-        launch_render_fwd_sorting(s, true, tiles, img.tile_count, bin.keys, (uint32_t)cap, img.ranges, img.total,
+        launch_render_fwd_sorting(s, aux, tiles, img.tile_count, bin.keys, (uint32_t)cap, img.ranges, img.total,
                                   bin.point_list, width_px, height_px, gx, geom.rec, img.final_T, img.n_contrib, background,
                                   out_color, out_invdepth, out_all_map, unit);
     } else {
         launch_tile_sort_bucket(s, tiles, img.tile_count, img.ranges, img.total, bin.keys, bin.point_list, (uint32_t)cap);
-        launch_render_fwd(s, true, tiles, img.ranges, bin.point_list, width_px, height_px, gx, geom.rec, img.final_T,
+        launch_render_fwd(s, aux, tiles, img.ranges, bin.point_list, width_px, height_px, gx, geom.rec, img.final_T,
                           img.n_contrib, background, out_color, out_invdepth, out_all_map, unit);
     }
     if (!check_launch("view_forward", false, s)) return CGS_ERR_HIP;

@@ -380,6 +380,9 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
                                                      uint32_t* __restrict__ n_contrib, const float* __restrict__ bg_color,
                                                      float* __restrict__ out_color, float* __restrict__ out_invdepth,
                                                      float* __restrict__ out_all_map, BucketSort bs) {
+    // UNIT without GEO is the image-only instance: the caller wants neither inverse depth nor all_map (a training iteration
+    // reads `render` only, train.py:98-107) -- the walk then carries the transmittance and nothing else.
+    constexpr bool IMAGE_ONLY = UNIT && !GEO;
     // staged entry j of the batch lives at index j + 1 (offset 0 = "nothing blended yet"); index BATCH + 1 is the padding
     // entry (never blended, and behind every real one: the list offsets stay sorted)
     __shared__ float4 s_geo[BATCH + 2];   // {cx, cy, A2, B2}
@@ -509,8 +512,11 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
                 if (s < cnt) {                                                  // wave-uniform
                 if ((s & 3) == 0) w4 = *reinterpret_cast<const uint4*>(list + g0 + s);
                 const uint32_t j0 = (s & 2) ? w4.z : w4.x, j1 = (s & 2) ? w4.w : w4.y;
-                const float2 t0 = *reinterpret_cast<const float2*>(at_bytes + j0);
-                const float2 t1 = *reinterpret_cast<const float2*>(at_bytes + j1);
+                float2 t0 = make_float2(0.f, 0.f), t1 = t0;
+                if (!IMAGE_ONLY) {
+                    t0 = *reinterpret_cast<const float2*>(at_bytes + j0);
+                    t1 = *reinterpret_cast<const float2*>(at_bytes + j1);
+                }
                 float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
                 if (GEO) {
                     c0 = *reinterpret_cast<const float4*>(c_bytes + j0);
@@ -543,10 +549,10 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
                 }
                 Tw = T2;
                 if (!UNIT) C = fmaf(t0.x, wa, C);
-                Dacc = fmaf(t0.y, wa, Dacc);
+                if (!IMAGE_ONLY) Dacc = fmaf(t0.y, wa, Dacc);
                 if (GEO) { A0 = fmaf(c0.x, wa, A0); A1 = fmaf(c0.y, wa, A1); A2 = fmaf(c0.z, wa, A2); if (!UNIT) A3 = fmaf(c0.w, wa, A3); }
                 if (!UNIT) C = fmaf(t1.x, wb, C);
-                Dacc = fmaf(t1.y, wb, Dacc);
+                if (!IMAGE_ONLY) Dacc = fmaf(t1.y, wb, Dacc);
                 if (GEO) { A0 = fmaf(c1.x, wb, A0); A1 = fmaf(c1.y, wb, A1); A2 = fmaf(c1.z, wb, A2); if (!UNIT) A3 = fmaf(c1.w, wb, A3); }
                 // the offsets grow along the list and w > 0 exactly when a splat was blended (its bit pattern then
                 // exceeds any offset): the median of the three keeps the offset of the last blended splat
@@ -575,8 +581,10 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
         n_contrib[g.pix_id] = last_contributor;
         if (UNIT) C = A3 = 1.f - T;
         out_color[g.pix_id] = C + T * bg_color[0];
-        out_invdepth[g.pix_id] = Dacc;
-        if (GEO) {
+        if (!IMAGE_ONLY) out_invdepth[g.pix_id] = Dacc;
+        if (IMAGE_ONLY) {
+            // (no other outputs)
+        } else if (GEO) {
             out_all_map[g.pix_id] = A0;
             out_all_map[HW + g.pix_id] = A1;
             out_all_map[2 * HW + g.pix_id] = A2;
@@ -993,6 +1001,9 @@ void launch_render_fwd(hipStream_t s, bool geo, int tiles, const uint2* ranges, 
         if (geo && unit)
             hipLaunchKernelGGL((k_render_fwd3<true, false, true>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H, grid_x,
                                rec, final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, BucketSort{});
+        else if (unit)
+            hipLaunchKernelGGL((k_render_fwd3<false, false, true>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H, grid_x,
+                               rec, final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, BucketSort{});
         else if (geo)
             hipLaunchKernelGGL((k_render_fwd3<true, false>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H, grid_x, rec,
                                final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, BucketSort{});
@@ -1019,6 +1030,9 @@ void launch_render_fwd_sorting(hipStream_t s, bool geo, int tiles, const uint32_
     if (!v2) {
         if (geo && unit)
             hipLaunchKernelGGL((k_render_fwd3<true, true, true>), dim3(tiles), dim3(256), 0, s, nullptr, nullptr, W, H, grid_x, rec,
+                               final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, bs);
+        else if (unit)
+            hipLaunchKernelGGL((k_render_fwd3<false, true, true>), dim3(tiles), dim3(256), 0, s, nullptr, nullptr, W, H, grid_x, rec,
                                final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, bs);
         else if (geo)
             hipLaunchKernelGGL((k_render_fwd3<true, true>), dim3(tiles), dim3(256), 0, s, nullptr, nullptr, W, H, grid_x, rec,

@@ -148,9 +148,12 @@ class GraphedTrainStep(TrainStep):
     ``step()`` returns the graph's static loss tensor: it is overwritten by the next step (copy or ``float()`` it
     to keep a value).  Call ``finish()`` before reading the model from outside or editing its topology."""
 
-    def __init__(self, *args, cap_margin=1.5, direct=True, collectives=None, fused_view=True, **kw):
+    def __init__(self, *args, cap_margin=1.5, direct=True, collectives=None, fused_view=True, aux_outputs=True, **kw):
         kw["fused"] = True
         super().__init__(*args, **kw)
+        # aux_outputs=False (fused direct body only): the forward writes `render` alone -- a training iteration reads nothing
+        # else (train.py:98-107); `last["depth"]` / `last["all_map"]` are then None.  Default: every output of render().
+        self.aux_outputs = bool(aux_outputs)
         # direct body only: cgs_view_forward / cgs_view_backward (the per-splat chains fused, csrc/view.hip) instead of the
         # sampling -> attributes -> rasterizer calls one by one; same results, five launches fewer per iteration
         self.fused_view = bool(fused_view)
@@ -366,7 +369,8 @@ class GraphedTrainStep(TrainStep):
             B, m, p(cp), p(wl), p(b["isb"]), p(b["coef"]), cf(1e-8), p(b["norms"]), p(ol), p(mask), cf(self.mask_threshold),
             None, p(b["geom"]), p(b["bin"]), b["nbin"], p(b["img"]), self._cap, p(b["bg"]), W, H,
             p(cam.world_view_transform), p(cam.full_proj_transform), p(cam.camera_center), tanx, tany, p(b["color"]),
-            p(b["invd"]), p(b["omap"]), p(b["radii"]), p(b["xyz"]), p(b["rot"]), p(b["scl"]), s), "view_forward")
+            p(b["invd"]) if self.aux_outputs else None, p(b["omap"]) if self.aux_outputs else None, p(b["radii"]),
+            p(b["xyz"]), p(b["rot"]), p(b["scl"]), s), "view_forward")
         a = self.lambda_mse * (1.0 - self.lambda_dssim)
         bb = self.lambda_mse * self.lambda_dssim
         chk(lib.cgs_photometric_loss_indexed(H, W, p(b["color"]), p(self._gt_stack), p(self._view_idx), cf(0.1),
@@ -402,7 +406,8 @@ class GraphedTrainStep(TrainStep):
         status = b["status"]
         if not self._collective:
             g.optimizer.step_dev(zero_grad=True, skip_flag=status[2:3])
-        self.last = dict(radii=b["radii"], dL_dmeans2D=b["g_m2d"], render=b["color"], depth=b["invd"], all_map=b["omap"])
+        self.last = dict(radii=b["radii"], dL_dmeans2D=b["g_m2d"], render=b["color"],
+                         depth=b["invd"] if self.aux_outputs else None, all_map=b["omap"] if self.aux_outputs else None)
         return loss, status
 
     def _probe_capacity(self):

@@ -602,6 +602,25 @@ def test_view_entry_points_match_the_oracle_chain_at_full_size(cfg):
     fw.free()
 
 
+def test_graphed_train_step_image_only_forward_follows_the_same_trajectory():
+    """GraphedTrainStep(aux_outputs=False): cgs_view_forward without inverse depth / all_map (the iteration reads `render`
+    only, train.py:98-107).  Same image, same parameters after ten iterations as with every output, through the mask phase."""
+    from curve_gaussian_amd.train_step import GraphedTrainStep
+    torch.manual_seed(0); ga, cams, gts = _train_fixture()
+    torch.manual_seed(0); gb, _, _ = _train_fixture()
+    sa = GraphedTrainStep(ga, cams, gts, seed=4, densify_until_iter=5)
+    sb = GraphedTrainStep(gb, cams, gts, seed=4, densify_until_iter=5, aux_outputs=False)
+    for it in range(10):
+        la, lb = sa.step()[0], sb.step()[0]
+        if it == 0:
+            assert torch.equal(sb.last["render"], sa.last["render"]) and sb.last["all_map"] is None
+    sa.finish(); sb.finish()
+    np.testing.assert_allclose(float(lb), float(la), rtol=2e-5)
+    for n in ("_curve_points", "_width", "_opacity", "_mask"):
+        np.testing.assert_allclose(getattr(gb, n).detach().cpu().numpy(), getattr(ga, n).detach().cpu().numpy(),
+                                   rtol=2e-4, atol=2e-6, err_msg=n)
+
+
 def test_graphed_train_step_crosses_the_mask_phase():
     """At densify_until_iter the iteration switches to the straight-through curve mask + mask loss (train.py:97,110-111);
     the graphed step re-captures once and keeps following the eager trajectory."""
