@@ -465,7 +465,7 @@ class _ViewCalls:
     """cgs_view_forward / cgs_view_backward through ctypes on caller-owned buffers, the way bench.py and GraphedTrainStep
     call them (no autograd)."""
 
-    def __init__(self, cp, width, opacity, is_bezier, cam, cap):
+    def __init__(self, cp, width, opacity, is_bezier, cam, cap, colors=None):
         import ctypes as C
         from curve_gaussian_amd import _lib as L
         from curve_gaussian_amd.ops import curve_sampling
@@ -481,6 +481,7 @@ class _ViewCalls:
         u8 = lambda n: torch.zeros(int(n), dtype=torch.uint8, device=DEV)
         self.f32 = lambda *sh: torch.zeros(*sh, dtype=torch.float32, device=DEV)
         self.cp, self.w, self.op = (t.detach().to(DEV).contiguous() for t in (cp, width, opacity))
+        self.colors = None if colors is None else colors.detach().to(DEV).float().contiguous()   # [P] (None: unit colours)
         self.isb = curve_sampling._bezier_mask(is_bezier.to(DEV), DEV)
         self.coef = curve_sampling.sample_coefficients(self.m, DEV)
         self.norms = torch.empty(384, dtype=torch.float64, device=DEV)
@@ -498,7 +499,7 @@ class _ViewCalls:
         L, lib, pt, cf, cam = self.L, self.lib, self.L.ptr, self.C.c_float, self.cam
         st = L.raw_stream(torch.device(DEV))
         L.check(lib.cgs_view_forward(self.B, self.m, pt(self.cp), pt(self.w), pt(self.isb), pt(self.coef), cf(1e-8),
-                                     pt(self.norms), pt(self.op), None, cf(0.01), None, pt(self.geom), pt(self.binb),
+                                     pt(self.norms), pt(self.op), None, cf(0.01), pt(self.colors), pt(self.geom), pt(self.binb),
                                      self.nbin, pt(self.img), self.cap, pt(self.bg), self.W, self.H,
                                      pt(cam.world_view_transform), pt(cam.full_proj_transform), pt(cam.camera_center),
                                      self.tf[0], self.tf[1], pt(self.color), pt(self.invd), pt(self.omap), pt(self.radii),
@@ -511,7 +512,7 @@ class _ViewCalls:
         st = L.raw_stream(torch.device(DEV))
         g_m2d = self.f32(self.P, 3)
         L.check(lib.cgs_view_backward(self.B, self.m, pt(self.cp), pt(self.w), pt(self.isb), pt(self.coef), cf(1e-8),
-                                      pt(self.norms), pt(self.op), None, cf(0.01), None, pt(self.geom), pt(self.binb),
+                                      pt(self.norms), pt(self.op), None, cf(0.01), pt(self.colors), pt(self.geom), pt(self.binb),
                                       pt(self.img), pt(self.bg), self.W, self.H, pt(cam.world_view_transform),
                                       pt(cam.full_proj_transform), pt(cam.camera_center), self.tf[0], self.tf[1],
                                       pt(self.radii), pt(dimg), None, pt(g_m2d), pt(g_cp), pt(g_w), pt(g_op), None,
@@ -548,14 +549,15 @@ def test_view_backward_accumulate_flag_adds_to_the_gradient_buffers():
         assert rel_l2(b, 2.0 * a) < 1e-3, name
 
 
-@pytest.mark.parametrize("cfg", ["cfg1", "cfg3"])
-def test_view_entry_points_match_the_oracle_chain_at_full_size(cfg):
+@pytest.mark.parametrize("cfg,coloured", [("cfg1", False), ("cfg3", False), ("cfg1", True), ("cfg2", True)])
+def test_view_entry_points_match_the_oracle_chain_at_full_size(cfg, coloured):
     """The whole per-view path of a BASELINE config through its two C-ABI calls -- curve tensors in, image out; image
     gradient in, curve-parameter gradients out -- against the chain of oracles: torch restatement of prepare_scaling_rot /
     get_rotation / get_opacity / all_map (autograd for their backward) around the C rasterizer oracle's forward and
     backward.  Image under the rasterizer criterion (1e-4 of max, flip budget); curve-parameter gradients in relative L2
     (the sampling backward sums 12 samples per curve with cancellation: element-wise noise of a few 1e-4 of max from the
-    compositor's atomics order alone, see test_view_backward_accumulate_flag...)."""
+    compositor's atomics order alone, see test_view_backward_accumulate_flag...).  Without colors_precomp the entry points
+    run the unit-colour instances of the compositors (closed-form sums), with it the general ones."""
     curves, cams = S.make_config(cfg, n_views=1)
     cam = cams[0]
     H, W = cam.image_height, cam.image_width
@@ -568,7 +570,8 @@ def test_view_entry_points_match_the_oracle_chain_at_full_size(cfg):
     amap = TR.build_all_map(rot.detach(), xyz.detach(), cam.camera_center, cam.world_view_transform).float().contiguous()
     tfx, tfy = tanfov(cam)
     n = lambda t: np.ascontiguousarray(t.detach().numpy())
-    fw = ORA.forward(np.zeros(3, np.float32), n(xyz), np.ones((P, 1), np.float32), n(opac), n(scl), n(rotn), 1.0, None,
+    colors = 0.2 + 0.8 * torch.rand(P, 1, generator=torch.Generator().manual_seed(5)) if coloured else torch.ones(P, 1)
+    fw = ORA.forward(np.zeros(3, np.float32), n(xyz), n(colors), n(opac), n(scl), n(rotn), 1.0, None,
                      n(amap), n(cam.world_view_transform), n(cam.full_proj_transform), tfx, tfy, H, W, None, 0,
                      n(cam.camera_center))
     dimg = torch.randn(1, H, W, generator=torch.Generator().manual_seed(17))
@@ -578,7 +581,8 @@ def test_view_entry_points_match_the_oracle_chain_at_full_size(cfg):
              + (rotn * t(gr["dL_drotations"])).sum() + (opac * t(gr["dL_dopacity"])).sum())
     chain.backward()
     # ---- product
-    vc = _ViewCalls(curves["curve_points"], curves["width"], curves["opacity"], curves["is_bezier"], cam, 1024)
+    vc = _ViewCalls(curves["curve_points"], curves["width"], curves["opacity"], curves["is_bezier"], cam, 1024,
+                    colors=colors.reshape(-1) if coloured else None)
     vc.forward()
     assert_close("color", vc.color.cpu().numpy(), fw.color)
     assert_close("all_map", vc.omap.cpu().numpy(), fw.out_all_map, outlier_frac=2e-4)
