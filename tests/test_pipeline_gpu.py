@@ -465,7 +465,7 @@ class _ViewCalls:
     """cgs_view_forward / cgs_view_backward through ctypes on caller-owned buffers, the way bench.py and GraphedTrainStep
     call them (no autograd)."""
 
-    def __init__(self, cp, width, opacity, is_bezier, cam, cap, colors=None):
+    def __init__(self, cp, width, opacity, is_bezier, cam, cap, colors=None, bg=0.0):
         import ctypes as C
         from curve_gaussian_amd import _lib as L
         from curve_gaussian_amd.ops import curve_sampling
@@ -490,7 +490,7 @@ class _ViewCalls:
         self.binb = u8(self.nbin)
         self.color, self.invd, self.omap = self.f32(1, self.H, self.W), self.f32(1, self.H, self.W), self.f32(4, self.H, self.W)
         self.radii = torch.empty(self.P, dtype=torch.int32, device=DEV)
-        self.bg = torch.zeros(3, device=DEV)
+        self.bg = torch.full((3,), float(bg), device=DEV)
         self.scratch = self.f32(int(lib.cgs_view_backward_scratch_floats(self.B, self.m)))
         off = int(lib.cgs_image_status_offset(self.W, self.H))
         self.status = self.img[off:off + 4 * int(lib.cgs_status_words())].view(torch.int32)
@@ -549,8 +549,9 @@ def test_view_backward_accumulate_flag_adds_to_the_gradient_buffers():
         assert rel_l2(b, 2.0 * a) < 1e-3, name
 
 
-@pytest.mark.parametrize("cfg,coloured", [("cfg1", False), ("cfg3", False), ("cfg1", True), ("cfg2", True)])
-def test_view_entry_points_match_the_oracle_chain_at_full_size(cfg, coloured):
+@pytest.mark.parametrize("cfg,coloured,bg", [("cfg1", False, 0.0), ("cfg3", False, 0.0), ("cfg1", True, 0.0), ("cfg2", True, 0.0),
+                                              ("cfg2", False, 0.35), ("cfg1", True, 0.35)])
+def test_view_entry_points_match_the_oracle_chain_at_full_size(cfg, coloured, bg):
     """The whole per-view path of a BASELINE config through its two C-ABI calls -- curve tensors in, image out; image
     gradient in, curve-parameter gradients out -- against the chain of oracles: torch restatement of prepare_scaling_rot /
     get_rotation / get_opacity / all_map (autograd for their backward) around the C rasterizer oracle's forward and
@@ -571,7 +572,7 @@ def test_view_entry_points_match_the_oracle_chain_at_full_size(cfg, coloured):
     tfx, tfy = tanfov(cam)
     n = lambda t: np.ascontiguousarray(t.detach().numpy())
     colors = 0.2 + 0.8 * torch.rand(P, 1, generator=torch.Generator().manual_seed(5)) if coloured else torch.ones(P, 1)
-    fw = ORA.forward(np.zeros(3, np.float32), n(xyz), n(colors), n(opac), n(scl), n(rotn), 1.0, None,
+    fw = ORA.forward(np.full(3, bg, np.float32), n(xyz), n(colors), n(opac), n(scl), n(rotn), 1.0, None,
                      n(amap), n(cam.world_view_transform), n(cam.full_proj_transform), tfx, tfy, H, W, None, 0,
                      n(cam.camera_center))
     dimg = torch.randn(1, H, W, generator=torch.Generator().manual_seed(17))
@@ -582,7 +583,7 @@ def test_view_entry_points_match_the_oracle_chain_at_full_size(cfg, coloured):
     chain.backward()
     # ---- product
     vc = _ViewCalls(curves["curve_points"], curves["width"], curves["opacity"], curves["is_bezier"], cam, 1024,
-                    colors=colors.reshape(-1) if coloured else None)
+                    colors=colors.reshape(-1) if coloured else None, bg=bg)
     vc.forward()
     assert_close("color", vc.color.cpu().numpy(), fw.color)
     assert_close("all_map", vc.omap.cpu().numpy(), fw.out_all_map, outlier_frac=2e-4)
