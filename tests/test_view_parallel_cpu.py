@@ -177,3 +177,21 @@ def test_ranks_draw_disjoint_views_from_one_stream():
         assert a[i] != b[i]
     assert sorted(a[:4] + b[:4]) == list(range(8)) and sorted(a[4:] + b[4:]) == list(range(8))
     assert sorted(draws(0, 1, 5, 5)) == list(range(5))
+
+
+def test_no_gc_suspends_the_cyclic_collector_and_restores_it():
+    """view_parallel.no_gc wraps stream captures: a cyclic collection inside a capture finalises retired graphs / events
+    whose HIP destroy calls are illegal there (observed as an abort in a captured autograd backward)."""
+    import gc
+    from curve_gaussian_amd.view_parallel import no_gc
+    assert gc.isenabled()
+    with no_gc():
+        assert not gc.isenabled()
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        with no_gc():
+            assert not gc.isenabled()
+        assert not gc.isenabled()      # a caller that runs without the collector keeps running without it
+    finally:
+        gc.enable()
