@@ -469,7 +469,8 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
             stage_splat(a, b, sa, sb);
             s_geo[threadIdx.x + 1] = sa;
             s_at[threadIdx.x + 1] = make_float4(sb.z, sb.w, sb.x, __builtin_amdgcn_logf(sb.y));   // v_log_f32 = log2
-            if (GEO) s_c[threadIdx.x + 1] = r->c;
+            // UNIT: all_map[3] == 1 is not read back, its slot carries 1/depth -- one 16-byte read per pair instead of two reads
+            if (GEO) s_c[threadIdx.x + 1] = UNIT ? make_float4(r->c.x, r->c.y, r->c.z, sb.w) : r->c;
             qm = quadrant_mask(a, b, r->d.z, X0, Y0);   // (0 unless opacity >= 1/255: the log is finite for every listed entry)
         }
 #pragma unroll
@@ -513,7 +514,7 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
                 if ((s & 3) == 0) w4 = *reinterpret_cast<const uint4*>(list + g0 + s);
                 const uint32_t j0 = (s & 2) ? w4.z : w4.x, j1 = (s & 2) ? w4.w : w4.y;
                 float2 t0 = make_float2(0.f, 0.f), t1 = t0;
-                if (!IMAGE_ONLY) {
+                if (!UNIT) {
                     t0 = *reinterpret_cast<const float2*>(at_bytes + j0);
                     t1 = *reinterpret_cast<const float2*>(at_bytes + j1);
                 }
@@ -549,10 +550,10 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
                 }
                 Tw = T2;
                 if (!UNIT) C = fmaf(t0.x, wa, C);
-                if (!IMAGE_ONLY) Dacc = fmaf(t0.y, wa, Dacc);
+                if (!IMAGE_ONLY) Dacc = fmaf(UNIT ? c0.w : t0.y, wa, Dacc);
                 if (GEO) { A0 = fmaf(c0.x, wa, A0); A1 = fmaf(c0.y, wa, A1); A2 = fmaf(c0.z, wa, A2); if (!UNIT) A3 = fmaf(c0.w, wa, A3); }
                 if (!UNIT) C = fmaf(t1.x, wb, C);
-                if (!IMAGE_ONLY) Dacc = fmaf(t1.y, wb, Dacc);
+                if (!IMAGE_ONLY) Dacc = fmaf(UNIT ? c1.w : t1.y, wb, Dacc);
                 if (GEO) { A0 = fmaf(c1.x, wb, A0); A1 = fmaf(c1.y, wb, A1); A2 = fmaf(c1.z, wb, A2); if (!UNIT) A3 = fmaf(c1.w, wb, A3); }
                 // the offsets grow along the list and w > 0 exactly when a splat was blended (its bit pattern then
                 // exceeds any offset): the median of the three keeps the offset of the last blended splat
