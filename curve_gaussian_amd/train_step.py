@@ -148,7 +148,8 @@ class GraphedTrainStep(TrainStep):
     ``step()`` returns the graph's static loss tensor: it is overwritten by the next step (copy or ``float()`` it
     to keep a value).  Call ``finish()`` before reading the model from outside or editing its topology."""
 
-    def __init__(self, *args, cap_margin=1.5, direct=True, collectives=None, fused_view=True, aux_outputs=True, **kw):
+    def __init__(self, *args, cap_margin=1.5, direct=True, collectives=None, fused_view=True, aux_outputs=True,
+                 capture_collectives=False, **kw):
         kw["fused"] = True
         super().__init__(*args, **kw)
         # aux_outputs=False (fused direct body only): the forward writes `render` alone -- a training iteration reads nothing
@@ -163,6 +164,10 @@ class GraphedTrainStep(TrainStep):
         # iteration k - 2 (blocking, long finished) at the start of iteration k, so every rank redoes the same iteration
         # at the same point of its collective sequence.
         self._collective = (self.world > 1) if collectives is None else bool(collectives)
+        # capture_collectives=True: the two all-reduces and the Adam kernel are captured with the rest of the iteration (one
+        # graph replay per step, no host touch between backward and optimizer).  Opt-in: exercised on a single-rank RCCL
+        # group only (no multi-GPU box in the build environment).
+        self._capture_coll = bool(capture_collectives) and self._collective
         if self._collective:
             import torch.distributed as dist
             if not (dist.is_available() and dist.is_initialized()):
@@ -353,7 +358,11 @@ class GraphedTrainStep(TrainStep):
             loss = loss + self.lambda_mask * sg.mean()
             grads.view("mask").add_(sg * (1 - sg), alpha=self.lambda_mask / mask.numel())
         status = b["status"]
-        if not self._collective:     # view-parallel: the all-reduce sits between the backward and the optimizer
+        if self._capture_coll:
+            import torch.distributed as dist
+            dist.all_reduce(g.optimizer.grads.flat)
+            dist.all_reduce(status[2:3], op=dist.ReduceOp.MAX)   # any rank overflowed -> every rank skips
+        if not self._collective or self._capture_coll:   # view-parallel: the all-reduce sits between backward and optimizer
             g.optimizer.step_dev(zero_grad=True, skip_flag=status[2:3])
         self.last = dict(radii=b["radii"], dL_dmeans2D=b["g_m2d"], render=b["color"], depth=b["invd"], all_map=b["omap"])
         return loss, status
@@ -404,7 +413,11 @@ class GraphedTrainStep(TrainStep):
             loss = loss + self.lambda_mask * sg.mean()
             grads.view("mask").add_(sg * (1 - sg), alpha=self.lambda_mask / mask.numel())
         status = b["status"]
-        if not self._collective:
+        if self._capture_coll:
+            import torch.distributed as dist
+            dist.all_reduce(g.optimizer.grads.flat)
+            dist.all_reduce(status[2:3], op=dist.ReduceOp.MAX)   # any rank overflowed -> every rank skips
+        if not self._collective or self._capture_coll:
             g.optimizer.step_dev(zero_grad=True, skip_flag=status[2:3])
         self.last = dict(radii=b["radii"], dL_dmeans2D=b["g_m2d"], render=b["color"],
                          depth=b["invd"] if self.aux_outputs else None, all_map=b["omap"] if self.aux_outputs else None)
@@ -539,7 +552,7 @@ class GraphedTrainStep(TrainStep):
             self._capture(vi)
         self._stage(vi)
         self._graph.replay()
-        if self._collective:
+        if self._collective and not self._capture_coll:
             import torch.distributed as dist
             dist.all_reduce(g.optimizer.grads.flat)
             dist.all_reduce(self._status[2:3], op=dist.ReduceOp.MAX)   # any rank overflowed -> every rank skips

@@ -668,17 +668,20 @@ def test_graphed_train_step_view_parallel_mode_single_rank_group():
         torch.manual_seed(0); gc, _, _ = _train_fixture()
         ea = TrainStep(ga, cams, gts, seed=9)
         gs = GraphedTrainStep(gb, cams, gts, seed=9, collectives=True)
+        torch.manual_seed(0); gd, _, _ = _train_fixture()
+        gcap = GraphedTrainStep(gd, cams, gts, seed=9, collectives=True, capture_collectives=True)   # RCCL inside the graph
         tiny = GraphedTrainStep(gc, cams, gts, seed=9, collectives=True)
         tiny._cap = 64
         tiny._probe_capacity = lambda: 64
         for _ in range(10):
-            ea.step(); gs.step(); tiny.step()
-        gs.finish(); tiny.finish()
+            ea.step(); gs.step(); tiny.step(); gcap.step()
+        gs.finish(); tiny.finish(); gcap.finish()
         assert gs.recaptures == 1 and tiny.recaptures > 1 and gc.optimizer.step_count == 10
         for n in ("_curve_points", "_width", "_opacity"):
             ref = getattr(ga, n).detach().cpu().numpy()
             np.testing.assert_allclose(getattr(gb, n).detach().cpu().numpy(), ref, rtol=2e-4, atol=2e-6, err_msg=n)
             np.testing.assert_allclose(getattr(gc, n).detach().cpu().numpy(), ref, rtol=2e-4, atol=2e-6, err_msg="overflow " + n)
+            np.testing.assert_allclose(getattr(gd, n).detach().cpu().numpy(), ref, rtol=2e-4, atol=2e-6, err_msg="captured collectives " + n)
     finally:
         if created:
             dist.destroy_process_group()
