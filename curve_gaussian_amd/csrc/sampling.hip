@@ -113,8 +113,9 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_sample_bwd(int B, int m, int c
         const SampleFwd s = sample_forward(c, k, N1, N2, eps);
         V3 g_v0 = {0, 0, 0}, g_v1 = {0, 0, 0}, g_v2 = {0, 0, 0};
         if (PASS > 1 && g_rot) {  // pass 1 cached dL/d{v0,v1,v2} (the quaternion backward) for passes 2 and 3
-            const float* gv = gv_cache + 9 * p;
-            g_v0 = {gv[0], gv[1], gv[2]}; g_v1 = {gv[3], gv[4], gv[5]}; g_v2 = {gv[6], gv[7], gv[8]};
+            const float* gv = gv_cache + p;   // planes [9][P]: a wave's accesses are contiguous
+            const size_t PS = (size_t)B * m;
+            g_v0 = {gv[0], gv[PS], gv[2 * PS]}; g_v1 = {gv[3 * PS], gv[4 * PS], gv[5 * PS]}; g_v2 = {gv[6 * PS], gv[7 * PS], gv[8 * PS]};
         } else if (g_rot) {
             float M[3][3], q[4], gM[3][3];
             rot_matrix(s, M);
@@ -125,9 +126,10 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_sample_bwd(int B, int m, int c
             g_v0 = {gM[0][0], gM[1][0], gM[2][0]};
             g_v1 = {gM[0][1], gM[1][1], gM[2][1]};
             g_v2 = {gM[0][2], gM[1][2], gM[2][2]};
-            float* gv = gv_cache + 9 * p;
-            gv[0] = g_v0.x; gv[1] = g_v0.y; gv[2] = g_v0.z; gv[3] = g_v1.x; gv[4] = g_v1.y; gv[5] = g_v1.z;
-            gv[6] = g_v2.x; gv[7] = g_v2.y; gv[8] = g_v2.z;
+            float* gv = gv_cache + p;         // planes [9][P]
+            const size_t PS = (size_t)B * m;
+            gv[0] = g_v0.x; gv[PS] = g_v0.y; gv[2 * PS] = g_v0.z; gv[3 * PS] = g_v1.x; gv[4 * PS] = g_v1.y; gv[5 * PS] = g_v1.z;
+            gv[6 * PS] = g_v2.x; gv[7 * PS] = g_v2.y; gv[8 * PS] = g_v2.z;
         }
         if (PASS == 1) {
             acc += (double)dot(g_v2, s.c2v);

@@ -143,9 +143,10 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK, CGS_VIEW_BWD_WAVES) k_view_bwd(
         const V3 g_v0 = {gM[0][0], gM[1][0], gM[2][0]};
         const V3 g_v1 = {gM[0][1], gM[1][1], gM[2][1]};
         const V3 g_v2 = {gM[0][2], gM[1][2], gM[2][2]};
-        float* gv = gv_cache + 9 * p;
-        gv[0] = g_v0.x; gv[1] = g_v0.y; gv[2] = g_v0.z; gv[3] = g_v1.x; gv[4] = g_v1.y; gv[5] = g_v1.z;
-        gv[6] = g_v2.x; gv[7] = g_v2.y; gv[8] = g_v2.z;
+        float* gv = gv_cache + p;             // planes [9][P]: a wave's accesses are contiguous
+        const size_t PS = (size_t)B * m;
+        gv[0] = g_v0.x; gv[PS] = g_v0.y; gv[2 * PS] = g_v0.z; gv[3 * PS] = g_v1.x; gv[4 * PS] = g_v1.y; gv[5 * PS] = g_v1.z;
+        gv[6 * PS] = g_v2.x; gv[7 * PS] = g_v2.y; gv[8 * PS] = g_v2.z;
         acc_d2 = (double)dot(g_v2, s.c2v);
         acc_a = (double)dot(g_v1, s.c1v) + (double)((1.f / N2) * dot(cross(g_v2, s.tan), s.c1v));
         g_xyz[3 * p] = o.dmean.x; g_xyz[3 * p + 1] = o.dmean.y; g_xyz[3 * p + 2] = o.dmean.z;
