@@ -645,9 +645,11 @@ __device__ __forceinline__ float rows_sum2(float a, float b) {     // -> [a, b, 
 //     blended) into a private list and walks it as a counted loop -- no scalar bit walk, no per-pair slot bookkeeping;
 //   * phase 1 (pixel-parallel) parks one scalar g per (pixel, splat) in a per-wave LDS slot buffer, eight splats at a time;
 //     phase 2 (splat-parallel): lane (slot, pixel row) folds its 8 pixels into the six moments about the row's first pixel
-//     and shifts them to the splat centre, the 8 row results of a slot are summed through LDS by the (slot, field) lanes,
-//     which issue the global f32 atomics -- 8 consecutive floats per splat = one L2 request (the reference issues 12 atomics
-//     per PIXEL pair, backward.cu:613-672);
+//     and shifts them to the splat centre, the 8 row results of a slot are summed through LDS by the (slot, field) lanes;
+//   * leaving the workgroup: in the training instances those lanes PARK the sums at the pair's list position (s_res below)
+//     and one combining pass per batch issues a single atomic request per tile instance; the instances with extra sums
+//     issue the global f32 atomics directly -- 8 consecutive floats per splat = one L2 request (the reference issues 12
+//     atomics per PIXEL pair, backward.cu:613-672);
 //   * the "power > 0" skip (backward.cu:583-585) is not evaluated: for a positive-definite conic it can only fire on
 //     rounding noise at pixels where G = 1 to 1e-6 (deviations).
 // LDS layouts of the per-wave slot buffer, bank-conflict free for the flush (searched by brute force over strides and row
