@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--views-per-step", type=int, default=8,
                     help="view mode: views per rank whose gradients are summed before the all-reduce (one optimizer "
                          "step's view batch per rank)")
+    ap.add_argument("--unit-backward", type=int, default=0, choices=[0, 3, 4],
+                    help="A/B: backward compositor of the unit-colour view path (cgs_set_unit_backward); 0 = library default")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -134,6 +136,8 @@ def main():
     from curve_gaussian_amd.diff_cur_rasterization import _C
     from curve_gaussian_amd.ops import curve_sampling
     lib = L.load()
+    if args.unit_backward:
+        lib.cgs_set_unit_backward(args.unit_backward)
 
     # ---------------------------------------------------------------- workload (resident in HBM before timing)
     K, Wm = args.steps, args.warmup

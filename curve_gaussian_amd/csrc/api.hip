@@ -120,10 +120,9 @@ static hipError_t zero_async(void* p, size_t bytes, hipStream_t s) {
     return hipGetLastError();
 }
 
-static inline bool fuse_sort() {   // CGS_FUSE_SORT=0 keeps the separate per-tile sort kernel (A/B measurements)
-    static const bool on = !(getenv("CGS_FUSE_SORT") && getenv("CGS_FUSE_SORT")[0] == '0');
-    return on;
-}
+static std::atomic<int> g_unit_bwd{4};     // backward compositor of the unit-colour view path: 4 = pair-major (render_unit_bwd.hip), 3 = pixel-major k_render_bwd3<UNIT>
+static std::atomic<int> g_fuse_sort{1};    // tile sort inside the forward compositor (cgs_set_fused_tile_sort)
+static inline bool fuse_sort() { return g_fuse_sort.load(std::memory_order_relaxed) != 0; }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace cgs
@@ -159,6 +158,13 @@ void cgs_reset_binning_hints(void) {
 }
 int cgs_set_tile_culling(int on) {
     return g_tile_cull.exchange(on ? 1 : 0, std::memory_order_relaxed);
+}
+int cgs_set_fused_tile_sort(int on) {
+    return g_fuse_sort.exchange(on ? 1 : 0, std::memory_order_relaxed);
+}
+int cgs_set_unit_backward(int variant) {
+    if (variant != 3 && variant != 4) return g_unit_bwd.load(std::memory_order_relaxed);
+    return g_unit_bwd.exchange(variant, std::memory_order_relaxed);
 }
 void cgs_prof_enable(int on) { g_prof_on = on != 0; }
 void cgs_prof_reset(void) {
@@ -662,8 +668,12 @@ int cgs_view_backward(int B, int m, const float* curve_points, const float* widt
     float* g_scl = scratch + (size_t)P * 12;   // [P,3]
     // training configuration: only dL/dcolour flows in, the colours themselves need no gradient; the forward wrote unit
     // colours unless it was given colors_precomp (same argument here): closed-form dL/dalpha, no recurrences (render.hip, UNIT)
-    launch_render_bwd(s, false, false, false, tiles, img.ranges, bin.point_list, width_px, height_px, gx, background, geom.rec,
-                      img.final_T, img.n_contrib, dL_dout_color, nullptr, nullptr, geom.grad_acc, colors_precomp == nullptr);
+    if (colors_precomp == nullptr && g_unit_bwd.load(std::memory_order_relaxed) == 4)
+        launch_render_bwd_unit(s, tiles, img.ranges, bin.point_list, width_px, height_px, gx, background, geom.rec, img.final_T,
+                               img.n_contrib, dL_dout_color, geom.grad_acc);
+    else
+        launch_render_bwd(s, false, false, false, tiles, img.ranges, bin.point_list, width_px, height_px, gx, background, geom.rec,
+                          img.final_T, img.n_contrib, dL_dout_color, nullptr, nullptr, geom.grad_acc, colors_precomp == nullptr);
     launch_view_backward(s, B, m, curve_points, width, is_bezier, coef, eps, norms, opacity_logit, mask_logit, mask_thr,
                          cam_pos, viewmatrix, projmatrix, tan_fovx, tan_fovy, focal_x, focal_y, width_px, height_px, radii,
                          geom.rec, geom.grad_acc, dL_drotation_extra, dL_dmeans2D, dL_dopacity_logit, dL_dmask_logit, g_xyz,

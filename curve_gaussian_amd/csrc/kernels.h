@@ -60,6 +60,11 @@ void launch_render_bwd(hipStream_t s, bool geo, bool invd, bool colg, int tiles,
                        bool unit = false);   // unit: colour == 1 for every splat (render.hip, UNIT)
 
 
+// render_unit_bwd.hip: the unit-colour training instance (colour == 1, only dL/dcolour flowing in), lane = (splat, quadrant)
+void launch_render_bwd_unit(hipStream_t s, int tiles, const uint2* ranges, const uint32_t* point_list, int W, int H,
+                            int grid_x, const float* bg_color, const SplatRec* rec, const float* final_Ts,
+                            const uint32_t* n_contrib, const float* dL_dpixels, float* grad_acc);
+
 // sampling.hip
 int sample_norm_words();
 void launch_sample_norms(hipStream_t s, int B, int m, const float* cp, const uint8_t* is_bezier, const void* coef, double* norms);

@@ -2,27 +2,29 @@
 // (reference K8, backward.cu:451-675).
 //
 // Mapping (gfx950, wave64): one workgroup = 256 threads = 4 waves per 16x16 tile; wave w owns the 8x8 pixel
-// quadrant (w&1, w>>1) (lane l -> x = l&7, y = l>>3).  Per 256-splat batch:
+// quadrant (w&1, w>>1) (lane l -> x = l&7, y = l>>3).  Per batch of staged splats:
 //   1. staging: thread t gathers splat t's 64-byte record into LDS and tests the splat's alpha>=1/255 ellipse
 //      against each of the four quadrant rectangles (exact convex-quadratic minimum over a box, conservative
 //      margin).  The four per-quadrant 64-bit ballots of each staging wave are stored in LDS.
-//   2. compositing: every wave walks ONLY the set bits of its own quadrant's masks (scalar s_ff1 loop), so a
-//      splat that cannot touch a quadrant costs that wave nothing.  LDS reads are wave-uniform broadcasts.
+//   2. lists: every wave compacts the set bits of its own quadrant's ballots (mbcnt) into a private list of LDS
+//      offsets, so a splat that cannot touch a quadrant costs that wave nothing; the walk over it is a counted loop.
+//   3. exponents: log2(alpha) of 16 listed splats x 64 pixels comes out of two bf16 MFMAs (p2_mfma.h): lane = pixel,
+//      accumulator register = splat.  The vector ALU is left with exp2, the alpha tests and the blend.
 // Results are identical to visiting every splat: a culled (splat, quadrant) pair has alpha < 1/255 at all 64 pixels.
 //
-// Backward reduction: per accepted (wave, splat) pair the 64 per-pixel partials of each gradient field are summed
-// inside 16-lane DPP rows (4 v_add_f32_dpp), parked in column (j & 15) of a per-wave register tile, and every 16
-// splats the tile is reduced across rows (v_permlane16/32_swap) and flushed with one global f32 atomic per
-// (quadrant, splat, field) -- no LDS atomics, no per-pixel global atomics (the reference issues 12 per pixel pair,
-// backward.cu:613-672).
+// Backward reduction (k_render_bwd3): the per-pixel g = alpha_u dL/dalpha of eight pairs are parked in a per-wave LDS
+// slot buffer, folded into the six moments sum g {1, dx, dy, dx^2, dx dy, dy^2} splat-parallel (lane = (slot, pixel
+// row)), and the per-(quadrant, splat) sums are parked at the pair's list position; one combining pass per batch adds
+// the up-to-four quadrant sums of an instance and issues ONE 6-float atomic request per (tile, splat) instance (the
+// reference issues 12 atomics per pixel pair, backward.cu:613-672).  The unit-colour training instance of the view entry
+// points has its own kernel with lane = (splat, quadrant) pair: render_unit_bwd.hip.
 #include "kernels.h"
 #include "p2_mfma.h"
-#include <stdlib.h>
+#include "composite.h"
 
 namespace cgs {
 
 constexpr int BATCH = 256;
-constexpr float ALPHA_MIN = 1.0f / 255.0f;
 // [x > t] as a 0/1 float with one instruction (v_fma_f32 ... clamp): scaling by 2^100 is exact and any non-zero difference
 // of two floats of these magnitudes times 2^100 exceeds 1, so the saturated product is exactly the step function.
 // [x >= thr] is [x > pred(thr)], pred = the next float below.
@@ -41,91 +43,6 @@ __device__ __forceinline__ StepConsts step_consts() {
 }
 constexpr int SLOTS = 8;          // accepted splats buffered per wave between two splat-parallel moment passes
 
-struct TileGeom {
-    uint32_t tile, tx, ty;
-    int wave, lane;
-    int px, py;  // this lane's pixel
-    bool inside;
-    uint32_t pix_id;
-};
-__device__ __forceinline__ TileGeom tile_geom(int W, int H, int grid_x) {
-    TileGeom g;
-    g.tile = blockIdx.x;
-    g.tx = g.tile % grid_x;
-    g.ty = g.tile / grid_x;
-    g.wave = threadIdx.x >> 6;
-    g.lane = threadIdx.x & 63;
-    const int lx = ((g.wave & 1) << 3) | (g.lane & 7);
-    const int ly = ((g.wave >> 1) << 3) | (g.lane >> 3);
-    g.px = g.tx * TILE + lx;
-    g.py = g.ty * TILE + ly;
-    g.inside = g.px < W && g.py < H;
-    g.pix_id = (uint32_t)(W * g.py + g.px);
-    return g;
-}
-
-// min over the box dx in [l,r], dy in [b,t] of q(dx,dy) = A dx^2 + 2 B dx dy + C dy^2  (A,C > 0, AC > B^2)
-__device__ __forceinline__ float quad_min_box(float A, float B, float C, float rA, float rC, float l, float r, float b,
-                                              float t) {
-    if (l <= 0.f && r >= 0.f && b <= 0.f && t >= 0.f) return 0.f;
-    float m;
-    {
-        const float d = fminf(fmaxf(-B * l * rC, b), t);
-        m = A * l * l + (2.f * B * l + C * d) * d;
-    }
-    {
-        const float d = fminf(fmaxf(-B * r * rC, b), t);
-        m = fminf(m, A * r * r + (2.f * B * r + C * d) * d);
-    }
-    {
-        const float d = fminf(fmaxf(-B * b * rA, l), r);
-        m = fminf(m, C * b * b + (2.f * B * b + A * d) * d);
-    }
-    {
-        const float d = fminf(fmaxf(-B * t * rA, l), r);
-        m = fminf(m, C * t * t + (2.f * B * t + A * d) * d);
-    }
-    return m;
-}
-
-// 4-bit mask: bit q set iff the splat may reach alpha >= 1/255 somewhere in quadrant q of the tile at (X0,Y0).
-// power = -0.5 q  and  alpha = op * exp(power) >= 1/255  <=>  q <= 2 ln(255 op) =: tau2 (stored in rec.d.z).
-__device__ __forceinline__ uint32_t quadrant_mask(const float4 a, const float4 b, float tau2, float X0, float Y0) {
-    if (!(tau2 >= 0.f)) return 0u;  // opacity < 1/255 (or NaN): never blended
-    const float A = a.z, B = a.w, C = b.x;
-    const float rA = __builtin_amdgcn_rcpf(A), rC = __builtin_amdgcn_rcpf(C);
-    // Conservative acceptance: slack = fixed margin + a bound on the float cancellation error of the quadratic form
-    // (both here and in the compositor's per-pixel evaluation), which scales with the magnitude of its terms.
-    const float lim = tau2 * 1.001f + 1e-3f;
-    const float l0 = X0 - a.x, b0 = Y0 - a.y;
-    uint32_t m = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const float l = l0 + (float)((q & 1) * 8), bb = b0 + (float)((q >> 1) * 8);
-        const float v = quad_min_box(A, B, C, rA, rC, l, l + 7.f, bb, bb + 7.f);
-        const float X = fmaxf(fabsf(l), fabsf(l + 7.f)), Y = fmaxf(fabsf(bb), fabsf(bb + 7.f));
-        const float mag = A * X * X + 2.f * fabsf(B) * X * Y + C * Y * Y;
-        m |= (v <= lim + 8e-6f * mag) ? (1u << q) : 0u;
-    }
-    return m;
-}
-
-__device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
-__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
-
-// Staged per-splat constants (LDS): the conic is pre-scaled so the compositor evaluates
-//   log2(G) = dx (A2 dx + B2 dy) + C2 dy dy   with  A2 = -0.5 A log2e, B2 = -B log2e, C2 = -0.5 C log2e
-// and G = exp2(.) is a single v_exp_f32.  (power > 0  <=>  log2(G) > 0.)
-constexpr float LOG2E = 1.4426950408889634f;
-__device__ __forceinline__ void stage_splat(const float4 a, const float4 b, float4& sa, float4& sb) {
-    sa = make_float4(a.x, a.y, (-0.5f * LOG2E) * a.z, -LOG2E * a.w);
-    sb = make_float4((-0.5f * LOG2E) * b.x, b.y, b.z, b.w);
-}
-
 // ------------------------------------------------------------------------------------------------ forward
 // What the SORT variant needs to turn a tile's unsorted bucket into its depth-ordered list (single-pass bucket binning).
 struct BucketSort {
@@ -136,211 +53,6 @@ struct BucketSort {
     uint32_t* total;             // status words: partial sums / maxima, overflow flag
     uint32_t cap;                // bucket capacity (<= RANK_MAX for this kernel)
 };
-
-// SORT = true fuses the per-tile depth sort of the bucket layout into the compositor: the workgroup rank-sorts its own
-// bucket (same scheme as k_tile_rank_sort: 32-bit depths, collision -> full keys), keeps the ordered indices in LDS for
-// its staging loads and writes them out for the backward.  The sort is bound by dependent-load latency and the
-// compositing by VALU issue, so inside one kernel the two overlap across the workgroups of a CU instead of running
-// back to back (tile_sort 38 us + render_fwd 155 us -> 170 us).
-template <bool GEO, bool SORT>
-__global__ void __launch_bounds__(256) k_render_fwd(const uint2* __restrict__ ranges,
-                                                    const uint32_t* __restrict__ point_list, int W, int H, int grid_x,
-                                                    const SplatRec* __restrict__ rec, float* __restrict__ final_T,
-                                                    uint32_t* __restrict__ n_contrib, const float* __restrict__ bg_color,
-                                                    float* __restrict__ out_color, float* __restrict__ out_invdepth,
-                                                    float* __restrict__ out_all_map, BucketSort bs) {
-    __shared__ float4 s_a[BATCH + 1];   // entry BATCH: all zeros (opacity 0), the partner of an odd tail
-    __shared__ float4 s_b[BATCH + 1];
-    __shared__ float4 s_c[GEO ? BATCH + 1 : 1];
-    __shared__ uint64_t s_qmask[4][4];  // [quadrant][64-splat chunk]
-    __shared__ uint32_t s_ord[SORT ? RANK_MAX + RANK_U : 1];  // depths -> claim array -> ordered splat indices
-    __shared__ uint32_t s_si[SORT ? RANK_MAX : 1];            // (scratch of tile_rank_sort, common.h)
-    __shared__ uint32_t s_hist[SORT ? RANK_NB : 1], s_start[SORT ? RANK_NB + 1 : 1], s_mm[8];
-    if (threadIdx.x == 0) {
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        s_a[BATCH] = z;
-        s_b[BATCH] = z;
-        if (GEO) s_c[GEO ? BATCH : 0] = z;
-    }
-    const TileGeom g = tile_geom(W, H, grid_x);
-    const float pixfx = (float)g.px, pixfy = (float)g.py;
-    const float X0 = (float)(g.tx * TILE), Y0 = (float)(g.ty * TILE);
-    uint2 range;
-    if (SORT) {
-        const uint32_t tid = threadIdx.x;
-        const uint32_t cnt = bs.tile_count[g.tile];
-        const uint32_t n = min(cnt, bs.cap);
-        const uint32_t base = g.tile * bs.cap;
-        range = make_uint2(base, base + n);
-        if (tid == 0) {
-            bs.ranges[g.tile] = range;
-            if (cnt) {
-                uint32_t* part = bs.total + 4 + 2 * (g.tile % TOTAL_PARTS);
-                atomicAdd(&part[0], n);
-                atomicMax(&part[1], cnt);
-                if (cnt > bs.cap) {
-                    bs.total[2] = 1u;
-                    atomicAdd(&bs.total[TOTAL_WORDS], 1u);   // sticky: survives the next forward's clear
-                }
-            }
-        }
-        if (n > 0) {   // block-uniform
-            uint32_t rank[4], idx[4];
-            tile_rank_sort<4>(bs.keys + base, n, RankScratch{s_ord, s_si, s_hist, s_start, s_mm}, rank, idx);
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t i = tid + 256u * q;
-                if (i < n) {
-                    s_ord[rank[q]] = idx[q];
-                    bs.point_list[base + rank[q]] = idx[q];
-                }
-            }
-            __syncthreads();
-        }
-    } else {
-        range = ranges[g.tile];
-    }
-    const int total = (int)(range.y - range.x);
-    const int rounds = (total + BATCH - 1) / BATCH;
-    // Per-lane state, branch- and predicate-free: Tw is the WORKING transmittance -- equal to T while the pixel is live
-    // and forced to 0 once it terminates (reference: done = true), so a dead pixel blends nothing and can never pass the
-    // T test again; T_dead catches the transmittance at termination (what the reference leaves in final_T).  The
-    // reference's three tests are evaluated as 0/1 floats (step_gt) and multiplied in: v_cmp / v_cndmask issue at half
-    // the rate of fma / mul on CDNA4 (4 vs 2 cycles per wave instruction, profiles/probes/valu_probe.hip) and the first
-    // version's 3 compares + 5 selects were 36 of its ~78 issue cycles per pair; no exec-mask or SGPR-pair bookkeeping
-    // either (the scalar unit was the bottleneck before that: ~30 SALU per splat vs ~9).
-    const StepConsts k = step_consts();
-    // Per-lane state.  A live pixel carries its transmittance in Tw and the acceptance constant cA = -pred(1/255) 2^100 of
-    // the [alpha >= 1/255] step; when a pixel terminates (reference: done = true) its transmittance is parked in T_dead,
-    // Tw becomes 1 and cA -huge, so every later alpha evaluates to a_eff = 0: the pixel blends nothing and its
-    // test_T = Tw = 1 never trips the termination test again -- no per-pair bookkeeping for dead pixels.
-    float T_dead = 0.0f;
-    float Tw = 1.0f;
-    float cA = g.inside ? k.cA : -0x1p126f;
-    uint32_t last_contributor = 0;
-    float C = 0.f, Dacc = 0.f;
-    float A0 = 0.f, A1 = 0.f, A2 = 0.f, A3 = 0.f;
-    bool wave_done = ballot64(cA > -0x1p120f) == 0ull;
-    for (int i = 0; i < rounds; i++) {
-        // vote: stop when every wave is finished (reference: __syncthreads_count(done) == BLOCK_SIZE); this barrier
-        // also guarantees every wave is done with the previous batch's staged data
-        if (!__syncthreads_or(!wave_done)) break;
-        const int progress = i * BATCH + threadIdx.x;
-        uint32_t qm = 0;
-        if (progress < total) {
-            const uint32_t id = SORT ? s_ord[progress] : point_list[range.x + progress];
-            const SplatRec* r = rec + id;
-            const float4 a = r->a, b = r->b;
-            float4 sa, sb;
-            stage_splat(a, b, sa, sb);
-            s_a[threadIdx.x] = sa;
-            s_b[threadIdx.x] = sb;
-            if (GEO) s_c[threadIdx.x] = r->c;
-            qm = quadrant_mask(a, b, r->d.z, X0, Y0);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint64_t bal = ballot64((qm >> q) & 1u);
-            if (g.lane == 0) s_qmask[q][g.wave] = bal;
-        }
-        __syncthreads();
-        if (wave_done) continue;
-        const uint32_t base = (uint32_t)(i * BATCH) + 1u;
-        // Two splats per trip: everything up to a_eff (loads, quadratic form, exp, the two skip tests) is independent of
-        // the pixel's state, only the three-fma transmittance update is sequential -- the loop is bound by the latency of
-        // one wave's dependent chain (instruction-count reductions alone did not move it), so the second splat's chain
-        // runs in the shadow of the first.  An odd tail pairs with the all-zero entry BATCH (alpha = 0: never a hit).
-        struct Eval { float a_eff; float col, invd; float4 cc; uint32_t pos1; };
-        auto eval = [&](int j) {
-            Eval e;
-            const float4 a = s_a[j];
-            const float4 b = s_b[j];
-            const float dx = a.x - pixfx, dy = a.y - pixfy;
-            const float p2 = dx * (a.z * dx + a.w * dy) + b.x * dy * dy;
-            const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(p2));
-            // reference: alpha < 1/255 -> skip.  (Its power > 0 skip, forward.cu:362-363, cannot fire for a positive
-            // definite conic except on rounding noise where G = 1 to 1e-6: not evaluated, DESIGN.md deviations.)
-            const float hA = sat01(fmaf(alpha, k.big, cA));           // [alpha >= 1/255] and the pixel is live
-            e.a_eff = alpha * hA;                                     // alpha if hit, else 0
-            e.col = b.z;
-            e.invd = b.w;
-            if (GEO) e.cc = s_c[j];
-            e.pos1 = base + (uint32_t)j;
-            return e;
-        };
-        // The two splats of a trip are blended together.  reference forward.cu:371-376: a hit that would take T below 1e-4
-        // terminates the pixel and is NOT blended -- at most once per pixel, so it is one compare and a wave-uniform
-        // branch per trip (the transmittance after both splats is below 1e-4 iff either of them trips the test), and
-        // the slow path redoes the two steps one by one.
-        auto blend2 = [&](const Eval& e0, const Eval& e1) {
-            float w0 = e0.a_eff * Tw;
-            float T1 = fmaf(-Tw, e0.a_eff, Tw);
-            float w1 = e1.a_eff * T1;
-            float T2 = fmaf(-T1, e1.a_eff, T1);
-            if (__builtin_expect(ballot64(T2 < 0.0001f) != 0ull, 0)) {
-                const bool d0 = T1 < 0.0001f;                 // dies on the first splat: neither is blended
-                T_dead = d0 ? Tw : T_dead;
-                w0 = d0 ? 0.f : w0;
-                T1 = d0 ? 1.0f : T1;
-                const float a1 = d0 ? 0.f : e1.a_eff;
-                w1 = a1 * T1;
-                T2 = fmaf(-T1, a1, T1);
-                const bool d1 = T2 < 0.0001f;                 // dies on the second: the first is blended
-                T_dead = d1 ? T1 : T_dead;
-                w1 = d1 ? 0.f : w1;
-                T2 = d1 ? 1.0f : T2;
-                cA = (d0 || d1) ? -0x1p126f : cA;
-            }
-            Tw = T2;
-            C = fmaf(e0.col, w0, C);
-            Dacc = fmaf(e0.invd, w0, Dacc);
-            if (GEO) { A0 = fmaf(e0.cc.x, w0, A0); A1 = fmaf(e0.cc.y, w0, A1); A2 = fmaf(e0.cc.z, w0, A2); A3 = fmaf(e0.cc.w, w0, A3); }
-            C = fmaf(e1.col, w1, C);
-            Dacc = fmaf(e1.invd, w1, Dacc);
-            if (GEO) { A0 = fmaf(e1.cc.x, w1, A0); A1 = fmaf(e1.cc.y, w1, A1); A2 = fmaf(e1.cc.z, w1, A2); A3 = fmaf(e1.cc.w, w1, A3); }
-            // 1-based list position of the last blended splat: w > 0 exactly when a splat was blended, its bit pattern
-            // then exceeds any list position, and positions only grow -> the median of the three
-            last_contributor = max(min(last_contributor, e0.pos1), min(max(last_contributor, e0.pos1), __float_as_uint(w0)));  // v_med3_u32
-            last_contributor = max(min(last_contributor, e1.pos1), min(max(last_contributor, e1.pos1), __float_as_uint(w1)));
-        };
-#pragma unroll 1
-        for (int c = 0; c < 4; c++) {
-            uint64_t m = uniform64(s_qmask[g.wave][c]);
-            while (m) {
-                const int j0 = c * 64 + __builtin_ctzll(m);
-                m &= m - 1;
-                const int j1 = m ? c * 64 + __builtin_ctzll(m) : BATCH;
-                m &= m - 1;    // (0 & anything = 0)
-                const Eval e0 = eval(j0);
-                const Eval e1 = eval(j1);
-                blend2(e0, e1);
-            }
-            if (ballot64(cA > -0x1p120f) == 0ull) {  // checked once per 64-splat chunk
-                wave_done = true;
-                break;
-            }
-        }
-    }
-    if (g.inside) {
-        const size_t HW = (size_t)H * W;
-        const float T = cA > -0x1p120f ? Tw : T_dead;   // live: Tw; terminated: the transmittance it stopped at
-        final_T[g.pix_id] = T;
-        n_contrib[g.pix_id] = last_contributor;
-        out_color[g.pix_id] = C + T * bg_color[0];
-        out_invdepth[g.pix_id] = Dacc;
-        if (GEO) {
-            out_all_map[g.pix_id] = A0;
-            out_all_map[HW + g.pix_id] = A1;
-            out_all_map[2 * HW + g.pix_id] = A2;
-            out_all_map[3 * HW + g.pix_id] = A3;
-        } else {
-            out_all_map[g.pix_id] = 0.f;
-            out_all_map[HW + g.pix_id] = 0.f;
-            out_all_map[2 * HW + g.pix_id] = 0.f;
-            out_all_map[3 * HW + g.pix_id] = 0.f;
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------ forward, v3
 // Same per-pixel arithmetic after the exponent, but the exponent itself -- log2(alpha) of every (pixel, splat) pair, a
@@ -368,7 +80,6 @@ constexpr int GROUP = 16;
 constexpr int BWD_BATCH = 128;   // splats staged per round by the backward (its LDS also holds the per-quadrant sums)
 constexpr uint32_t BWD_PAD_OFF = (BWD_BATCH + 1) * 16;
 constexpr uint32_t PAD_OFF = (BATCH + 1) * 16;   // byte offset of the padding entry in the staged arrays
-constexpr float L2_NEVER = -1000.f;   // log2 "opacity" of the padding entry: alpha = exp2(-1000) = 0
 
 // UNIT: the caller guarantees colour == 1 and all_map[3] == 1 for every splat (the view entry point builds both itself:
 // unit features, gaussian_renderer/__init__.py:97,104).  Then sum w c = sum w = 1 - T (w_i = T_i - T_{i+1} telescopes), and
@@ -600,9 +311,6 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-__device__ __forceinline__ float dpp_row_ror8(float v) {  // lane i <- lane i^8 (rotate by 8 inside each 16-lane row)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
-}
 // column-wise sum over the four 16-lane rows, result replicated in every row
 __device__ __forceinline__ float rows_sum(float v) {
     const unsigned x = __float_as_uint(v);
@@ -611,24 +319,6 @@ __device__ __forceinline__ float rows_sum(float v) {
     const unsigned y = __float_as_uint(t);
     auto s32 = __builtin_amdgcn_permlane32_swap(y, y, false, false);  // [lo lo], [hi hi]
     return __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
-}
-
-// Row sums of FOUR values at once: returns, in row r (r = lane >> 4), the sum over the four rows of the r-th argument
-// (column-wise).  v_permlane16_swap(X, Y) leaves X = [X0 Y0 X2 Y2], Y = [X1 Y1 X3 Y3]; v_permlane32_swap(X, Y) leaves
-// X = [Xlo Ylo], Y = [Xhi Yhi].
-__device__ __forceinline__ float rows_pair16(float a, float b) {  // -> [a0+a1, b0+b1, a2+a3, b2+b3]
-    auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
-}
-__device__ __forceinline__ float rows_sum4(float a, float b, float c, float d) {
-    const float ab = rows_pair16(a, b), cd = rows_pair16(c, d);
-    auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(ab), __float_as_uint(cd), false, false);
-    return __uint_as_float(s[0]) + __uint_as_float(s[1]);   // [a, b, c, d]
-}
-__device__ __forceinline__ float rows_sum2(float a, float b) {     // -> [a, b, a, b]
-    const float ab = rows_pair16(a, b);
-    auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(ab), __float_as_uint(ab), false, false);
-    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -995,32 +685,17 @@ __global__ void __launch_bounds__(256, GEO ? 2 : (INVD || COLG) ? 4 : CGS_BWD3_W
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
+#define CGS_FWD3(G, S, U, R, PL, BS)                                                                                  \
+    hipLaunchKernelGGL((k_render_fwd3<G, S, U>), dim3(tiles), dim3(256), 0, s, R, PL, W, H, grid_x, rec, final_T,     \
+                       n_contrib, bg_color, out_color, out_invdepth, out_all_map, BS)
 void launch_render_fwd(hipStream_t s, bool geo, int tiles, const uint2* ranges, const uint32_t* point_list, int W,
                        int H, int grid_x, const SplatRec* rec, float* final_T, uint32_t* n_contrib,
                        const float* bg_color, float* out_color, float* out_invdepth, float* out_all_map, bool unit) {
     ProfScope p("render_fwd", s);
-    static const bool v2 = getenv("CGS_FWD_V2") && getenv("CGS_FWD_V2")[0] == '1';   // A/B: exponent on the vector ALU
-    if (!v2) {
-        if (geo && unit)
-            hipLaunchKernelGGL((k_render_fwd3<true, false, true>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H, grid_x,
-                               rec, final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, BucketSort{});
-        else if (unit)
-            hipLaunchKernelGGL((k_render_fwd3<false, false, true>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H, grid_x,
-                               rec, final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, BucketSort{});
-        else if (geo)
-            hipLaunchKernelGGL((k_render_fwd3<true, false>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H, grid_x, rec,
-                               final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, BucketSort{});
-        else
-            hipLaunchKernelGGL((k_render_fwd3<false, false>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H, grid_x, rec,
-                               final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, BucketSort{});
-        return;
-    }
-    if (geo)
-        hipLaunchKernelGGL((k_render_fwd<true, false>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H, grid_x, rec,
-                           final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, BucketSort{});
-    else
-        hipLaunchKernelGGL((k_render_fwd<false, false>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H, grid_x, rec,
-                           final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, BucketSort{});
+    if (geo && unit) CGS_FWD3(true, false, true, ranges, point_list, BucketSort{});
+    else if (unit) CGS_FWD3(false, false, true, ranges, point_list, BucketSort{});
+    else if (geo) CGS_FWD3(true, false, false, ranges, point_list, BucketSort{});
+    else CGS_FWD3(false, false, false, ranges, point_list, BucketSort{});
 }
 bool render_fwd_can_sort(uint32_t cap) { return cap <= RANK_MAX; }
 void launch_render_fwd_sorting(hipStream_t s, bool geo, int tiles, const uint32_t* tile_count, const uint64_t* keys,
@@ -1028,30 +703,15 @@ void launch_render_fwd_sorting(hipStream_t s, bool geo, int tiles, const uint32_
                                int grid_x, const SplatRec* rec, float* final_T, uint32_t* n_contrib,
                                const float* bg_color, float* out_color, float* out_invdepth, float* out_all_map, bool unit) {
     ProfScope p("render_fwd", s);
-    BucketSort bs{tile_count, keys, point_list, ranges, total, cap};
-    static const bool v2 = getenv("CGS_FWD_V2") && getenv("CGS_FWD_V2")[0] == '1';
-    if (!v2) {
-        if (geo && unit)
-            hipLaunchKernelGGL((k_render_fwd3<true, true, true>), dim3(tiles), dim3(256), 0, s, nullptr, nullptr, W, H, grid_x, rec,
-                               final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, bs);
-        else if (unit)
-            hipLaunchKernelGGL((k_render_fwd3<false, true, true>), dim3(tiles), dim3(256), 0, s, nullptr, nullptr, W, H, grid_x, rec,
-                               final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, bs);
-        else if (geo)
-            hipLaunchKernelGGL((k_render_fwd3<true, true>), dim3(tiles), dim3(256), 0, s, nullptr, nullptr, W, H, grid_x, rec,
-                               final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, bs);
-        else
-            hipLaunchKernelGGL((k_render_fwd3<false, true>), dim3(tiles), dim3(256), 0, s, nullptr, nullptr, W, H, grid_x, rec,
-                               final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, bs);
-        return;
-    }
-    if (geo)
-        hipLaunchKernelGGL((k_render_fwd<true, true>), dim3(tiles), dim3(256), 0, s, nullptr, nullptr, W, H, grid_x, rec,
-                           final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, bs);
-    else
-        hipLaunchKernelGGL((k_render_fwd<false, true>), dim3(tiles), dim3(256), 0, s, nullptr, nullptr, W, H, grid_x, rec,
-                           final_T, n_contrib, bg_color, out_color, out_invdepth, out_all_map, bs);
+    const BucketSort bs{tile_count, keys, point_list, ranges, total, cap};
+    const uint2* no_ranges = nullptr;
+    const uint32_t* no_list = nullptr;
+    if (geo && unit) CGS_FWD3(true, true, true, no_ranges, no_list, bs);
+    else if (unit) CGS_FWD3(false, true, true, no_ranges, no_list, bs);
+    else if (geo) CGS_FWD3(true, true, false, no_ranges, no_list, bs);
+    else CGS_FWD3(false, true, false, no_ranges, no_list, bs);
 }
+#undef CGS_FWD3
 void launch_render_bwd(hipStream_t s, bool geo, bool invd, bool colg, int tiles, const uint2* ranges,
                        const uint32_t* point_list, int W, int H, int grid_x, const float* bg_color,
                        const SplatRec* rec, const float* final_Ts, const uint32_t* n_contrib, const float* dL_dpixels,

@@ -306,6 +306,14 @@ int cgs_knn_mean_dist2(int P, const float* points /*[P,3]*/, float* mean_dist2 /
  * num_rendered and the per-tile lists are bit-identical to the reference's.  Returns the previous setting.
  * ------------------------------------------------------------------------------------------------ */
 int cgs_set_tile_culling(int on);
+/* A/B switches for measurements (process-wide; each returns the previous setting).
+ *   cgs_set_fused_tile_sort: 1 (default) = the sync-free forward sorts each tile's bucket inside the compositor kernel when the
+ *     bucket capacity allows; 0 = separate per-tile sort launch.
+ *   cgs_set_unit_backward: backward compositor of the unit-colour view path (cgs_view_backward without colors_precomp):
+ *     4 (default) = pair-major kernel (lane = (splat, quadrant) pair, csrc/render_unit_bwd.hip), 3 = the pixel-major
+ *     k_render_bwd3<UNIT>.  Same results to rounding.  Any other value only queries. */
+int cgs_set_fused_tile_sort(int on);
+int cgs_set_unit_backward(int variant);
 /* Introspection of the calling thread's last cgs_rasterize_forward: num_rendered, the longest per-tile list and
  * which binning path produced it (0 = exact count/scan/scatter layout, 1 = single-pass fixed-capacity buckets). */
 /* ------------------------------------------------------------------------------------------------
