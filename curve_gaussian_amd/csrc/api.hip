@@ -577,7 +577,8 @@ int cgs_view_forward(int B, int m, const float* curve_points, const float* width
                      float* scaling, void* stream_) {
     hipStream_t s = (hipStream_t)stream_;
     const int P = B * m;
-    if (B <= 0 || m <= 0 || m > 32 || width_px <= 0 || height_px <= 0 || !curve_points || !width || !coef || !norms ||
+    if (B <= 0 || m <= 0 || m > 32 || (long long)B * m >= (1ll << 28) || width_px <= 0 || height_px <= 0 || !curve_points ||
+        !width || !coef || !norms ||
         !opacity_logit || !geometry_buffer || !binning_buffer || !image_buffer || bucket_capacity == 0 || !background ||
         !viewmatrix || !projmatrix || !cam_pos || !out_color || (!out_invdepth != !out_all_map) ||
         (!out_all_map && colors_precomp) || !radii || (xyz && (!rotation || !scaling)) || !aligned16(curve_points) || !aligned16(coef) || !aligned16(rotation)) {

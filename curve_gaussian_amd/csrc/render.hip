@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
                 const uint32_t i = tid + 256u * q;
                 if (i < n) {
                     s_ord[rank[q]] = idx[q];
-                    bs.point_list[base + rank[q]] = idx[q];
+                    if (!UNIT) bs.point_list[base + rank[q]] = idx[q];   // (UNIT: written at staging time, tagged)
                 }
             }
             __syncthreads();
@@ -183,6 +183,10 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
             // UNIT: all_map[3] == 1 is not read back, its slot carries 1/depth -- one 16-byte read per pair instead of two reads
             if (GEO) s_c[threadIdx.x + 1] = UNIT ? make_float4(r->c.x, r->c.y, r->c.z, sb.w) : r->c;
             qm = quadrant_mask(a, b, r->d.z, X0, Y0);   // (0 unless opacity >= 1/255: the log is finite for every listed entry)
+            // UNIT (view entry points): the list entry carries the quadrant mask in its top four bits for the backward of the
+            // same view (LIST_ID_MASK / LIST_TAG_SHIFT, composite.h) -- its staging then needs no reach test.  Entries of
+            // batches this workgroup never stages (every pixel terminated before) lie behind every pixel's cut.
+            if (UNIT) const_cast<uint32_t*>(SORT ? bs.point_list : point_list)[range.x + progress] = id | (qm << LIST_TAG_SHIFT);
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -450,7 +454,7 @@ __global__ void __launch_bounds__(256, GEO ? 2 : (INVD || COLG) ? 4 : CGS_BWD3_W
         const int progress = i * BB + threadIdx.x;
         uint32_t qm = 0;
         if (threadIdx.x < BB && progress < total) {
-            const uint32_t id = point_list[range.y - progress - 1];  // back to front (backward.cu:554)
+            const uint32_t id = point_list[range.y - progress - 1] & (UNIT ? LIST_ID_MASK : 0xffffffffu);  // back to front (backward.cu:554)
             const SplatRec* r = rec + id;
             const float4 a = r->a, b = r->b;
             float4 sa, sb;

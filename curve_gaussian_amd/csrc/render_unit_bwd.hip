@@ -83,14 +83,45 @@ __device__ __forceinline__ P2Frag ub_pixel_operand(int lane, int block) {
     return f;
 }
 
+// Constants of the walk, kept in VGPRs on purpose (opaque to the compiler): a VOP2 with a literal or scalar operand issues
+// slower than one on registers (profiles/probes/enc_probe.hip).
+struct WalkConsts { float one, floor01, amin; };
+__device__ __forceinline__ WalkConsts walk_consts() {
+    WalkConsts k;
+    k.one = 1.0f;
+    k.floor01 = 1.0f - 0.99f;    // 1 - min(0.99, e) = max(1 - e, 1 - 0.99): the same float as the reference's 1 - alpha at the clamp
+    k.amin = ALPHA_MIN;
+    asm volatile("" : "+v"(k.one), "+v"(k.floor01), "+v"(k.amin));
+    return k;
+}
+
+// s += v in the lanes where the pair is blended at this pixel: alpha >= 1/255 (reference backward.cu:595: alpha < 1/255 ->
+// continue; !(e < 1/255) like the C oracle, e = the unclamped alpha: the 0.99 clamp cannot change the outcome) and, SLOW, the
+// entry lies in front of the pixel's cut.  v_cmpx narrows EXEC, the add runs under it, EXEC is restored: one instruction less
+// than compare + select + add.  (The walk runs in wave-uniform control flow: EXEC is all ones on entry.)
+template <bool SLOW>
+__device__ __forceinline__ void masked_add(float& s, float v, float e, float amin, uint32_t pos, uint32_t cut) {
+#ifdef CGS_UBWD_NOASM
+    bool ok = !(e < amin);
+    if (SLOW) ok = ok && pos < cut;
+    s += ok ? v : 0.f;
+    return;
+#endif
+    if (SLOW)
+        asm volatile("v_cmpx_nlt_f32_e32 vcc, %[e], %[amin]\n\tv_cmpx_lt_u32_e32 vcc, %[pos], %[cut]\n\tv_add_f32_e32 %[s], %[s], %[v]\n\ts_mov_b64 exec, -1"
+                     : [s] "+v"(s) : [e] "v"(e), [amin] "v"(amin), [pos] "v"(pos), [cut] "v"(cut), [v] "v"(v) : "vcc");
+    else
+        asm volatile("v_cmpx_nlt_f32_e32 vcc, %[e], %[amin]\n\tv_add_f32_e32 %[s], %[s], %[v]\n\ts_mov_b64 exec, -1"
+                     : [s] "+v"(s) : [e] "v"(e), [amin] "v"(amin), [v] "v"(v) : "vcc");
+}
+
 // One row of eight pixels of the lane's pair (registers r0 .. r0 + 7 of the block's exponents): g per pixel, consumed on
 // the spot by the row's three sums  R0 = sum g, R1 = sum x g, R2 = sum x^2 g  (x = 0..7).  The sums are built as running
-// suffix sums from x = 7 down -- s += g; u += s; w += u -- which needs adds only (an fma with a constant operand issues
-// slower than an add of two registers, profiles/probes) and no register per pixel:
+// suffix sums from x = 7 down -- s += g; u += s; w += u -- which needs adds only and no register per pixel:
 //     s = sum_{x>=1} g_x,  u = sum_k s_k = sum x g_x,  w = sum_k u_k = sum x (x + 1) / 2 g_x   =>   R2 = 2 w - u.
 template <bool SLOW>
 __device__ __forceinline__ void ub_walk_row(const f32x16& P, int r0, const float* __restrict__ krow, const uint32_t* __restrict__ lrow,
-                                            uint32_t pos, float& R0, float& R1, float& R2) {
+                                            uint32_t pos, const WalkConsts& k, float& R0, float& R1, float& R2) {
     float s = 0.f, u = 0.f, w = 0.f;
 #pragma unroll
     for (int rr = 1; rr >= 0; rr--) {
@@ -102,15 +133,13 @@ __device__ __forceinline__ void ub_walk_row(const f32x16& P, int r0, const float
 #pragma unroll
         for (int t = 3; t >= 0; t--) {
             const float e = __builtin_amdgcn_exp2f(P[r0 + 4 * rr + t]);   // alpha_u = opacity G
-            const float a = fminf(0.99f, e);                                // forward.cu:368 / backward.cu:593
-            bool ok = !(a < ALPHA_MIN);
-            if (SLOW) ok = ok && pos < Lv[t];                               // behind the pixel's cut: not blended
-            const float v = (e * __builtin_amdgcn_rcpf(1.f - a)) * Kv[t];
-            const float g = ok ? v : 0.f;
-            if (4 * rr + t > 0) { s += g; u += s; w += u; }
-            else R0 = s + g;
+            const float om = fmaxf(k.one - e, k.floor01);                   // 1 - alpha, alpha = min(0.99, e)  (forward.cu:368)
+            const float v = (e * Kv[t]) * __builtin_amdgcn_rcpf(om);        // g = alpha_u K / (1 - alpha)
+            masked_add<SLOW>(s, v, e, k.amin, pos, Lv[t]);
+            if (4 * rr + t > 0) { u += s; w += u; }
         }
     }
+    R0 = s;
     R1 = u;
     R2 = (w + w) - u;
 }
@@ -178,6 +207,7 @@ __global__ void __launch_bounds__(256, CGS_UBWD_WAVES) k_render_bwd_unit(
     // loop-invariant matrix-core operands (pixel side)
     const P2Frag pix0 = ub_pixel_operand(lane, 0), pix1 = ub_pixel_operand(lane, 1);
     const int n = lane & 31, hh = lane >> 5;
+    const WalkConsts wk = walk_consts();
     float* const outw = &s_out[g.wave][0][0];
 
     for (int i = 0; i < rounds; i++) {
@@ -186,14 +216,15 @@ __global__ void __launch_bounds__(256, CGS_UBWD_WAVES) k_render_bwd_unit(
         const int pos = i * UB + (int)threadIdx.x;
         uint32_t qm = 0, cutm = 0;
         if (pos < nb) {
-            const uint32_t id = point_list[range.x + pos];
+            const uint32_t tagged = point_list[range.x + pos];   // quadrant mask in the top bits (the forward's, composite.h)
+            const uint32_t id = tagged & LIST_ID_MASK;
             const SplatRec* r = rec + id;
             const float4 a = r->a, b = r->b;
             float4 sa, sb;
             stage_splat(a, b, sa, sb);
             s_geo[threadIdx.x] = sa;
             s_at[threadIdx.x] = make_float4(sb.x, __builtin_amdgcn_logf(sb.y), __uint_as_float(id), 0.f);   // v_log_f32 = log2
-            qm = quadrant_mask(a, b, r->d.z, X0, Y0);
+            qm = tagged >> LIST_TAG_SHIFT;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 if ((uint32_t)pos >= qmax[q]) qm &= ~(1u << q);   // behind everything this quadrant blended
@@ -263,12 +294,12 @@ __global__ void __launch_bounds__(256, CGS_UBWD_WAVES) k_render_bwd_unit(
                 P = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, px.k0), __builtin_bit_cast(bf16x8, bf.k0), P, 0, 0, 0);
                 P = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pix0.k1), __builtin_bit_cast(bf16x8, bf.k1), P, 0, 0, 0);
                 float r0, r1, r2;
-                if (slow) ub_walk_row<true>(P, 0, krow + 16 * b, lrow + 16 * b, lpos, r0, r1, r2);    // row j = 2 b
-                else ub_walk_row<false>(P, 0, krow + 16 * b, lrow + 16 * b, lpos, r0, r1, r2);
+                if (slow) ub_walk_row<true>(P, 0, krow + 16 * b, lrow + 16 * b, lpos, wk, r0, r1, r2);    // row j = 2 b
+                else ub_walk_row<false>(P, 0, krow + 16 * b, lrow + 16 * b, lpos, wk, r0, r1, r2);
                 N00 += r0; X1 += r1; X2 += r2;
                 if (b) { Y1 = fmaf(2.f, r0, Y1); Y2 = fmaf(4.f, r0, Y2); XY = fmaf(2.f, r1, XY); }
-                if (slow) ub_walk_row<true>(P, 8, krow + 16 * b, lrow + 16 * b, lpos, r0, r1, r2);    // row j = 2 b + 1
-                else ub_walk_row<false>(P, 8, krow + 16 * b, lrow + 16 * b, lpos, r0, r1, r2);
+                if (slow) ub_walk_row<true>(P, 8, krow + 16 * b, lrow + 16 * b, lpos, wk, r0, r1, r2);    // row j = 2 b + 1
+                else ub_walk_row<false>(P, 8, krow + 16 * b, lrow + 16 * b, lpos, wk, r0, r1, r2);
                 N00 += r0; X1 += r1; X2 += r2;
                 const float j = (float)(2 * b + 1);
                 Y1 = fmaf(j, r0, Y1); Y2 = fmaf(j * j, r0, Y2); XY = fmaf(j, r1, XY);

@@ -67,7 +67,7 @@ with open(f"profiles/{rnd}_pmc.csv", "w") as o:
 traffic = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, profiles/collect.sh), bench.py --steps 4 serial "
                    "eager view mode cfg3, per-launch averages; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE "
                    "half-count correction of MI355X_MICROARCH.md; WRITE_SIZE uncalibrated)",
-           "round": int(rnd[1:]), "snapshot": tag, "config": config, "kernels": {}}
+           "round": int(re.match(r"r(\d+)", rnd).group(1)), "snapshot": tag, "config": config, "kernels": {}}
 for k in agg:
     if "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
         fv, wv = agg[k]["FETCH_SIZE"], agg[k]["WRITE_SIZE"]
