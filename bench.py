@@ -470,7 +470,7 @@ def main():
         ref = flat_sets[0][0].clone()
         vstreams, use_graphs[0] = keep_s, keep_u
         grad_check = float((got - ref).norm() / ref.norm().clamp_min(1e-30))
-        if not grad_check < 1e-3:
+        if not grad_check < 1e-3 and os.environ.get("CGS_BENCH_WHATIF") != "1":   # (what-if timing builds compute garbage)
             raise RuntimeError(f"bench: overlapped schedule changed the step gradient (relative L2 error {grad_check:.3e})")
 
     # the reference's schedule for comparison: one view at a time, one stream (latency of a single view's hot path)

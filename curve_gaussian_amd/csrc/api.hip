@@ -674,7 +674,8 @@ int cgs_view_backward(int B, int m, const float* curve_points, const float* widt
                                img.n_contrib, dL_dout_color, geom.grad_acc);
     else
         launch_render_bwd(s, false, false, false, tiles, img.ranges, bin.point_list, width_px, height_px, gx, background, geom.rec,
-                          img.final_T, img.n_contrib, dL_dout_color, nullptr, nullptr, geom.grad_acc, colors_precomp == nullptr);
+                          img.final_T, img.n_contrib, dL_dout_color, nullptr, nullptr, geom.grad_acc, colors_precomp == nullptr,
+                          ACC_STRIDE_VIEW);
     launch_view_backward(s, B, m, curve_points, width, is_bezier, coef, eps, norms, opacity_logit, mask_logit, mask_thr,
                          cam_pos, viewmatrix, projmatrix, tan_fovx, tan_fovy, focal_x, focal_y, width_px, height_px, radii,
                          geom.rec, geom.grad_acc, dL_drotation_extra, dL_dmeans2D, dL_dopacity_logit, dL_dmask_logit, g_xyz,

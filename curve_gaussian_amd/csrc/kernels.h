@@ -57,7 +57,8 @@ void launch_render_bwd(hipStream_t s, bool geo, bool invd, bool colg, int tiles,
                        const uint32_t* point_list, int W, int H, int grid_x, const float* bg_color,
                        const SplatRec* rec, const float* final_Ts, const uint32_t* n_contrib, const float* dL_dpixels,
                        const float* dL_dout_invdepth, const float* dL_dout_all_map, float* grad_acc,
-                       bool unit = false);   // unit: colour == 1 for every splat (render.hip, UNIT)
+                       bool unit = false,    // unit: colour == 1 for every splat (render.hip, UNIT)
+                       int acc_stride = ACC_STRIDE);   // floats per accumulator record (ACC_STRIDE_VIEW on the view path)
 
 
 // render_unit_bwd.hip: the unit-colour training instance (colour == 1, only dL/dcolour flowing in), lane = (splat, quadrant)

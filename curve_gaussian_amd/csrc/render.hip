@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(256, GEO ? 2 : (INVD || COLG) ? 4 : CGS_BWD3_W
     const float* __restrict__ bg_color, const SplatRec* __restrict__ rec, const float* __restrict__ final_Ts,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
     const float* __restrict__ dL_dout_invdepth, const float* __restrict__ dL_dout_all_map,
-    float* __restrict__ grad_acc) {
+    float* __restrict__ grad_acc, int acc_stride) {
     constexpr bool EXTRA = COLG || INVD || GEO;   // sums beyond the six geometric ones
     constexpr int NF = GEO ? 12 : EXTRA ? 8 : 6;  // fields of the packed per-splat accumulator record that can be non-zero
     constexpr int BB = BWD_BATCH, NC = BB / 64;
@@ -635,10 +635,10 @@ __global__ void __launch_bounds__(256, GEO ? 2 : (INVD || COLG) ? 4 : CGS_BWD3_W
                             const uint32_t joff = list[k0 + fs];
                             const uint32_t id = INVD ? *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_id) + (joff >> 2))
                                                      : __float_as_uint(*reinterpret_cast<const float*>(at_bytes + joff + 4));
-                            if (v != 0.f) atomicAdd(grad_acc + (size_t)id * ACC_STRIDE + ff, v);
+                            if (v != 0.f) atomicAdd(grad_acc + (size_t)id * acc_stride + ff, v);
                             if (GEO) {
                                 const float v2 = ff < 4 ? s_x[g.wave][fs][2 + ff] : 0.f;
-                                if (v2 != 0.f) atomicAdd(grad_acc + (size_t)id * ACC_STRIDE + 8 + ff, v2);
+                                if (v2 != 0.f) atomicAdd(grad_acc + (size_t)id * acc_stride + 8 + ff, v2);
                             }
                         }
                     }
@@ -679,7 +679,7 @@ __global__ void __launch_bounds__(256, GEO ? 2 : (INVD || COLG) ? 4 : CGS_BWD3_W
                         }
                         if (any && v != 0.f) {
                             const uint32_t id = __float_as_uint(s_at[e + 1].y);
-                            atomicAdd(grad_acc + (size_t)id * ACC_STRIDE + f, v);
+                            atomicAdd(grad_acc + (size_t)id * acc_stride + f, v);
                         }
                     }
                 }
@@ -719,16 +719,17 @@ void launch_render_fwd_sorting(hipStream_t s, bool geo, int tiles, const uint32_
 void launch_render_bwd(hipStream_t s, bool geo, bool invd, bool colg, int tiles, const uint2* ranges,
                        const uint32_t* point_list, int W, int H, int grid_x, const float* bg_color,
                        const SplatRec* rec, const float* final_Ts, const uint32_t* n_contrib, const float* dL_dpixels,
-                       const float* dL_dout_invdepth, const float* dL_dout_all_map, float* grad_acc, bool unit) {
+                       const float* dL_dout_invdepth, const float* dL_dout_all_map, float* grad_acc, bool unit,
+                       int acc_stride) {
     ProfScope p("render_bwd", s);
     if (unit && !geo && !invd && !colg) {
         hipLaunchKernelGGL((k_render_bwd3<false, false, false, true>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H,
-                           grid_x, bg_color, rec, final_Ts, n_contrib, dL_dpixels, dL_dout_invdepth, dL_dout_all_map, grad_acc);
+                           grid_x, bg_color, rec, final_Ts, n_contrib, dL_dpixels, dL_dout_invdepth, dL_dout_all_map, grad_acc, acc_stride);
         return;
     }
 #define CGS_BWD(G, I, C)                                                                                         \
     hipLaunchKernelGGL((k_render_bwd3<G, I, C>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H, grid_x, \
-                       bg_color, rec, final_Ts, n_contrib, dL_dpixels, dL_dout_invdepth, dL_dout_all_map, grad_acc)
+                       bg_color, rec, final_Ts, n_contrib, dL_dpixels, dL_dout_invdepth, dL_dout_all_map, grad_acc, acc_stride)
     if (geo && invd) CGS_BWD(true, true, true);        // full-gradient configuration
     else if (geo) CGS_BWD(true, false, true);
     else if (invd) CGS_BWD(false, true, true);

@@ -128,7 +128,9 @@ __device__ __forceinline__ void masked_add(float& s, float v, float x, float thr
 //     s = sum_{x>=1} g_x,  u = sum_k s_k = sum x g_x,  w = sum_k u_k = sum x (x + 1) / 2 g_x   =>   R2 = 2 w - u.
 // nP holds -log2(alpha_u) (the coefficient sets are built negated).  LEAN -- no splat of the chunk has opacity >= 0.99, so the
 // reference's alpha = min(0.99, alpha_u) never clamps: with E = 1 / alpha_u = exp2(nP),
-//     g = alpha_u K / (1 - alpha_u) = K / (E - 1):   exp2, subtract, rcp, one multiply.
+//     g = alpha_u K / (1 - alpha_u) = K / (E - 1) = 1 / (E Kinv - Kinv):   exp2, one fma, rcp  (Kinv = 1 / K from the second
+// per-pixel table; 1e30 where K = 0: the quotient is then ~1e-30 K-units, i.e. nothing).  The two transcendentals cost next
+// to nothing here (what-if builds without them run as fast); the plain vector instructions are what the kernel pays for.
 template <bool SLOW, bool LEAN>
 __device__ __forceinline__ void ub_walk_row(const f32x16& nP, int r0, const float* __restrict__ krow, const uint32_t* __restrict__ lrow,
                                             uint32_t pos, const WalkConsts& k, float& R0, float& R1, float& R2) {
@@ -142,9 +144,9 @@ __device__ __forceinline__ void ub_walk_row(const f32x16& nP, int r0, const floa
         const uint32_t Lv[4] = {L4.x, L4.y, L4.z, L4.w};
 #pragma unroll
         for (int t = 3; t >= 0; t--) {
-            if (LEAN) {
+            if (LEAN) {   // (krow holds 1 / K here)
                 const float E = __builtin_amdgcn_exp2f(nP[r0 + 4 * rr + t]);     // 1 / alpha_u
-                const float v = Kv[t] * __builtin_amdgcn_rcpf(E - k.one);         // g = K / (1 / alpha_u - 1)
+                const float v = __builtin_amdgcn_rcpf(fmaf(E, Kv[t], -Kv[t]));   // g = K / (1 / alpha_u - 1) = 1 / ((E - 1) / K)
                 masked_add<SLOW, true>(s, v, E, k.ramin, pos, Lv[t]);
             } else {
                 const float e = __builtin_amdgcn_exp2f(-nP[r0 + 4 * rr + t]);    // alpha_u = opacity G
@@ -168,6 +170,7 @@ __global__ void __launch_bounds__(256, CGS_UBWD_WAVES) k_render_bwd_unit(
     __shared__ float4 s_at[UB + 1];      // {C2, log2 opacity, splat id bits, -}
     __shared__ uint16_t s_list[UB * 4 + CH];
     __shared__ __attribute__((aligned(16))) float s_K[8 * KROW];        // [quadrant][lane half][block][register]
+    __shared__ __attribute__((aligned(16))) float s_Kinv[8 * KROW];     // 1 / K (clamp-free walk)
     __shared__ __attribute__((aligned(16))) uint32_t s_last[8 * KROW];  // the same layout: the pixel's cut (list position)
     __shared__ uint32_t s_wcount[4];
     __shared__ uint32_t s_qlast[8];      // [q]: deepest cut of the quadrant, [4 + q]: shallowest
@@ -194,6 +197,7 @@ __global__ void __launch_bounds__(256, CGS_UBWD_WAVES) k_render_bwd_unit(
         const int b = y >> 2, yy = y & 3, hh = yy & 1, r = x + 8 * (yy >> 1);
         const int idx = (g.wave * 2 + hh) * KROW + b * 16 + r;
         s_K[idx] = K;
+        s_Kinv[idx] = fabsf(K) > 1e-30f ? __builtin_amdgcn_rcpf(K) : 1e30f;
         s_last[idx] = last;
         uint32_t mx = last, mn = g.inside ? last : 0xffffffffu;
 #pragma unroll
@@ -301,7 +305,7 @@ __global__ void __launch_bounds__(256, CGS_UBWD_WAVES) k_render_bwd_unit(
             const uint32_t lpos = (uint32_t)(i * UB) + J;                       // the pair's list position
             const bool slow = ballot64((ent >> 15) != 0u) != 0ull;              // some pixel of some pair may be cut
             const bool lean = ballot64(at.y >= -0.0145f) == 0ull;            // log2(0.99) = -0.0144996; below: no alpha can reach the clamp
-            const float* const krow = s_K + (q * 2u + (uint32_t)hh) * KROW;
+            const float* const krow = (lean ? s_Kinv : s_K) + (q * 2u + (uint32_t)hh) * KROW;
             const uint32_t* const lrow = s_last + (q * 2u + (uint32_t)hh) * KROW;
             float N00 = 0.f, X1 = 0.f, X2 = 0.f, Y1 = 0.f, Y2 = 0.f, XY = 0.f;   // moments about (qox, qoy + hh), y in steps of 2
 #pragma unroll
@@ -364,7 +368,7 @@ __global__ void __launch_bounds__(256, CGS_UBWD_WAVES) k_render_bwd_unit(
                 if (e < n_lead && f < 6) {
                     const float v = outw[e * 8 + f];
                     const uint32_t id = __float_as_uint(outw[e * 8 + 6]);
-                    if (v != 0.f) atomicAdd(grad_acc + (size_t)id * ACC_STRIDE + f, v);
+                    if (v != 0.f) atomicAdd(grad_acc + (size_t)id * ACC_STRIDE_VIEW + f, v);
                 }
             }
             wave_lds_fence();   // the array is rewritten by the next chunk

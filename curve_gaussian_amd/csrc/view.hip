@@ -31,10 +31,10 @@ __global__ void __launch_bounds__(256) k_view_fwd(
     for (uint32_t i = (uint32_t)p; i < n_clear; i += gridDim.x * blockDim.x) clear_words[i] = 0u;
     if (p >= B * m) return;
     {
-        float4* accp = reinterpret_cast<float4*>(grad_acc + (size_t)p * ACC_STRIDE);
+        float4* accp = reinterpret_cast<float4*>(grad_acc + (size_t)p * ACC_STRIDE_VIEW);
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int k = 0; k < ACC_STRIDE / 4; k++) accp[k] = z;
+        for (int k = 0; k < ACC_STRIDE_VIEW / 4; k++) accp[k] = z;
     }
     const int b = p / m, i = p - b * m;
     const CurveCP c = load_curve(cp, is_bezier, b);
@@ -106,11 +106,11 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK, CGS_VIEW_BWD_WAVES) k_view_bwd(
         const AttrsFwd a = attrs_forward(q, s.xyz, opacity_logit[b], has_mask, ml, mask_thr, cam, vp.vm);
         const float3 sc = make_float3(s.dist * a.mk, w * a.mk, w * a.mk);
         // ---- rasterizer backward tail (K9 + K10) on the compositor's sums; the record is handed back zeroed
-        float4* accp = reinterpret_cast<float4*>(grad_acc + p * ACC_STRIDE);
-        const float4 acc0 = accp[0], acc1 = accp[1], acc2 = accp[2];
+        float4* accp = reinterpret_cast<float4*>(grad_acc + (size_t)p * ACC_STRIDE_VIEW);
+        const float4 acc0 = accp[0], acc1 = accp[1];
         {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            accp[0] = z; accp[1] = z; accp[2] = z;
+            accp[0] = z; accp[1] = z;
         }
         const bool vis = radii[p] > 0;
         float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK, CGS_VIEW_BWD_WAVES) k_view_bwd(
         // ---- splat attributes backward
         const V3 gs = {o.dscale.x, o.dscale.y, o.dscale.z};
         const V3 scl = {s.dist, w, w};
-        const AttrsBwd ab = attrs_backward(q, s.xyz, opacity_logit[b], has_mask, ml, mask_thr, cam, vp.vm, o.drot, true, acc2,
+        const AttrsBwd ab = attrs_backward(q, s.xyz, opacity_logit[b], has_mask, ml, mask_thr, cam, vp.vm, o.drot, false /* no gradient reaches all_map on this path */, make_float4(0.f, 0.f, 0.f, 0.f),
                                            o.dopac, has_mask, gs, scl);
         g_op_term = ab.g_op_term;
         if (g_mask_logit) g_mask_logit[p] = accumulate ? g_mask_logit[p] + ab.g_mask_logit : ab.g_mask_logit;
