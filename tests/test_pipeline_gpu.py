@@ -42,8 +42,9 @@ def test_render_matches_oracle_composition(use_mask):
     dimg = torch.randn(1, H, W, generator=g)
     (pkg["render"] * dimg.to(DEV)).sum().backward()
     torch.cuda.synchronize()
-    # ---- oracle composition
-    xyz, rot, scl = TR.prepare_scaling_rot(c["curve_points"], c["width"], c["is_bezier"])
+    # ---- oracle composition on the splat tensors the model derived (HIP sampling kernels; checked against the torch
+    # restatement in test_sampling_gpu.py), so that both rasterizers see the same splats
+    xyz, rot, scl = (t.detach().cpu() for t in (gm._xyz, gm._rotation, gm._scaling))
     P = xyz.shape[0]
     rotn = torch.nn.functional.normalize(rot)
     opac = torch.sigmoid(c["opacity"]).unsqueeze(1).expand(-1, 12, -1).reshape(-1, 1)
@@ -56,19 +57,18 @@ def test_render_matches_oracle_composition(use_mask):
     fw = ORA.forward(np.zeros(3, np.float32), n(xyz), np.ones((P, 1), np.float32), n(opac), n(scl), n(rotn), 1.0, None,
                      n(amap), n(cam.world_view_transform), n(cam.full_proj_transform), tfx, tfy, H, W, None, 0,
                      n(cam.camera_center))
-    assert (pkg["radii"].cpu().numpy() == fw.radii).mean() > 0.999     # 1 ulp in scale can move ceil(3 sigma)
-    assert_close("render", pkg["render"].detach().cpu().numpy(), np.clip(fw.color, 0, 1), outlier_frac=2e-3)
-    assert_close("rend_alpha", pkg["rend_alpha"].detach().cpu().numpy(), fw.out_all_map[3:4], outlier_frac=2e-3)
+    assert (pkg["radii"].cpu().numpy() == fw.radii).all()
+    assert_close("render", pkg["render"].detach().cpu().numpy(), np.clip(fw.color, 0, 1))
+    assert_close("rend_alpha", pkg["rend_alpha"].detach().cpu().numpy(), fw.out_all_map[3:4])
     rd = torch.tensor(fw.out_all_map[0:3]).permute(1, 2, 0) @ cam.world_view_transform[:3, :3].T
-    assert_close("rend_dir", pkg["rend_dir"].detach().cpu().numpy(), rd.permute(2, 0, 1).numpy(), outlier_frac=2e-3)
+    assert_close("rend_dir", pkg["rend_dir"].detach().cpu().numpy(), rd.permute(2, 0, 1).numpy())
     assert pkg["visibility_filter"].shape[1] == 1 and pkg["viewspace_points"].grad.shape == (P, 3)
     # gradient reaches the curve parameters; means2D grad is consumable by add_densification_stats (GM:618-620)
     assert gm._curve_points.grad.abs().max() > 0 and gm._opacity.grad.abs().max() > 0
     gm.add_densification_stats(pkg["viewspace_points"], pkg["visibility_filter"].squeeze(1))
     assert gm.denom.sum() == pkg["visibility_filter"].shape[0]
     gr = ORA.backward(fw, np.where((fw.color > 0) & (fw.color < 1), dimg.numpy(), 0).astype(np.float32), None, None)
-    assert_close("means2D grad", pkg["viewspace_points"].grad.cpu().numpy(), gr["dL_dmeans2D"], outlier_frac=5e-3,
-                 abs_floor=1e-6)
+    assert_close("means2D grad", pkg["viewspace_points"].grad.cpu().numpy(), gr["dL_dmeans2D"], abs_floor=1e-6)
     fw.free()
 
 
@@ -495,15 +495,20 @@ class _ViewCalls:
         off = int(lib.cgs_image_status_offset(self.W, self.H))
         self.status = self.img[off:off + 4 * int(lib.cgs_status_words())].view(torch.int32)
 
-    def forward(self):
+    def forward(self, want_splats=False, image_only=False):
+        """want_splats: also return the model's derived splat tensors (xyz, raw rotation, scaling) the kernels computed;
+        image_only: pass neither inverse depth nor all_map (the image-only instance of the unit-colour forward)."""
         L, lib, pt, cf, cam = self.L, self.lib, self.L.ptr, self.C.c_float, self.cam
         st = L.raw_stream(torch.device(DEV))
+        if want_splats:
+            self.xyz, self.rot, self.scl = self.f32(self.P, 3), self.f32(self.P, 4), self.f32(self.P, 3)
+        sp = (pt(self.xyz), pt(self.rot), pt(self.scl)) if want_splats else (None, None, None)
         L.check(lib.cgs_view_forward(self.B, self.m, pt(self.cp), pt(self.w), pt(self.isb), pt(self.coef), cf(1e-8),
                                      pt(self.norms), pt(self.op), None, cf(0.01), pt(self.colors), pt(self.geom), pt(self.binb),
                                      self.nbin, pt(self.img), self.cap, pt(self.bg), self.W, self.H,
                                      pt(cam.world_view_transform), pt(cam.full_proj_transform), pt(cam.camera_center),
-                                     self.tf[0], self.tf[1], pt(self.color), pt(self.invd), pt(self.omap), pt(self.radii),
-                                     None, None, None, st), "cgs_view_forward")
+                                     self.tf[0], self.tf[1], pt(self.color), None if image_only else pt(self.invd),
+                                     None if image_only else pt(self.omap), pt(self.radii), *sp, st), "cgs_view_forward")
         torch.cuda.synchronize()
         assert int(self.status[2]) == 0, "bucket overflow: raise cap"
 
@@ -609,6 +614,82 @@ def test_view_entry_points_match_the_oracle_chain_at_full_size(cfg, coloured, bg
         rel = float((got.cpu() - want).norm() / want.norm())
         print(f"{cfg}: dL/d{name} relative L2 {rel:.2e}")
         assert rel < tol, f"dL/d{name}: relative L2 error {rel:.2e}"
+    fw.free()
+
+
+def _opaque(curves):
+    """Every third curve nearly opaque (0.995 / 0.9995): alpha reaches the reference's 0.99 clamp (forward.cu:368), which the
+    clamp-free walk of the pair-major backward must not be used for."""
+    c = dict(curves)
+    op = c["opacity"].clone()
+    op[0::3] = float(np.log(0.995 / 0.005))
+    op[1::6] = float(np.log(0.9995 / 0.0005))
+    c["opacity"] = op
+    return c
+
+
+@pytest.mark.parametrize("cfg,bg,opaque", [("cfg1", 0.0, False), ("cfg2", 0.35, False), ("cfg3", 0.0, False), ("cfg3", 0.35, False),
+                                            ("cfg4", 0.0, False), ("cfg5", 0.0, False), ("cfg2", 0.0, True), ("cfg1", 0.35, True)])
+def test_headline_instances_meet_the_raster_criterion_on_identical_inputs(cfg, bg, opaque):
+    """The kernel instances bench.py times (cgs_view_forward / cgs_view_backward without colors_precomp: unit-colour forward
+    with the in-kernel tile sort, pair-major unit-colour backward) held to the SAME criterion as the general rasterizer
+    instances in test_raster_gpu.py: the splat tensors the fused forward computed (xyz, raw rotation, scaling) are read back
+    and handed to oracle/raster_ref.c -- together with the oracle-side normalisation, opacity and all_map -- so both
+    compositors see the same splats up to the last bits of one normalisation; image, all_map and dL/dmeans2D then have to
+    agree to 1e-4 of the tensor's maximum on all but 1e-4 of the elements (assert_close defaults), radii exactly up to +-1 on
+    <= 1e-5 of the splats.  The curve-parameter gradients are compared with the torch pull-back of the ORACLE's per-splat
+    gradients through the restated sampling graph, in relative L2 (the sampling backward sums 12 samples per curve with
+    cancellation; two runs of the same kernels differ by 1e-4 from the order of the compositor's float atomics alone)."""
+    curves, cams = S.make_config(cfg, n_views=1)
+    if opaque:
+        curves = _opaque(curves)
+    cam = cams[0]
+    H, W = cam.image_height, cam.image_width
+    vc = _ViewCalls(curves["curve_points"], curves["width"], curves["opacity"], curves["is_bezier"], cam,
+                    4096 if cfg == "cfg5" else 1024, bg=bg)
+    vc.forward(want_splats=True)
+    xyz_h, rot_h, scl_h = vc.xyz.cpu(), vc.rot.cpu(), vc.scl.cpu()
+    P = xyz_h.shape[0]
+    rotn_h = torch.nn.functional.normalize(rot_h)
+    opac = torch.sigmoid(curves["opacity"]).repeat_interleave(12, 0)
+    amap = TR.build_all_map(rot_h, xyz_h, cam.camera_center, cam.world_view_transform).float().contiguous()
+    tfx, tfy = tanfov(cam)
+    n = lambda t: np.ascontiguousarray(t.detach().numpy())
+    fw = ORA.forward(np.full(3, bg, np.float32), n(xyz_h), np.ones((P, 1), np.float32), n(opac), n(scl_h), n(rotn_h), 1.0, None,
+                     n(amap), n(cam.world_view_transform), n(cam.full_proj_transform), tfx, tfy, H, W, None, 0,
+                     n(cam.camera_center))
+    radii = vc.radii.cpu().numpy()
+    off = radii != fw.radii
+    assert off.mean() <= 1e-5 and (np.abs(radii[off] - fw.radii[off]) <= 1).all(), f"radii: {off.sum()} of {P} differ"
+    assert_close("color", vc.color.cpu().numpy(), fw.color)
+    assert_close("all_map", vc.omap.cpu().numpy(), fw.out_all_map)
+    assert_close("invdepth", vc.invd.cpu().numpy(), fw.invdepth)
+    dimg = torch.randn(1, H, W, generator=torch.Generator().manual_seed(17))
+    gr = ORA.backward(fw, dimg.numpy(), None, None)
+    B = vc.B
+    g = [vc.f32(B, 4, 3), vc.f32(B, 1), vc.f32(B, 1)]
+    g_m2d = vc.backward(dimg.to(DEV), *g, 0)
+    assert_close("dL_dmeans2D", g_m2d.cpu().numpy(), gr["dL_dmeans2D"], abs_floor=1e-6)
+    want = torch.from_numpy(gr["dL_dmeans2D"])
+    print(f"{cfg} bg={bg}: dL_dmeans2D relative L2 {float((g_m2d.cpu() - want).norm() / want.norm()):.2e}")
+    # curve-parameter gradients: the oracle's per-splat gradients pulled back through the restated sampling graph
+    leaves = [curves[k].clone().requires_grad_(True) for k in ("curve_points", "width", "opacity")]
+    xyz, rot, scl = TR.prepare_scaling_rot(leaves[0], leaves[1], curves["is_bezier"])
+    t = lambda a: torch.from_numpy(np.asarray(a, np.float32))
+    ((xyz * t(gr["dL_dmeans3D"])).sum() + (scl * t(gr["dL_dscales"])).sum()
+     + (torch.nn.functional.normalize(rot) * t(gr["dL_drotations"])).sum()
+     + (torch.sigmoid(leaves[2]).repeat_interleave(12, 0) * t(gr["dL_dopacity"])).sum()).backward()
+    for name, got, leaf in zip(("curve_points", "width", "opacity"), g, leaves):
+        rel = float((got.cpu() - leaf.grad).norm() / leaf.grad.norm())
+        print(f"{cfg} bg={bg}: dL/d{name} relative L2 {rel:.2e}")
+        # measured 2e-6 .. 8e-6 (cfg1-4); cfg5: 2.0e-4 -- every pixel of that view terminates early (T < 1e-4) and which splat
+        # terminates a pixel flips under the last bits of the exponent far more often than an alpha test does
+        assert rel < (3e-4 if cfg == "cfg5" else 3e-5), f"dL/d{name}: relative L2 error {rel:.2e}"
+    if cfg == "cfg3" and bg == 0.0:
+        # the image-only instance of the forward (no inverse depth, no all_map) at a BASELINE size: same image, bit for bit
+        full = vc.color.clone()
+        vc.forward(image_only=True)
+        assert torch.equal(vc.color, full)
     fw.free()
 
 

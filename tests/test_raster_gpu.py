@@ -556,9 +556,9 @@ def test_baseline_config_training_instance_matches_oracle(cfg, P):
 
 @pytest.mark.parametrize("cfg,P", [("cfg3", 200004), ("cfg4", 300000), ("cfg5", 1000008)])
 def test_full_size_properties(cfg, P):
-    """BASELINE cfg3 / cfg4 / cfg5 (200k splats 1600^2, 300k splats 1200x680 room, 1M splats 2048^2): too big for a
-    per-element oracle compare inside the GPU-test budget, so check size-independent properties: sortedness of every
-    tile list, instance conservation, value ranges."""
+    """BASELINE cfg3 / cfg4 / cfg5 (200k splats 1600^2, 300k splats 1200x680 room, 1M splats 2048^2): on top of the
+    per-element oracle compare at these sizes (test_baseline_config_matches_oracle above), the size-independent properties:
+    sortedness of every tile list, instance conservation, value ranges."""
     from curve_gaussian_amd.diff_cur_rasterization import _C
     from oracle import torch_ref as TR
     dev = torch.device(DEV)
