@@ -70,19 +70,43 @@ struct HintEntry { int P = -1, W = 0, H = 0; uint64_t stamp = 0; BinHints h; };
 static std::mutex g_hint_mu;
 static HintEntry g_hint_tab[32];
 static uint64_t g_hint_clock = 0;
-static HintEntry* hint_entry_locked(int P, int W, int H) {
-    HintEntry* lru = &g_hint_tab[0];
-    for (auto& e : g_hint_tab) {
+// Exact match, or nullptr.  (A pure lookup never inserts: cgs_view_forward / cgs_rasterize_forward_static only ask.)
+static HintEntry* hint_find_locked(int P, int W, int H) {
+    for (auto& e : g_hint_tab)
         if (e.P == P && e.W == W && e.H == H) { e.stamp = ++g_hint_clock; return &e; }
-        if (e.stamp < lru->stamp) lru = &e;
+    return nullptr;
+}
+// Most recently used entry of the same resolution but another splat count: a topology edit (densify / prune / split) changes
+// P by a few curves, and the new cloud bins almost like the old one -- its history seeds the new shape (R scaled by the
+// splat ratio) instead of sending the next forward of every resolution through the exact path again.
+static const HintEntry* hint_neighbour_locked(int W, int H) {
+    const HintEntry* best = nullptr;
+    for (auto& e : g_hint_tab)
+        if (e.P > 0 && e.W == W && e.H == H && (!best || e.stamp > best->stamp)) best = &e;
+    return best;
+}
+static BinHints hint_seed_locked(int P, int W, int H) {
+    BinHints h;
+    if (const HintEntry* nb = hint_neighbour_locked(W, H)) {
+        h = nb->h;
+        h.R = (int64_t)((double)nb->h.R * (double)P / (double)nb->P);
     }
+    return h;
+}
+static HintEntry* hint_entry_locked(int P, int W, int H) {   // find or insert (LRU eviction)
+    if (HintEntry* e = hint_find_locked(P, W, H)) return e;
+    const BinHints seed = hint_seed_locked(P, W, H);
+    HintEntry* lru = &g_hint_tab[0];
+    for (auto& e : g_hint_tab)
+        if (e.stamp < lru->stamp) lru = &e;
     *lru = HintEntry{};
-    lru->P = P; lru->W = W; lru->H = H; lru->stamp = ++g_hint_clock;
+    lru->P = P; lru->W = W; lru->H = H; lru->stamp = ++g_hint_clock; lru->h = seed;
     return lru;
 }
 static BinHints hints_load(int P, int W, int H) {
     std::lock_guard<std::mutex> lk(g_hint_mu);
-    return hint_entry_locked(P, W, H)->h;
+    if (HintEntry* e = hint_find_locked(P, W, H)) return e->h;
+    return hint_seed_locked(P, W, H);
 }
 // R < 0 / big < 0: leave that field; longest: folded into the decaying maximum
 static void hints_update(int P, int W, int H, int64_t R, uint32_t longest, int64_t big) {

@@ -78,6 +78,8 @@ constexpr int GROUP = 16;
 #define CGS_BWD3_CAP 104
 #endif
 constexpr int BWD_BATCH = 128;   // splats staged per round by the backward (its LDS also holds the per-quadrant sums)
+// the park-or-atomics decision is taken per group of SLOTS list positions, the combining pass reads every position < CAP
+static_assert(CGS_BWD3_CAP % 8 == 0 && CGS_BWD3_CAP <= BWD_BATCH, "CGS_BWD3_CAP: a multiple of SLOTS (8), at most BWD_BATCH");
 constexpr uint32_t BWD_PAD_OFF = (BWD_BATCH + 1) * 16;
 constexpr uint32_t PAD_OFF = (BATCH + 1) * 16;   // byte offset of the padding entry in the staged arrays
 

@@ -213,9 +213,9 @@ def densify_and_split_curve(g, selected_pts_mask, t, N=2):
 def densify_and_prune(g, max_grad, min_opacity, extent=None, max_screen_size=None, radii=None):
     """:351-365 -- split the curves whose largest per-splat mean screen-space gradient reaches max_grad at the sample
     where it is largest, then prune curves below min_opacity."""
-    from ..view_parallel import sync_densification_stats
-    sync_densification_stats(g)      # view-parallel runs: statistics of all ranks' views (no-op on one rank)
-    grads = g.xyz_gradient_accum / g.denom
+    from ..view_parallel import global_densification_stats
+    accum, denom = global_densification_stats(g)   # view-parallel runs: the sums over all ranks' views (copies)
+    grads = accum / denom
     grads[grads.isnan()] = 0.0
     g.tmp_radii = radii
     m = g.n_gaussians

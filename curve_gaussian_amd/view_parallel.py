@@ -24,20 +24,27 @@ def _dist_world(group=None):
     return dist, dist.get_world_size(group)
 
 
-def sync_densification_stats(g, group=None):
-    """Make the densification statistics of a view-parallel run rank-consistent right before a topology decision: every
-    rank accumulated ``xyz_gradient_accum`` / ``denom`` (gaussian_model.py:618-620) over ITS views only, so the sums are
-    all-reduced (the quotient densify_and_prune thresholds, gaussian_curve_model.py:352, becomes the mean over the views
-    of all ranks) and ``max_radii2D`` takes the maximum.  With identical parameters (same all-reduced gradients, same
-    Adam step) every rank then takes the same split / prune decisions and the flat buffers keep the same size.
-    8 B/splat + 4 B/splat, only on densification iterations.  No-op without a process group."""
+def global_densification_stats(g, group=None):
+    """The densification statistics of ALL ranks' views, for a topology decision of a view-parallel run: every rank
+    accumulates ``xyz_gradient_accum`` / ``denom`` (gaussian_model.py:618-620) over ITS views only, so the decision
+    thresholds the quotient of the all-reduced sums (gaussian_curve_model.py:352: the mean over the views of all ranks).
+    Returns ``(accum, denom)`` as NEW tensors: the rank-local buffers are left untouched, because they keep accumulating
+    until a split resets them (densification_postfix) -- reducing them in place would count the views seen so far once per
+    rank again at the next decision.  ``max_radii2D`` is maximised in place (idempotent).  With identical parameters (same
+    all-reduced gradients, same Adam step) every rank then takes the same split / prune decisions and the flat buffers
+    keep the same size.  8 B/splat + 4 B/splat, only on densification iterations.  Without a process group:
+    the local buffers themselves."""
     dist, world = _dist_world(group)
     if world == 1:
-        return
-    for name, op in (("xyz_gradient_accum", dist.ReduceOp.SUM), ("denom", dist.ReduceOp.SUM), ("max_radii2D", dist.ReduceOp.MAX)):
-        t = getattr(g, name, None)
-        if t is not None and t.numel():
-            dist.all_reduce(t, op=op, group=group)
+        return g.xyz_gradient_accum, g.denom
+    accum, denom = g.xyz_gradient_accum.clone(), g.denom.clone()
+    if accum.numel():
+        dist.all_reduce(accum, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(denom, op=dist.ReduceOp.SUM, group=group)
+    t = getattr(g, "max_radii2D", None)
+    if t is not None and t.numel():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return accum, denom
 
 
 def assert_same_topology(n_curves: int, device=None, group=None):

@@ -68,11 +68,22 @@ traffic = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate pass
                    "eager view mode cfg3, per-launch averages; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE "
                    "half-count correction of MI355X_MICROARCH.md; WRITE_SIZE uncalibrated)",
            "round": int(re.match(r"r(\d+)", rnd).group(1)), "snapshot": tag, "config": config, "kernels": {}}
+# duration of each kernel in the trace pass of the same collection (same box, same command): the scale the counters belong to
+trace_us = collections.defaultdict(lambda: [0.0, 0])
+tf = sorted(glob.glob(f"{root}/trace/*/*_kernel_stats.csv"))
+if tf:
+    for r in csv.DictReader(open(tf[-1])):
+        k = short(r["Name"])
+        if k:
+            trace_us[k][0] += float(r["TotalDurationNs"]) * 1e-3
+            trace_us[k][1] += int(r["Calls"])
 for k in agg:
     if "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
         fv, wv = agg[k]["FETCH_SIZE"], agg[k]["WRITE_SIZE"]
         fkb, wkb = sum(fv.values()) / len(fv), sum(wv.values()) / len(wv)
         traffic["kernels"][k] = {"FETCH_SIZE_KB": round(fkb, 1), "WRITE_SIZE_KB": round(wkb, 1),
                                  "hbm_bytes_per_launch": int((2 * fkb + wkb) * 1024)}
+        if trace_us[k][1]:
+            traffic["kernels"][k]["kernel_us_in_trace"] = round(trace_us[k][0] / trace_us[k][1], 2)
 json.dump(traffic, open(f"profiles/{rnd}_traffic.json", "w"), indent=1)
 print("wrote", rnd, "kernels with traffic:", sorted(traffic["kernels"]))

@@ -162,6 +162,51 @@ def test_two_ranks_take_the_same_densify_and_prune_decisions(tmp_path):
     assert not torch.equal(sel(g0), sel(g1))
 
 
+def _two_edits_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gm = _cpu_model()
+    n0 = gm._curve_points.shape[0]
+    _local_stats(gm, rank)
+    gm.densify_and_prune(1.0, 0.0, 1.0, 20, torch.zeros(gm._xyz.shape[0], dtype=torch.int32))   # threshold out of reach: no split, no prune
+    assert gm._curve_points.shape[0] == n0
+    _local_stats(gm, rank + 10)                                                               # the interval's next views
+    gm.densify_and_prune(6.2e-4, 0.1, 1.0, 20, torch.zeros(gm._xyz.shape[0], dtype=torch.int32))
+    torch.save({"cp": gm._curve_points.detach().clone(), "op": gm._opacity.detach().clone()}, out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_statistics_survive_a_decision_without_a_split(tmp_path):
+    """The statistics buffers are only reset when a split happens (densification_postfix); a densify_and_prune that splits
+    nothing leaves them accumulating.  The all-reduce of the view-parallel decision therefore must not write the global sums
+    back into the rank-local buffers -- the second decision would count the first interval once per rank again.  Two ranks,
+    two consecutive decisions (the first out of reach), against ONE process that saw the views of both ranks."""
+    out = str(tmp_path / "topo2.pt")
+    mp.spawn(_two_edits_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    a, b = torch.load(out + ".0"), torch.load(out + ".1")
+    assert torch.equal(a["cp"], b["cp"]) and torch.equal(a["op"], b["op"])
+    gm = _cpu_model()
+    n0 = gm._curve_points.shape[0]
+    for seed in (0, 1):
+        o = _cpu_model()
+        _local_stats(o, seed)
+        gm.xyz_gradient_accum += o.xyz_gradient_accum
+        gm.denom += o.denom
+    gm.densify_and_prune(1.0, 0.0, 1.0, 20, torch.zeros(gm._xyz.shape[0], dtype=torch.int32))
+    for seed in (10, 11):
+        o = _cpu_model()
+        _local_stats(o, seed)
+        gm.xyz_gradient_accum += o.xyz_gradient_accum
+        gm.denom += o.denom
+    gm.densify_and_prune(6.2e-4, 0.1, 1.0, 20, torch.zeros(gm._xyz.shape[0], dtype=torch.int32))
+    assert gm._curve_points.shape[0] != n0
+    assert torch.equal(a["cp"], gm._curve_points.detach()) and torch.equal(a["op"], gm._opacity.detach())
+
+
 def test_ranks_draw_disjoint_views_from_one_stream():
     """TrainStep._next_view: every rank runs the same random stream and takes its own element of each group of `world`
     draws -- no view is rendered twice in one step, every view once per epoch (train.py:85-90 across ranks)."""
