@@ -38,6 +38,52 @@ def initialize_bezier_curves(points, bound, n_control_points=4):
     return torch.stack([points - direction, points - 0.5 * direction, points + 0.5 * direction, points + direction], dim=1)
 
 
+def _optimizer_state(opt):
+    """Adam state by group name: {"step": int, "groups": {name: {"lr", "exp_avg", "exp_avg_sq"}}} from a torch.optim.Adam
+    with named single-parameter groups or from ops.optim.FlatAdam (moments None before the first step)."""
+    if opt is None:
+        return None
+    out = {"step": 0, "groups": {}}
+    flat = hasattr(opt, "state_of")
+    if flat:
+        out["step"] = int(opt.step_count)
+    for g in opt.param_groups:
+        name, p = g["name"], g["params"][0]
+        if flat:
+            st = opt.state_of(name)
+            m, v = (st[0].detach().clone(), st[1].detach().clone()) if st is not None else (None, None)
+        else:
+            st = opt.state.get(p, None)
+            m, v = (st["exp_avg"].detach().clone(), st["exp_avg_sq"].detach().clone()) if st else (None, None)
+            if st:
+                out["step"] = int(st["step"])
+        out["groups"][name] = {"lr": float(g["lr"]), "exp_avg": m, "exp_avg_sq": v}
+    return out
+
+
+def _load_optimizer_state(opt, st):
+    if opt is None or st is None:
+        return
+    flat = hasattr(opt, "state_of")
+    if flat:
+        opt.step_count = int(st["step"])
+    for g in opt.param_groups:
+        e = st["groups"].get(g["name"])
+        if e is None:
+            continue
+        g["lr"] = e["lr"]
+        if e["exp_avg"] is None:
+            continue
+        p = g["params"][0]
+        if flat:
+            m, v = opt.state_of(g["name"])
+            m.copy_(e["exp_avg"].to(m.device))
+            v.copy_(e["exp_avg_sq"].to(v.device))
+        else:
+            opt.state[p] = {"step": torch.tensor(float(st["step"])), "exp_avg": e["exp_avg"].to(p.device).clone(),
+                            "exp_avg_sq": e["exp_avg_sq"].to(p.device).clone()}
+
+
 class GaussianCurveModel:
     def __init__(self, sh_degree: int = 0, n_gaussians: int = 12, optimizer_type: str = "default", device="cuda"):
         self.active_sh_degree = 0
@@ -56,6 +102,11 @@ class GaussianCurveModel:
         self._rotation = torch.empty(0)
         self._scaling = torch.empty(0)
         self.optimizer = None
+        self.exposure_optimizer = None
+        self.exposure_mapping = {}
+        self.pretrained_exposures = None
+        self._exposure = nn.Parameter(torch.eye(3, 4)[None].repeat(0, 1, 1).requires_grad_(True))   # [n_cameras, 3, 4]
+        self.spatial_lr_scale = 0
         # activations, scene/gaussian_model.py:38-53
         self.scaling_activation = torch.exp
         self.scaling_inverse_activation = torch.log
@@ -123,35 +174,119 @@ class GaussianCurveModel:
         self.prepare_scaling_rot()
         return self
 
-    def training_setup(self, feature_lr=0.0025, opacity_lr=0.025, scaling_lr=0.005, lr_curve_points_init=0.0005,
-                       mask_lr=0.01, lr_curve_points_final=0.000005, position_lr_delay_mult=0.01,
-                       position_lr_max_steps=30000):
-        """Adam groups of the reference (:200-213; lrs from arguments/__init__.py:83-89); the densification statistics
-        start at zero (:201-202)."""
+    # hyper-parameters of training_setup with the reference's defaults (arguments/__init__.py:79-114)
+    _TRAINING_DEFAULTS = dict(feature_lr=0.0025, opacity_lr=0.025, scaling_lr=0.005, lr_curve_points_init=0.0005,
+                              mask_lr=0.01, lr_curve_points_final=0.000005, position_lr_delay_mult=0.01,
+                              position_lr_max_steps=30000, exposure_lr_init=0.01, exposure_lr_final=0.001,
+                              exposure_lr_delay_steps=0, exposure_lr_delay_mult=0.0, iterations=10000)
+
+    def training_setup(self, training_args=None, **kw):
+        """Adam groups of the reference (:200-232; lrs from arguments/__init__.py:83-114), the exposure optimizer and the two
+        schedules; the densification statistics start at zero (:201-202).  `training_args`: the reference's
+        OptimizationParams-style object (train.py:48 ``gaussians.training_setup(opt)``), attributes missing from it and
+        keyword arguments fall back to / override the reference's defaults."""
+        hp = dict(self._TRAINING_DEFAULTS)
+        if training_args is not None:
+            hp.update({k: getattr(training_args, k) for k in hp if hasattr(training_args, k)})
+        unknown = set(kw) - set(hp)
+        if unknown:
+            raise TypeError(f"training_setup: unknown hyper-parameters {sorted(unknown)}")
+        hp.update(kw)
         P = self._curve_points.shape[0] * self.n_gaussians
         self.denom = torch.zeros((P, 1), device=self._curve_points.device)
         self.xyz_gradient_accum = torch.zeros((P, 1), device=self._curve_points.device)
         l = [
-            {'params': [self._features_dc], 'lr': feature_lr, "name": "f_dc"},
-            {'params': [self._features_rest], 'lr': feature_lr / 20.0, "name": "f_rest"},
-            {'params': [self._opacity], 'lr': opacity_lr, "name": "opacity"},
-            {'params': [self._width], 'lr': scaling_lr, "name": "width"},
-            {'params': [self._curve_points], 'lr': lr_curve_points_init, "name": "curve_points"},
-            {'params': [self._mask], 'lr': mask_lr, "name": "mask"},
+            {'params': [self._features_dc], 'lr': hp["feature_lr"], "name": "f_dc"},
+            {'params': [self._features_rest], 'lr': hp["feature_lr"] / 20.0, "name": "f_rest"},
+            {'params': [self._opacity], 'lr': hp["opacity_lr"], "name": "opacity"},
+            {'params': [self._width], 'lr': hp["scaling_lr"], "name": "width"},
+            {'params': [self._curve_points], 'lr': hp["lr_curve_points_init"], "name": "curve_points"},
+            {'params': [self._mask], 'lr': hp["mask_lr"], "name": "mask"},
         ]
         self.optimizer = torch.optim.Adam(l, lr=0.0, eps=1e-15)
-        self.curve_scheduler_args = get_expon_lr_func(lr_init=lr_curve_points_init, lr_final=lr_curve_points_final,
-                                                      lr_delay_mult=position_lr_delay_mult,
-                                                      max_steps=position_lr_max_steps)
+        self.exposure_optimizer = torch.optim.Adam([self._exposure])                                    # :221
+        self.curve_scheduler_args = get_expon_lr_func(lr_init=hp["lr_curve_points_init"], lr_final=hp["lr_curve_points_final"],
+                                                      lr_delay_mult=hp["position_lr_delay_mult"],
+                                                      max_steps=hp["position_lr_max_steps"])
+        self.exposure_scheduler_args = get_expon_lr_func(hp["exposure_lr_init"], hp["exposure_lr_final"],    # :228-232
+                                                         lr_delay_steps=hp["exposure_lr_delay_steps"],
+                                                         lr_delay_mult=hp["exposure_lr_delay_mult"],
+                                                         max_steps=hp["iterations"])
         return self.optimizer
 
     def update_learning_rate(self, iteration):
-        """:234-244"""
+        """:234-244 (exposure schedule: scene/gaussian_model.py:257-259)"""
+        if self.pretrained_exposures is None and self.exposure_optimizer is not None:
+            for param_group in self.exposure_optimizer.param_groups:
+                param_group['lr'] = self.exposure_scheduler_args(iteration)
         for param_group in self.optimizer.param_groups:
             if param_group["name"] == "curve_points":
                 lr = self.curve_scheduler_args(iteration)
                 param_group['lr'] = lr
                 return lr
+
+    def oneupSHdegree(self):
+        """scene/gaussian_model.py:187-189 (train.py:81-82, every 1000 iterations; a no-op at the default sh_degree 0)"""
+        if self.active_sh_degree < self.max_sh_degree:
+            self.active_sh_degree += 1
+
+    @property
+    def get_exposure(self):
+        return self._exposure
+
+    def get_exposure_from_name(self, image_name):
+        """scene/gaussian_model.py:178-182"""
+        if self.pretrained_exposures is None:
+            return self._exposure[self.exposure_mapping[image_name]]
+        return self.pretrained_exposures[image_name]
+
+    # ------------------------------------------------------------------ checkpoint / resume
+    def capture(self):
+        """train.py:238-240 ``torch.save((gaussians.capture(), iteration), ...)``.  DEVIATION from the reference, whose
+        GaussianCurveModel inherits the base class's capture / restore (scene/gaussian_model.py:74-106): those save the DERIVED
+        splat tensors and drop `_curve_points / _width / _mask / is_bezier`, so a resumed run cannot continue (SURVEY quirk
+        19).  Here the curve tensors, the statistics, both optimizers' state and the exposures round-trip; the optimizer state
+        is stored per group NAME (torch.optim.Adam or the flat one-launch Adam: either can resume the other's checkpoint)."""
+        t = lambda x: x.detach().clone()
+        return {
+            "format": "curvegs-checkpoint-1",
+            "active_sh_degree": self.active_sh_degree, "max_sh_degree": self.max_sh_degree, "n_gaussians": self.n_gaussians,
+            "curve_points": t(self._curve_points), "width": t(self._width), "opacity": t(self._opacity), "mask": t(self._mask),
+            "features_dc": t(self._features_dc), "features_rest": t(self._features_rest), "is_bezier": t(self.is_bezier),
+            "max_radii2D": t(self.max_radii2D),
+            "xyz_gradient_accum": t(self.xyz_gradient_accum) if hasattr(self, "xyz_gradient_accum") else None,
+            "denom": t(self.denom) if hasattr(self, "denom") else None,
+            "optimizer": _optimizer_state(self.optimizer),
+            "exposure": t(self._exposure), "exposure_mapping": dict(self.exposure_mapping),
+            "exposure_optimizer": self.exposure_optimizer.state_dict() if self.exposure_optimizer is not None else None,
+            "spatial_lr_scale": self.spatial_lr_scale,
+        }
+
+    def restore(self, model_args, training_args=None):
+        """train.py:49-51 ``gaussians.restore(model_params, opt)``: the inverse of ``capture`` (see there)."""
+        a = model_args
+        if not (isinstance(a, dict) and a.get("format") == "curvegs-checkpoint-1"):
+            raise ValueError("restore: not a checkpoint written by GaussianCurveModel.capture()")
+        if a["n_gaussians"] != self.n_gaussians:
+            raise ValueError(f"restore: checkpoint has {a['n_gaussians']} samples per curve, the model {self.n_gaussians}")
+        dev = self.device
+        par = lambda x: nn.Parameter(x.to(dev).float().contiguous().requires_grad_(True))
+        self.active_sh_degree, self.max_sh_degree = a["active_sh_degree"], a["max_sh_degree"]
+        self._curve_points, self._width, self._opacity, self._mask = (par(a[k]) for k in ("curve_points", "width", "opacity", "mask"))
+        self._features_dc, self._features_rest = par(a["features_dc"]), par(a["features_rest"])
+        self.is_bezier = a["is_bezier"].to(dev)
+        self.max_radii2D = a["max_radii2D"].to(dev)
+        self._exposure = par(a["exposure"])
+        self.exposure_mapping = dict(a["exposure_mapping"])
+        self.spatial_lr_scale = a["spatial_lr_scale"]
+        self.prepare_scaling_rot()
+        self.training_setup(training_args)
+        if a["xyz_gradient_accum"] is not None:
+            self.xyz_gradient_accum, self.denom = a["xyz_gradient_accum"].to(dev), a["denom"].to(dev)
+        _load_optimizer_state(self.optimizer, a["optimizer"])
+        if a["exposure_optimizer"] is not None:
+            self.exposure_optimizer.load_state_dict(a["exposure_optimizer"])
+        return self
 
     # ------------------------------------------------------------------ per-step derivation
     def prepare_scaling_rot(self, eps=1e-8):

@@ -46,8 +46,12 @@ class TrainStep:
         self.flat = FlatGrads(named)
         self.fused = fused
         if fused:   # one-launch Adam with the reference's per-group learning rates (training_setup :203-213)
+            from .scene.gaussian_curve_model import _load_optimizer_state, _optimizer_state
             lrs = {g["name"]: g["lr"] for g in gaussians.optimizer.param_groups}
+            carried = _optimizer_state(gaussians.optimizer)     # a run resumed with restore(): moments and step count
             gaussians.optimizer = FlatAdam(named, lrs, self.flat, eps=1e-15)
+            if carried is not None and carried["step"] > 0:
+                _load_optimizer_state(gaussians.optimizer, carried)
             gaussians.prepare_scaling_rot()   # parameters moved into the flat buffer: rebuild the derived tensors
         self.iteration = 0
         if hasattr(gaussians, "add_topology_listener"):
