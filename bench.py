@@ -459,7 +459,7 @@ def main():
     # the step's summed gradient under the timed schedule (streams, graphs, double-buffered sets) against the same views
     # run one at a time, eagerly, on one stream: the overlap machinery must not change what is computed
     grad_check = None
-    if args.mode == "view" and (vstreams.n > 1 or use_graphs[0]) and dist is None:
+    if args.mode == "view" and (vstreams.n > 1 or use_graphs[0]) and (dist is None or world == 1):
         barrier()
         for _ in range(3):     # several consecutive steps: both sets, and a reuse of the first
             run_views(my_cams[:G])
@@ -498,7 +498,7 @@ def main():
 
     # ---------------------------------------------------------------- view-parallel training iteration (all ranks)
     vp_train_ms = None
-    if dist is not None and world > 1 and args.train_step_multi and args.mode == "view":
+    if dist is not None and args.train_step_multi and args.mode == "view":   # (world == 1: CGS_BENCH_FORCE_DIST, tests)
         from curve_gaussian_amd.scene import GaussianCurveModel
         from curve_gaussian_amd.train_step import GraphedTrainStep
         gmv = GaussianCurveModel(0, m, device=dev).create_from_curves(curves["curve_points"], curves["width"],

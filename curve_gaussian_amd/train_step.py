@@ -169,8 +169,10 @@ class GraphedTrainStep(TrainStep):
         # at the same point of its collective sequence.
         self._collective = (self.world > 1) if collectives is None else bool(collectives)
         # capture_collectives=True: the two all-reduces and the Adam kernel are captured with the rest of the iteration (one
-        # graph replay per step, no host touch between backward and optimizer).  Opt-in: exercised on a single-rank RCCL
-        # group only (no multi-GPU box in the build environment).
+        # graph replay per step, no host touch between backward and optimizer).  Opt-in and UNVERIFIED for world > 1: exercised
+        # on a single-rank RCCL group only, there also across forced bucket overflows (no multi-GPU box in the build
+        # environment).  With more ranks every rank must run the same number of warm-up executions and re-captures -- the
+        # captured body issues collectives -- which the fixed two-iteration overflow lag is designed to guarantee.
         self._capture_coll = bool(capture_collectives) and self._collective
         if self._collective:
             import torch.distributed as dist

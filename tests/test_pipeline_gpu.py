@@ -754,10 +754,17 @@ def test_graphed_train_step_view_parallel_mode_single_rank_group():
         tiny = GraphedTrainStep(gc, cams, gts, seed=9, collectives=True)
         tiny._cap = 64
         tiny._probe_capacity = lambda: 64
+        torch.manual_seed(0); ge, _, _ = _train_fixture()
+        tcap = GraphedTrainStep(ge, cams, gts, seed=9, collectives=True, capture_collectives=True)   # ... across overflows
+        tcap._cap = 64
+        tcap._probe_capacity = lambda: 64
         for _ in range(10):
-            ea.step(); gs.step(); tiny.step(); gcap.step()
-        gs.finish(); tiny.finish(); gcap.finish()
+            ea.step(); gs.step(); tiny.step(); gcap.step(); tcap.step()
+        gs.finish(); tiny.finish(); gcap.finish(); tcap.finish()
         assert gs.recaptures == 1 and tiny.recaptures > 1 and gc.optimizer.step_count == 10
+        assert tcap.recaptures > 1 and ge.optimizer.step_count == 10
+        np.testing.assert_allclose(ge._curve_points.detach().cpu().numpy(), ga._curve_points.detach().cpu().numpy(), rtol=2e-4,
+                                   atol=2e-6, err_msg="captured collectives across a bucket overflow")
         for n in ("_curve_points", "_width", "_opacity"):
             ref = getattr(ga, n).detach().cpu().numpy()
             np.testing.assert_allclose(getattr(gb, n).detach().cpu().numpy(), ref, rtol=2e-4, atol=2e-6, err_msg=n)
@@ -793,6 +800,27 @@ def test_bench_two_rank_control_flow_rehearsal():
     assert out["n_gpus"] == 2 and out["steps"] == 8 and out["value"] > 0
     assert "roofline" in out and out["config"]["parallelism"] == "view-parallel x2"
     assert out["train_step_view_parallel_ms"] > 0
+
+
+def test_bench_default_schedule_over_single_rank_rccl():
+    """bench.py with CGS_BENCH_FORCE_DIST=1: the default schedule (graph replay per view, three views in flight, double-buffered
+    gradient sets, one all-reduce per step) and --train-step-multi with the collectives going through a real RCCL communicator
+    of ONE rank -- what the driver's N > 1 runs execute per rank, minus the peers.  `rccl_ranks` says what the group spanned."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CGS_BENCH_FORCE_DIST="1", MASTER_PORT="29547")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1", "--min-seconds", "0.2", "--config", "cfg1",
+           "--no-cpu-baseline", "--no-train-step", "--train-step-multi"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["rccl_ranks"] == 1 and out["n_gpus"] == 1 and out["value"] > 0
+    assert out["train_step_view_parallel_ms"] > 0
+    assert out["step_gradient_rel_l2_vs_serial_eager"] < 1e-3
 
 
 def test_connection_loss_matches_the_reference_block():
