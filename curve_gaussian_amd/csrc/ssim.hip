@@ -2,9 +2,9 @@
 // Replaces the reference's fusedssimCUDA / fusedssim_backwardCUDA (submodules/fused-ssim/ssim.cu:187-286, :288-366):
 // separable 11-tap Gaussian window (sigma 1.5, taps ssim.cu:9-19), zero padding ("same").
 //
-// MI355X mapping: one 256-thread workgroup per 32x32 output tile of one (batch, channel) plane.  The 42x42 halo of
+// MI355X mapping: one 512-thread workgroup per 32 x 54 output tile of one (batch, channel) plane.  The 42 x 64 halo of
 // both images is staged once in LDS; the horizontal pass produces the five filtered rows (x1, x2, x1^2, x2^2, x1 x2)
-// for all 42 rows into LDS, the vertical pass finishes them in registers (4 outputs per thread), and the SSIM map
+// for all 64 rows into LDS, the vertical pass finishes them in registers (4 outputs per thread), and the SSIM map
 // plus the three derivative maps are written with 128-byte row segments.  The reference re-loads and re-filters the
 // tile five times with a barrier-separated scratch flush in between (ssim.cu:213-260); here every input pixel is read
 // from HBM once per tile and every LDS element is written once.
@@ -16,7 +16,15 @@ __device__ constexpr float SSIM_G[11] = {0.001028380123898387f, 0.00759875820949
                                          0.10936068743467331f,  0.21300552785396576f,   0.26601171493530273f,
                                          0.21300552785396576f,  0.10936068743467331f,   0.036000773310661316f,
                                          0.0075987582094967365f, 0.001028380123898387f};
-constexpr int STX = 32, STY = 32, SR = 5, SSX = STX + 2 * SR, SSY = STY + 2 * SR;
+// Tile: 32 columns x 54 rows of output per 512-thread workgroup.  The halo is then 42 x 64: the horizontal pass has exactly
+// 64 rows x 8 groups of four columns = 512 items = one per thread (the 32 x 32 tile of rounds 1-2 filtered 42 rows for 32 of
+// output, 1.31x, in two rounds with a third of the threads idle in the second: 1.56x issue slots), and every staged row is
+// one 42-lane row segment of a wave (row-wise staging: one add of the pitch per element instead of a division by 42).
+constexpr int STX = 32, STY = 54, SR = 5, SSX = STX + 2 * SR, SSY = STY + 2 * SR;
+constexpr int STH = 512;                   // threads per workgroup: one horizontal item each
+constexpr int VR = 4;                      // output rows per thread in the vertical pass (16 row groups x 4 >= 54)
+constexpr int SROWS = SSY / (STH / 64);    // halo rows staged per wave
+static_assert(SSY == 64 && SSY * (STX / 4) == STH && (STH / 32) * VR >= STY, "tile geometry");
 
 __device__ __forceinline__ float pix_or_zero(const float* __restrict__ img, int y, int x, int H, int W) {
     return (x >= W || y >= H || x < 0 || y < 0) ? 0.0f : img[(size_t)y * W + x];  // ssim.cu:36-42
@@ -39,23 +47,27 @@ struct PhotoArgs {
     double* edge_slots;        // [PHOTO_SLOTS]
 };
 __device__ __forceinline__ void block_sum_to_slot(float v, double* slots) {
-    __shared__ float s_w[4];
+    __shared__ float s_w[STH / 64];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0)
-        atomicAdd(&slots[(blockIdx.x + blockIdx.y * gridDim.x) % PHOTO_SLOTS], (double)s_w[0] + (double)s_w[1] + (double)s_w[2] + (double)s_w[3]);
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < STH / 64; w++) t += (double)s_w[w];
+        atomicAdd(&slots[(blockIdx.x + blockIdx.y * gridDim.x) % PHOTO_SLOTS], t);
+    }
 }
 __device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
 
 template <bool FUSED>
-__global__ void __launch_bounds__(256) k_ssim_fwd(int H, int W, float C1, float C2, const float* __restrict__ img1,
+__global__ void __launch_bounds__(STH) k_ssim_fwd(int H, int W, float C1, float C2, const float* __restrict__ img1,
                                                   const float* __restrict__ img2, float* __restrict__ ssim_map,
                                                   float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq,
                                                   float* __restrict__ dm_dsigma12, PhotoArgs pa) {
     // the staged halos (s1, s2) are dead once every thread holds its horizontal windows in registers, so the filtered
-    // rows (hq) reuse their LDS: 27.7 KB instead of 42 KB per workgroup = 5 instead of 3 workgroups per CU
+    // rows (hq) reuse their LDS: 42 KB per workgroup
     __shared__ float smem[5 * SSY * (STX + 1)];
     float (*s1)[SSX + 1] = reinterpret_cast<float (*)[SSX + 1]>(smem);
     float (*s2)[SSX + 1] = reinterpret_cast<float (*)[SSX + 1]>(smem + SSY * (SSX + 1));
@@ -65,54 +77,51 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(int H, int W, float C1, float 
     const float* p1 = img1 + plane;
     const float* p2 = img2 + plane + view * ((size_t)H * W);
     const int x0 = blockIdx.x * STX, y0 = blockIdx.y * STY;
-    const int tid = threadIdx.x;
-    // halo staging in two phases -- all global loads first (addresses clamped into the image, out-of-image values zeroed
-    // afterwards), then the LDS stores: a rolled loop waited for its loads every trip, 7 dependent memory round trips per
-    // workgroup, which was most of the kernel's time
-    constexpr int NST = (SSY * SSX + 255) / 256;
-    float g1[NST], g2[NST];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // halo staging, row-wise: wave w stages halo rows 16 w .. 16 w + 15, lane = halo column (42 of 64 lanes).  Two phases --
+    // all global loads first (addresses clamped into the image, out-of-image values zeroed afterwards: ssim.cu:36-42), then
+    // the LDS stores: a loop that waits for its loads every trip costs a memory round trip per element
+    {
+        const int lx = min(lane, SSX - 1);
+        const int x = x0 + lx - SR;
+        const bool xin = lane < SSX && x >= 0 && x < W;
+        const int xc = min(max(x, 0), W - 1);
+        float g1[SROWS], g2[SROWS];
 #pragma unroll
-    for (int e = 0; e < NST; e++) {
-        const int t = tid + 256 * e;
-        const int ly = t / SSX, lx = t - ly * SSX;
-        const int y = y0 + ly - SR, x = x0 + lx - SR;
-        const bool inb = t < SSY * SSX && x >= 0 && y >= 0 && x < W && y < H;
-        const size_t o = (size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
-        const float v1 = p1[o], v2 = p2[o];
-        g1[e] = inb ? v1 : 0.f;    // ssim.cu:36-42: zero padding
-        g2[e] = inb ? v2 : 0.f;
-    }
+        for (int e = 0; e < SROWS; e++) {
+            const int y = y0 + wave * SROWS + e - SR;
+            const size_t o = (size_t)min(max(y, 0), H - 1) * W + xc;
+            const float v1 = p1[o], v2 = p2[o];
+            const bool inb = xin && y >= 0 && y < H;
+            g1[e] = inb ? v1 : 0.f;
+            g2[e] = inb ? v2 : 0.f;
+        }
+        if (lane < SSX) {
 #pragma unroll
-    for (int e = 0; e < NST; e++) {
-        const int t = tid + 256 * e;
-        if (t < SSY * SSX) {
-            const int ly = t / SSX, lx = t - ly * SSX;
-            s1[ly][lx] = (FUSED && pa.clamp) ? clamp01(g1[e]) : g1[e];
-            s2[ly][lx] = g2[e];
+            for (int e = 0; e < SROWS; e++) {
+                s1[wave * SROWS + e][lane] = (FUSED && pa.clamp) ? clamp01(g1[e]) : g1[e];
+                s2[wave * SROWS + e][lane] = g2[e];
+            }
         }
     }
     __syncthreads();
-    // Both passes are register-blocked along the filter direction: a thread produces 4 neighbouring outputs from a
-    // 14-value sliding window (3.5 LDS reads per output and quantity instead of 11 -- the kernel is LDS-bound); every
-    // output still sums its 11 taps in the reference's order.
-    // horizontal pass: 42 rows x 8 groups of 4 columns = 336 items, <= 2 per thread; windows first, then (after a
-    // barrier, because hq overwrites s1/s2) the filtering
-    constexpr int NIT = SSY * (STX / 4);
-    float uw[2][14], vw[2][14];
+    // Both passes are register-blocked along the filter direction: a thread produces neighbouring outputs from a sliding
+    // window (horizontal: 4 outputs from 14 values, 3.5 LDS reads per output and quantity instead of 11); every output still
+    // sums its 11 taps in the reference's order.
+    // horizontal pass: 64 rows x 8 groups of 4 columns = 512 items, two per thread; windows first, then (after a barrier,
+    // because hq overwrites s1/s2) the filtering
+    float uw[1][14], vw[1][14];
 #pragma unroll
-    for (int e = 0; e < 2; e++) {
-        const int it = tid + 256 * e;
-        if (it < NIT) {
-            const int r = it >> 3, c0 = (it & 7) * 4;
+    for (int e = 0; e < 1; e++) {
+        const int it = tid;
+        const int r = it >> 3, c0 = (it & 7) * 4;
 #pragma unroll
-            for (int k = 0; k < 14; k++) { uw[e][k] = s1[r][c0 + k]; vw[e][k] = s2[r][c0 + k]; }
-        }
+        for (int k = 0; k < 14; k++) { uw[e][k] = s1[r][c0 + k]; vw[e][k] = s2[r][c0 + k]; }
     }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 2; e++) {
-        const int it = tid + 256 * e;
-        if (it >= NIT) break;
+    for (int e = 0; e < 1; e++) {
+        const int it = tid;
         const int r = it >> 3, c0 = (it & 7) * 4;
         const float (&u)[14] = uw[e];
         const float (&v)[14] = vw[e];
@@ -128,38 +137,47 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(int H, int W, float C1, float 
         }
     }
     __syncthreads();
-    // vertical pass + SSIM: thread = (column tx, 4 consecutive rows)
+    // vertical pass + SSIM: thread = (column tx, VR consecutive rows), one quantity at a time (14-value window -> 4 outputs)
     const int tx = tid & 31, rg = tid >> 5;
-    float win[5][14];
+    float res[5][VR];
 #pragma unroll
-    for (int q = 0; q < 5; q++)
+    for (int q = 0; q < 5; q++) {
+        float win[VR + 10];
 #pragma unroll
-        for (int k = 0; k < 14; k++) win[q][k] = hq[q][4 * rg + k][tx];
+        for (int k = 0; k < VR + 10; k++) win[k] = hq[q][min(VR * rg + k, SSY - 1)][tx];   // (rows past the halo feed no valid output)
+#pragma unroll
+        for (int j = 0; j < VR; j++) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) a += SSIM_G[k] * win[j + k];
+            res[q][j] = a;
+        }
+    }
     float ssim_acc = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int oy = 4 * rg + j;
-        float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float g = SSIM_G[k];
-            mu1 += g * win[0][j + k]; mu2 += g * win[1][j + k];
-            e11 += g * win[2][j + k]; e22 += g * win[3][j + k]; e12 += g * win[4][j + k];
-        }
+    for (int j = 0; j < VR; j++) {
+        const int oy = VR * rg + j;
+        const float mu1 = res[0][j], mu2 = res[1][j], e11 = res[2][j], e22 = res[3][j], e12 = res[4][j];
         const int px = x0 + tx, py = y0 + oy;
-        if (px < W && py < H) {
+        if (oy < STY && px < W && py < H) {
             const float sigma1_sq = e11 - mu1 * mu1, sigma2_sq = e22 - mu2 * mu2, sigma12 = e12 - mu1 * mu2;
             const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu1_mu2 = mu1 * mu2;
             const float C = 2.0f * mu1_mu2 + C1, D = 2.0f * sigma12 + C2;
             const float A = mu1_sq + mu2_sq + C1, B = sigma1_sq + sigma2_sq + C2;
             const size_t o = plane + (size_t)py * W + px;
-            const float val = (C * D) / (A * B);
+            // One reciprocal (v_rcp_f32 + a Newton step: <= 1 ulp) instead of the reference's seven divisions per pixel
+            // (ssim.cu:268-283); the four terms of dm/dmu1 are regrouped over the common denominator:
+            //   2 mu2 D/(AB) - 2 mu2 C/(AB) - 2 mu1 CD/(A^2 B) + 2 mu1 CD/(A B^2) = 2/(AB) [mu2 (D - C) - mu1 CD (B - A)/(AB)].
+            const float AB = A * B;
+            float rAB = __builtin_amdgcn_rcpf(AB);
+            rAB = fmaf(fmaf(-AB, rAB, 1.0f), rAB, rAB);
+            const float CD = C * D;
+            const float val = CD * rAB;
             if (FUSED) ssim_acc += val; else ssim_map[o] = val;
             if (dm_dmu1) {  // ssim.cu:274-283
-                dm_dmu1[o] = (mu2 * 2.0f * D) / (A * B) - (mu2 * 2.0f * C) / (A * B) - (mu1 * 2.0f * C * D) / (A * A * B) +
-                             (mu1 * 2.0f * C * D) / (A * B * B);
-                dm_dsigma1_sq[o] = (-C * D) / (A * B * B);
-                dm_dsigma12[o] = (2 * C) / (A * B);
+                dm_dmu1[o] = 2.0f * rAB * (mu2 * (D - C) - mu1 * (val * (B - A)));
+                dm_dsigma1_sq[o] = -val * (A * rAB);
+                dm_dsigma12[o] = 2.0f * C * rAB;
             }
         }
     }
@@ -168,68 +186,65 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(int H, int W, float C1, float 
 
 // dL/dimg1 = G*(dL_dmap dm_dmu1) + 2 img1 G*(dL_dmap dm_dsigma1_sq) + img2 G*(dL_dmap dm_dsigma12)   (ssim.cu:315-365)
 template <bool FUSED>
-__global__ void __launch_bounds__(256) k_ssim_bwd(int H, int W, const float* __restrict__ img1,
+__global__ void __launch_bounds__(STH) k_ssim_bwd(int H, int W, const float* __restrict__ img1,
                                                   const float* __restrict__ img2, const float* __restrict__ dL_dmap,
                                                   const float* __restrict__ dm_dmu1,
                                                   const float* __restrict__ dm_dsigma1_sq,
                                                   const float* __restrict__ dm_dsigma12, float* __restrict__ dL_dimg1,
                                                   PhotoArgs pa) {
-    __shared__ float smem[3 * SSY * (SSX + 1)];   // s[3][42][43]; hq[3][42][33] reuses it (see k_ssim_fwd)
+    __shared__ float smem[3 * SSY * (SSX + 1)];   // s[3][64][43]; hq[3][64][33] reuses it (see k_ssim_fwd)
     float (*s)[SSY][SSX + 1] = reinterpret_cast<float (*)[SSY][SSX + 1]>(smem);
     float (*hq)[SSY][STX + 1] = reinterpret_cast<float (*)[SSY][STX + 1]>(smem);
     const size_t plane = (size_t)blockIdx.z * H * W;
     const int x0 = blockIdx.x * STX, y0 = blockIdx.y * STY;
-    const int tid = threadIdx.x;
-    // (two-phase halo staging, see k_ssim_fwd)
-    constexpr int NST = (SSY * SSX + 255) / 256;
-    float ga[NST], gb[NST], gc[NST];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (row-wise two-phase halo staging, see k_ssim_fwd)
+    {
+        const int lx = min(lane, SSX - 1);
+        const int x = x0 + lx - SR;
+        const bool xin = lane < SSX && x >= 0 && x < W;
+        const int xc = min(max(x, 0), W - 1);
+        float ga[SROWS], gb[SROWS], gc[SROWS];
 #pragma unroll
-    for (int e = 0; e < NST; e++) {
-        const int t = tid + 256 * e;
-        const int ly = t / SSX, lx = t - ly * SSX;
-        const int y = y0 + ly - SR, x = x0 + lx - SR;
-        const bool inb = t < SSY * SSX && x >= 0 && y >= 0 && x < W && y < H;
-        const size_t o = plane + (size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
-        const float g = !inb ? 0.f : (FUSED ? pa.dmap_const : dL_dmap[o]);
-        ga[e] = dm_dmu1[o] * g; gb[e] = dm_dsigma1_sq[o] * g; gc[e] = dm_dsigma12[o] * g;
-    }
+        for (int e = 0; e < SROWS; e++) {
+            const int y = y0 + wave * SROWS + e - SR;
+            const size_t o = plane + (size_t)min(max(y, 0), H - 1) * W + xc;
+            const bool inb = xin && y >= 0 && y < H;
+            const float g = !inb ? 0.f : (FUSED ? pa.dmap_const : dL_dmap[o]);
+            ga[e] = dm_dmu1[o] * g; gb[e] = dm_dsigma1_sq[o] * g; gc[e] = dm_dsigma12[o] * g;
+        }
+        if (lane < SSX) {
 #pragma unroll
-    for (int e = 0; e < NST; e++) {
-        const int t = tid + 256 * e;
-        if (t < SSY * SSX) {
-            const int ly = t / SSX, lx = t - ly * SSX;
-            s[0][ly][lx] = ga[e]; s[1][ly][lx] = gb[e]; s[2][ly][lx] = gc[e];
+            for (int e = 0; e < SROWS; e++) {
+                s[0][wave * SROWS + e][lane] = ga[e]; s[1][wave * SROWS + e][lane] = gb[e]; s[2][wave * SROWS + e][lane] = gc[e];
+            }
         }
     }
     // the epilogue's image values, requested now: their latency hides behind the two filter passes
     const int tx = tid & 31, rg = tid >> 5;
     const size_t gt_view = (FUSED && pa.view_index) ? (size_t)pa.view_index[0] * ((size_t)H * W) : 0;
-    float xs[4], ys[4];
+    float xs[VR], ys[VR];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int px = min(x0 + tx, W - 1), py = min(y0 + 4 * rg + j, H - 1);
+    for (int j = 0; j < VR; j++) {
+        const int px = min(x0 + tx, W - 1), py = min(y0 + VR * rg + j, H - 1);
         const size_t o = plane + (size_t)py * W + px;
         xs[j] = img1[o];
         ys[j] = img2[o + gt_view];
     }
     __syncthreads();
-    // register-blocked passes (see k_ssim_fwd): 4 neighbouring outputs per thread from a 14-value window
-    constexpr int NIT = SSY * (STX / 4);
-    float ww[2][3][14];
+    // register-blocked passes (see k_ssim_fwd)
+    float ww[1][3][14];
 #pragma unroll
-    for (int e = 0; e < 2; e++) {
-        const int it = tid + 256 * e;
-        if (it < NIT) {
-            const int r = it >> 3, c0 = (it & 7) * 4;
+    for (int e = 0; e < 1; e++) {
+        const int it = tid;
+        const int r = it >> 3, c0 = (it & 7) * 4;
 #pragma unroll
-            for (int k = 0; k < 14; k++) { ww[e][0][k] = s[0][r][c0 + k]; ww[e][1][k] = s[1][r][c0 + k]; ww[e][2][k] = s[2][r][c0 + k]; }
-        }
+        for (int k = 0; k < 14; k++) { ww[e][0][k] = s[0][r][c0 + k]; ww[e][1][k] = s[1][r][c0 + k]; ww[e][2][k] = s[2][r][c0 + k]; }
     }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 2; e++) {
-        const int it = tid + 256 * e;
-        if (it >= NIT) break;
+    for (int e = 0; e < 1; e++) {
+        const int it = tid;
         const int r = it >> 3, c0 = (it & 7) * 4;
         const float (&w0)[14] = ww[e][0];
         const float (&w1)[14] = ww[e][1];
@@ -246,11 +261,20 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(int H, int W, const float* __r
         }
     }
     __syncthreads();
-    float win[3][14];
+    float res[3][VR];
 #pragma unroll
-    for (int q = 0; q < 3; q++)
+    for (int q = 0; q < 3; q++) {
+        float win[VR + 10];
 #pragma unroll
-        for (int k = 0; k < 14; k++) win[q][k] = hq[q][4 * rg + k][tx];
+        for (int k = 0; k < VR + 10; k++) win[k] = hq[q][min(VR * rg + k, SSY - 1)][tx];
+#pragma unroll
+        for (int j = 0; j < VR; j++) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) a += SSIM_G[k] * win[j + k];
+            res[q][j] = a;
+        }
+    }
     float w_pos = 0.f, w_neg = 0.f, edge_acc = 0.f;
     if (FUSED) {  // loss_utils.py:100-108 (weights from the class balance of the gt edge mask)
         const float n_pos = (float)pa.n_pos[pa.view_index ? pa.view_index[0] : 0], n_neg = (float)H * (float)W - n_pos;
@@ -258,16 +282,11 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(int H, int W, const float* __r
         w_neg = 1.0f * (n_pos + 1.f) / (n_pos + n_neg);
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int oy = 4 * rg + j;
-        float a = 0.f, b = 0.f, c = 0.f;
-#pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float g = SSIM_G[k];
-            a += g * win[0][j + k]; b += g * win[1][j + k]; c += g * win[2][j + k];
-        }
+    for (int j = 0; j < VR; j++) {
+        const int oy = VR * rg + j;
+        const float a = res[0][j], b = res[1][j], c = res[2][j];
         const int px = x0 + tx, py = y0 + oy;
-        if (px < W && py < H) {
+        if (oy < STY && px < W && py < H) {
             const size_t o = plane + (size_t)py * W + px;
             const float x = xs[j], y = ys[j];
             const float xc = (FUSED && pa.clamp) ? clamp01(x) : x;
@@ -304,14 +323,14 @@ __global__ void __launch_bounds__(64) k_photo_finish(double* __restrict__ ssim_s
 void launch_ssim_fwd(hipStream_t s, int planes, int H, int W, float C1, float C2, const float* img1, const float* img2,
                      float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12) {
     ProfScope p("ssim_fwd", s);
-    hipLaunchKernelGGL(k_ssim_fwd<false>, dim3((W + STX - 1) / STX, (H + STY - 1) / STY, planes), dim3(256), 0, s, H, W,
+    hipLaunchKernelGGL(k_ssim_fwd<false>, dim3((W + STX - 1) / STX, (H + STY - 1) / STY, planes), dim3(STH), 0, s, H, W,
                        C1, C2, img1, img2, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, PhotoArgs{});
 }
 void launch_ssim_bwd(hipStream_t s, int planes, int H, int W, const float* img1, const float* img2,
                      const float* dL_dmap, const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
                      float* dL_dimg1) {
     ProfScope p("ssim_bwd", s);
-    hipLaunchKernelGGL(k_ssim_bwd<false>, dim3((W + STX - 1) / STX, (H + STY - 1) / STY, planes), dim3(256), 0, s, H, W,
+    hipLaunchKernelGGL(k_ssim_bwd<false>, dim3((W + STX - 1) / STX, (H + STY - 1) / STY, planes), dim3(STH), 0, s, H, W,
                        img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1, PhotoArgs{});
 }
 
@@ -338,8 +357,8 @@ void launch_photometric_loss(hipStream_t s, int H, int W, const float* image, co
     pa.edge_slots = slots + PHOTO_SLOTS;
     const dim3 grid((W + STX - 1) / STX, (H + STY - 1) / STY, 1);
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;  // fused_ssim/__init__.py: C1 = 0.01**2, C2 = 0.03**2
-    { ProfScope p("ssim_fwd", s); hipLaunchKernelGGL(k_ssim_fwd<true>, grid, dim3(256), 0, s, H, W, C1, C2, image, gt, nullptr, dm1, dm2, dm3, pa); }
-    { ProfScope p("ssim_bwd", s); hipLaunchKernelGGL(k_ssim_bwd<true>, grid, dim3(256), 0, s, H, W, image, gt, nullptr, dm1, dm2, dm3, grad, pa); }
+    { ProfScope p("ssim_fwd", s); hipLaunchKernelGGL(k_ssim_fwd<true>, grid, dim3(STH), 0, s, H, W, C1, C2, image, gt, nullptr, dm1, dm2, dm3, pa); }
+    { ProfScope p("ssim_bwd", s); hipLaunchKernelGGL(k_ssim_bwd<true>, grid, dim3(STH), 0, s, H, W, image, gt, nullptr, dm1, dm2, dm3, grad, pa); }
     { ProfScope p("photo_finish", s); hipLaunchKernelGGL(k_photo_finish, dim3(1), dim3(64), 0, s, pa.ssim_slots, pa.edge_slots, lambda_a, lambda_b, 1.0 / (double)N, loss); }
 }
 
