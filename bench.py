@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--views-per-step", type=int, default=8,
                     help="view mode: views per rank whose gradients are summed before the all-reduce (one optimizer "
                          "step's view batch per rank)")
+    ap.add_argument("--fused-sort", type=int, default=-1, choices=[-1, 0, 1],
+                    help="A/B: tile sort inside the forward compositor (cgs_set_fused_tile_sort); -1 = library default")
     ap.add_argument("--unit-backward", type=int, default=0, choices=[0, 3, 4],
                     help="A/B: backward compositor of the unit-colour view path (cgs_set_unit_backward); 0 = library default")
     args = ap.parse_args()
@@ -140,6 +142,8 @@ def main():
     lib = L.load()
     if args.unit_backward:
         lib.cgs_set_unit_backward(args.unit_backward)
+    if args.fused_sort >= 0:
+        lib.cgs_set_fused_tile_sort(args.fused_sort)
 
     # ---------------------------------------------------------------- workload (resident in HBM before timing)
     K, Wm = args.steps, args.warmup

@@ -470,10 +470,7 @@ int cgs_rasterize_forward_static(void* geometry_buffer, void* binning_buffer, si
     const bool defer_big = hints_load(P, width, height).big > 0;   // (from the caller's probing forwards of this shape)
     launch_scatter_bucket(s, P, radii, geom.rec, gx, gy, img.tile_count, bin.keys, (uint32_t)cap, 1, img.total + 3,
                           defer_big ? img.tile_cursor : nullptr, (uint32_t)tiles);
-    if (fuse_sort()) {
-        if (cap > render_fwd_sort_limit((uint32_t)cap))   // lists the compositor cannot sort in its LDS: sorted beforehand
-            launch_tile_sort_bucket_beyond(s, tiles, img.tile_count, bin.keys, bin.point_list, (uint32_t)cap,
-                                           render_fwd_sort_limit((uint32_t)cap));
+    if (render_fwd_can_sort((uint32_t)cap) && fuse_sort()) {
         launch_render_fwd_sorting(s, render_geo != 0, tiles, img.tile_count, bin.keys, (uint32_t)cap, img.ranges, img.total,
                                   bin.point_list, width, height, gx, geom.rec, img.final_T, img.n_contrib, background,
                                   out_color, out_invdepth, out_all_map);
@@ -648,10 +645,7 @@ int cgs_view_forward(int B, int m, const float* curve_points, const float* width
     const bool defer_big = hints_load(P, width_px, height_px).big > 0;
     launch_scatter_bucket(s, P, radii, geom.rec, gx, gy, img.tile_count, bin.keys, (uint32_t)cap, 1, img.total + 3,
                           defer_big ? img.tile_cursor : nullptr, (uint32_t)tiles);
-    if (fuse_sort()) {
-        if (cap > render_fwd_sort_limit((uint32_t)cap))   // lists the compositor cannot sort in its LDS: sorted beforehand
-            launch_tile_sort_bucket_beyond(s, tiles, img.tile_count, bin.keys, bin.point_list, (uint32_t)cap,
-                                           render_fwd_sort_limit((uint32_t)cap));
+    if (render_fwd_can_sort((uint32_t)cap) && fuse_sort()) {
         launch_render_fwd_sorting(s, aux, tiles, img.tile_count, bin.keys, (uint32_t)cap, img.ranges, img.total,
                                   bin.point_list, width_px, height_px, gx, geom.rec, img.final_T, img.n_contrib, background,
                                   out_color, out_invdepth, out_all_map, unit);

@@ -523,11 +523,6 @@ void launch_tile_sort_bucket(hipStream_t s, int tiles, const uint32_t* tile_coun
                                tile_count);
     }
 }
-void launch_tile_sort_bucket_beyond(hipStream_t s, int tiles, const uint32_t* tile_count, uint64_t* keys, uint32_t* point_list,
-                                    uint32_t cap, uint32_t min_n) {
-    ProfScope p("tile_sort_big", s);
-    hipLaunchKernelGGL(k_tile_sort<true>, dim3(tiles), dim3(256), 0, s, nullptr, keys, point_list, min_n, cap, tile_count);
-}
 uint32_t bucket_cap_limit() { return SORT_LDS_KEYS; }
 
 }  // namespace cgs

@@ -36,9 +36,6 @@ void launch_scatter_bucket(hipStream_t s, int P, const int* radii, const SplatRe
                            uint32_t* big_queue, uint32_t big_cap);
 void launch_tile_sort_bucket(hipStream_t s, int tiles, const uint32_t* tile_count, uint2* ranges, uint32_t* total,
                              uint64_t* keys, uint32_t* point_list, uint32_t cap);
-// only the tiles whose list is longer than min_n (bitonic network): the pre-pass of the sorting forward compositor
-void launch_tile_sort_bucket_beyond(hipStream_t s, int tiles, const uint32_t* tile_count, uint64_t* keys, uint32_t* point_list,
-                                    uint32_t cap, uint32_t min_n);
 uint32_t bucket_cap_limit();
 void launch_tile_sort_small(hipStream_t s, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* point_list,
                             uint32_t cap);
@@ -50,7 +47,7 @@ void launch_render_fwd(hipStream_t s, bool geo, int tiles, const uint2* ranges, 
                        int H, int grid_x, const SplatRec* rec, float* final_T, uint32_t* n_contrib,
                        const float* bg_color, float* out_color, float* out_invdepth, float* out_all_map,
                        bool unit = false);   // unit: colour == 1 and all_map[3] == 1 for every splat (render.hip, UNIT)
-uint32_t render_fwd_sort_limit(uint32_t cap);   // longest list the sorting forward handles itself at this bucket capacity
+bool render_fwd_can_sort(uint32_t cap);
 void launch_render_fwd_sorting(hipStream_t s, bool geo, int tiles, const uint32_t* tile_count, const uint64_t* keys,
                                uint32_t cap, uint2* ranges, uint32_t* total, uint32_t* point_list, int W, int H,
                                int grid_x, const SplatRec* rec, float* final_T, uint32_t* n_contrib,

@@ -86,10 +86,7 @@ constexpr uint32_t PAD_OFF = (BATCH + 1) * 16;   // byte offset of the padding e
 // UNIT: the caller guarantees colour == 1 and all_map[3] == 1 for every splat (the view entry point builds both itself:
 // unit features, gaussian_renderer/__init__.py:97,104).  Then sum w c = sum w = 1 - T (w_i = T_i - T_{i+1} telescopes), and
 // the two accumulators are not carried through the walk -- two of the six fmas per pair.
-// SORT: keys per thread of the in-kernel tile sort -- 0: the list arrives sorted (ranges / point_list), 4: buckets of up to 1024
-// entries, 8: up to 2048 (8 KB more LDS).  A tile whose list is longer than 256 * SORT entries was sorted by a separate
-// launch before (api.hip: the bitonic network for lists > 2048) and is read from point_list like a presorted one.
-template <bool GEO, int SORT, bool UNIT = false>
+template <bool GEO, bool SORT, bool UNIT = false>
 __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2* __restrict__ ranges,
                                                      const uint32_t* __restrict__ point_list, int W, int H, int grid_x,
                                                      const SplatRec* __restrict__ rec, float* __restrict__ final_T,
@@ -107,10 +104,9 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
     __shared__ uint64_t s_qmask[4][4];
     __shared__ __attribute__((aligned(16))) uint32_t s_list[4][BATCH + GROUP];   // per wave: 16 * (staged index + 1); dwords: a
                                                                                  // broadcast read hands the walk ready LDS addresses
-    __shared__ uint32_t s_ord[SORT ? 256 * SORT + RANK_U : 1];
-    __shared__ uint32_t s_si[SORT ? 256 * SORT : 1];
+    __shared__ uint32_t s_ord[SORT ? RANK_MAX + RANK_U : 1];
+    __shared__ uint32_t s_si[SORT ? RANK_MAX : 1];
     __shared__ uint32_t s_hist[SORT ? RANK_NB : 1], s_start[SORT ? RANK_NB + 1 : 1], s_mm[8];
-    bool sorted_here = false;   // (block-uniform) this workgroup sorted its bucket itself: the order lives in s_ord
     if (threadIdx.x == 0) {
         s_geo[BATCH + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
         s_at[BATCH + 1] = make_float4(0.f, 0.f, 0.f, L2_NEVER);
@@ -138,13 +134,11 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
                 }
             }
         }
-        sorted_here = n <= 256u * (uint32_t)SORT;
-        if (n > 0 && sorted_here) {   // block-uniform
-            constexpr int KPT = SORT ? SORT : 4;
-            uint32_t rank[KPT], idx[KPT];
-            tile_rank_sort<KPT>(bs.keys + base, n, RankScratch{s_ord, s_si, s_hist, s_start, s_mm}, rank, idx);
+        if (n > 0) {   // block-uniform
+            uint32_t rank[4], idx[4];
+            tile_rank_sort<4>(bs.keys + base, n, RankScratch{s_ord, s_si, s_hist, s_start, s_mm}, rank, idx);
 #pragma unroll
-            for (int q = 0; q < KPT; q++) {
+            for (int q = 0; q < 4; q++) {
                 const uint32_t i = tid + 256u * q;
                 if (i < n) {
                     s_ord[rank[q]] = idx[q];
@@ -181,7 +175,7 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
         const int progress = i * BATCH + threadIdx.x;
         uint32_t qm = 0;
         if (progress < total) {
-            const uint32_t id = sorted_here ? s_ord[progress] : (SORT ? bs.point_list : point_list)[range.x + progress] & LIST_ID_MASK;
+            const uint32_t id = SORT ? s_ord[progress] : point_list[range.x + progress];
             const SplatRec* r = rec + id;
             const float4 a = r->a, b = r->b;
             float4 sa, sb;
@@ -704,13 +698,12 @@ void launch_render_fwd(hipStream_t s, bool geo, int tiles, const uint2* ranges, 
                        int H, int grid_x, const SplatRec* rec, float* final_T, uint32_t* n_contrib,
                        const float* bg_color, float* out_color, float* out_invdepth, float* out_all_map, bool unit) {
     ProfScope p("render_fwd", s);
-    if (geo && unit) CGS_FWD3(true, 0, true, ranges, point_list, BucketSort{});
-    else if (unit) CGS_FWD3(false, 0, true, ranges, point_list, BucketSort{});
-    else if (geo) CGS_FWD3(true, 0, false, ranges, point_list, BucketSort{});
-    else CGS_FWD3(false, 0, false, ranges, point_list, BucketSort{});
+    if (geo && unit) CGS_FWD3(true, false, true, ranges, point_list, BucketSort{});
+    else if (unit) CGS_FWD3(false, false, true, ranges, point_list, BucketSort{});
+    else if (geo) CGS_FWD3(true, false, false, ranges, point_list, BucketSort{});
+    else CGS_FWD3(false, false, false, ranges, point_list, BucketSort{});
 }
-// longest list the compositor sorts itself for a bucket capacity `cap` (longer ones need launch_tile_sort_bucket_beyond first)
-uint32_t render_fwd_sort_limit(uint32_t cap) { return cap <= RANK_MAX ? RANK_MAX : 2u * RANK_MAX; }
+bool render_fwd_can_sort(uint32_t cap) { return cap <= RANK_MAX; }
 void launch_render_fwd_sorting(hipStream_t s, bool geo, int tiles, const uint32_t* tile_count, const uint64_t* keys,
                                uint32_t cap, uint2* ranges, uint32_t* total, uint32_t* point_list, int W, int H,
                                int grid_x, const SplatRec* rec, float* final_T, uint32_t* n_contrib,
@@ -719,17 +712,10 @@ void launch_render_fwd_sorting(hipStream_t s, bool geo, int tiles, const uint32_
     const BucketSort bs{tile_count, keys, point_list, ranges, total, cap};
     const uint2* no_ranges = nullptr;
     const uint32_t* no_list = nullptr;
-    if (cap <= RANK_MAX) {
-        if (geo && unit) CGS_FWD3(true, 4, true, no_ranges, no_list, bs);
-        else if (unit) CGS_FWD3(false, 4, true, no_ranges, no_list, bs);
-        else if (geo) CGS_FWD3(true, 4, false, no_ranges, no_list, bs);
-        else CGS_FWD3(false, 4, false, no_ranges, no_list, bs);
-    } else {
-        if (geo && unit) CGS_FWD3(true, 8, true, no_ranges, no_list, bs);
-        else if (unit) CGS_FWD3(false, 8, true, no_ranges, no_list, bs);
-        else if (geo) CGS_FWD3(true, 8, false, no_ranges, no_list, bs);
-        else CGS_FWD3(false, 8, false, no_ranges, no_list, bs);
-    }
+    if (geo && unit) CGS_FWD3(true, true, true, no_ranges, no_list, bs);
+    else if (unit) CGS_FWD3(false, true, true, no_ranges, no_list, bs);
+    else if (geo) CGS_FWD3(true, true, false, no_ranges, no_list, bs);
+    else CGS_FWD3(false, true, false, no_ranges, no_list, bs);
 }
 #undef CGS_FWD3
 void launch_render_bwd(hipStream_t s, bool geo, bool invd, bool colg, int tiles, const uint2* ranges,
