@@ -693,6 +693,45 @@ def test_headline_instances_meet_the_raster_criterion_on_identical_inputs(cfg, b
     fw.free()
 
 
+@pytest.mark.parametrize("W,H,B,seed,bg,opaque,wide", [(70, 50, 60, 1, 0.0, False, 0.0), (129, 97, 300, 2, 0.35, False, 0.0),
+                                                         (160, 128, 900, 3, 0.0, True, 0.0), (48, 16, 40, 4, 0.0, False, 1.5),
+                                                         (333, 211, 2500, 5, 0.2, True, 0.8), (16, 16, 5, 6, 0.0, False, 0.0)])
+def test_pair_major_backward_matches_pixel_major(W, H, B, seed, bg, opaque, wide):
+    """The two backward compositors of the unit-colour view path -- pair-major `k_render_bwd_unit` (default) and pixel-major
+    `k_render_bwd3<UNIT>` (cgs_set_unit_backward(3)) -- on the same forward: image sizes that are not multiples of the tile
+    (partial border tiles and quadrants), a single tile, tile lists longer than one 256-entry batch (dense small images), grey
+    background, opacities at the 0.99 clamp (exact walk instead of the clamp-free one), fat splats that fill whole tiles.  The
+    kernels evaluate the same closed form with different exponent roundings (quadrant- vs half-quadrant-centred), so they agree
+    to threshold flips: relative L2 and the 1e-4-of-max criterion."""
+    from curve_gaussian_amd import _lib as L
+    lib = L.load()
+    curves = S.make_curves(B, seed)
+    if opaque:
+        curves = _opaque(curves)
+    if wide:
+        curves = dict(curves)
+        curves["width"] = curves["width"] + wide          # log-width: e^wide times wider splats
+    cam = S.make_camera((0.5, -1.5, 0.8), (0.5, 0.5, 0.5), (0, 0, 1), H, W)
+    vc = _ViewCalls(curves["curve_points"], curves["width"], curves["opacity"], curves["is_bezier"], cam, 2048, bg=bg)
+    dimg = torch.randn(1, H, W, generator=torch.Generator().manual_seed(seed)).to(DEV)
+    res = {}
+    prev = lib.cgs_set_unit_backward(4)
+    try:
+        for v in (3, 4):
+            lib.cgs_set_unit_backward(v)
+            vc.forward()
+            g = [vc.f32(vc.B, 4, 3), vc.f32(vc.B, 1), vc.f32(vc.B, 1)]
+            m2d = vc.backward(dimg, *g, 0)
+            res[v] = [m2d.cpu().double()] + [t.cpu().double() for t in g]
+    finally:
+        lib.cgs_set_unit_backward(prev)
+    assert float(res[3][0].abs().max()) > 0
+    for name, a, b in zip(("dL_dmeans2D", "curve_points", "width", "opacity"), res[4], res[3]):
+        rel = float((a - b).norm() / b.norm().clamp_min(1e-30))
+        assert rel < 2e-4, f"{name}: relative L2 {rel:.2e}"
+    assert_close("dL_dmeans2D", res[4][0].numpy(), res[3][0].numpy(), abs_floor=1e-7, outlier_frac=1e-3)
+
+
 def test_graphed_train_step_image_only_forward_follows_the_same_trajectory():
     """GraphedTrainStep(aux_outputs=False): cgs_view_forward without inverse depth / all_map (the iteration reads `render`
     only, train.py:98-107).  Same image, same parameters after ten iterations as with every output, through the mask phase."""
