@@ -137,6 +137,8 @@ size_t cgs_binning_bytes(int64_t R);
  *   cgs_view_forward: arguments as the three calls it replaces; xyz / rotation / scaling may be NULL (all three) when the
  *     caller does not need the model's derived splat tensors.  out_invdepth and out_all_map may BOTH be NULL (only without
  *     colors_precomp): image-only forward for a training iteration, which reads `render` alone (train.py:98-107).  Status words as cgs_rasterize_forward_static.
+ *     B * m < 2^28 (the tile-list entries of this path carry four tag bits for the matching cgs_view_backward; the binning
+ *     buffer and the 32-byte gradient accumulator records it leaves in the geometry buffer are private to that pair of calls).
  *   cgs_view_backward: valid ONCE per cgs_view_forward (it consumes scratch sums the forward zeroed).  Only dL/dcolour
  *     flows in (train.py's loss reads `render` only); colors_precomp as given to the forward (NULL = unit colours: the
  *     compositors then use closed forms, sum w = 1 - T and dC/dalpha = (1 - bg) T_final / (1 - alpha)); dL_drotation_extra [P,4] or NULL is added to the gradient of the
