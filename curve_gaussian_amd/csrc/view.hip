@@ -65,12 +65,13 @@ __global__ void __launch_bounds__(256) k_view_fwd(
 
 // Blocks hold whole curves (curves_per_block * m active threads), as k_attrs_bwd / k_sample_bwd<3> do: the per-curve
 // opacity-logit gradient is the sample-ordered sum of its m per-splat terms.
-// 7 waves per SIMD = 72 VGPRs, the allocation of the compositors this kernel shares the GPU with when several views are
+// 6 waves per SIMD = 80 VGPRs, the allocation of the compositors this kernel shares the GPU with when several views are
 // in flight: at its natural 115 VGPRs its waves only fit a SIMD once several compositor waves have drained, and the
-// kernel (18 us alone) stretched to 102 us inside the overlapped schedule.  The 45 spilled values cost 2 % serially and
-// buy 5 % of view throughput (0.406 -> 0.385 ms per view at cfg3, three views in flight).
+// kernel (18 us alone) stretched to 102 us inside the overlapped schedule (round 2: 0.406 -> 0.385 ms per view at 72
+// VGPRs).  Round 3, with both compositors at 80 VGPRs: 7 / 6 / 5 waves = 23.8 / 20.4 / 18.4 us serial and 792 / 793 / 774
+// Msplats/s with three views in flight -- 6 takes the serial gain without the overlapped loss.
 #ifndef CGS_VIEW_BWD_WAVES
-#define CGS_VIEW_BWD_WAVES 7
+#define CGS_VIEW_BWD_WAVES 6
 #endif
 __global__ void __launch_bounds__(SAMPLE_BLOCK, CGS_VIEW_BWD_WAVES) k_view_bwd(
     int B, int m, int curves_per_block, const float* __restrict__ cp, const float* __restrict__ width,
