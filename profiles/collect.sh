@@ -12,7 +12,6 @@ cd /tmp && export TMPDIR=/tmp
 # serial eager schedule of the headline body (fused direct entry points, one view at a time, no graph)
 B="python $R/bench.py --streams 1 --views-per-step 1 --no-graph --no-cpu-baseline --no-kernel-times --no-train-step --min-seconds 0"
 O=$R/gpurun_out/$TAG
-rm -rf $O    # (gpurun merges into an existing directory: stale files of an earlier collection would be summed in)
 mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $B --steps 16 --warmup 2 > $O/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc1 -- $B --steps 4 --warmup 1 > $O/pmc1.log 2>&1

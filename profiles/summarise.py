@@ -52,7 +52,15 @@ stats("trace_graph", f"profiles/{rnd}_kernel_stats_graph.csv",
       "so per-kernel durations are inflated relative to the serial schedule)\n")
 
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
+# one counter file per pass: gpurun MERGES a new collection into an existing gpurun_out/<tag>/, so a pass directory can hold
+# the files of an earlier collection as well -- only the newest of each pass counts
+import os
+newest = {}
 for f in glob.glob(f"{root}/*/*/*_counter_collection.csv"):
+    k = f.split(os.sep)[-3]
+    if k not in newest or os.path.getmtime(f) > os.path.getmtime(newest[k]):
+        newest[k] = f
+for f in newest.values():
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
         if k:
