@@ -732,6 +732,30 @@ def test_pair_major_backward_matches_pixel_major(W, H, B, seed, bg, opaque, wide
     assert_close("dL_dmeans2D", res[4][0].numpy(), res[3][0].numpy(), abs_floor=1e-7, outlier_frac=1e-3)
 
 
+def test_headline_backward_is_linear_in_the_image_gradient_at_cfg3():
+    """Size-independent property of the headline backward (cgs_view_backward, pair-major unit compositor) at the BASELINE size it
+    is benchmarked on: the curve-parameter gradients are linear in the upstream image gradient -- g(2 a - 3 b) = 2 g(a) - 3 g(b)
+    up to the order of the compositor's float atomics -- and nothing for a zero image gradient (the clamp-free walk divides by
+    (E - 1) / K with 1e30 standing in for 1 / 0: 1e-30 per pair instead of an exact zero)."""
+    curves, cams = S.make_config("cfg3", n_views=1)
+    vc = _ViewCalls(curves["curve_points"], curves["width"], curves["opacity"], curves["is_bezier"], cams[0], 1024)
+    gen = torch.Generator().manual_seed(23)
+    da = torch.randn(1, vc.H, vc.W, generator=gen).to(DEV)
+    db = torch.randn(1, vc.H, vc.W, generator=gen).to(DEV)
+
+    def grads(dimg):
+        vc.forward()
+        g = [vc.f32(vc.B, 4, 3), vc.f32(vc.B, 1), vc.f32(vc.B, 1)]
+        m2d = vc.backward(dimg, *g, 0)
+        return [m2d.double()] + [t.double() for t in g]
+    ga, gb, gc, gz = grads(da), grads(db), grads(2.0 * da - 3.0 * db), grads(torch.zeros_like(da))
+    for name, a, b, c, z in zip(("dL_dmeans2D", "curve_points", "width", "opacity"), ga, gb, gc, gz):
+        want = 2.0 * a - 3.0 * b
+        rel = float((c - want).norm() / want.norm())
+        assert rel < 1e-4, f"{name}: relative L2 {rel:.2e}"
+        assert float(z.abs().max()) < 1e-20, name
+
+
 def test_graphed_train_step_image_only_forward_follows_the_same_trajectory():
     """GraphedTrainStep(aux_outputs=False): cgs_view_forward without inverse depth / all_map (the iteration reads `render`
     only, train.py:98-107).  Same image, same parameters after ten iterations as with every output, through the mask phase."""
