@@ -756,6 +756,56 @@ def test_headline_backward_is_linear_in_the_image_gradient_at_cfg3():
         assert float(z.abs().max()) < 1e-20, name
 
 
+def test_unit_colour_instances_agree_with_the_general_ones_on_random_scenes():
+    """Seeded fuzz of the whole per-view path: cgs_view_forward / cgs_view_backward WITHOUT colors_precomp (unit-colour forward,
+    pair-major unit backward) against the same calls WITH an all-ones colors_precomp (general compositor instances) on 16 random
+    scenes -- curve counts 40 .. 8 000, odd image sizes, cameras outside, at the rim of and inside the cloud (near culls,
+    screen-filling splats), widths up to e^2.5 times the default, opacities from 0.1 to 0.97, black and grey background."""
+    import random
+    cams_at = [((0.5, -1.6, 0.7), (0.5, 0.5, 0.5), (0, 0, 1)), ((2.0, 1.4, 1.1), (0.4, 0.5, 0.6), (0, 0, 1)),
+               ((0.5, 0.5, 0.5), (0.9, 0.2, 0.5), (0, 0, 1)), ((0.5, -0.6, 0.5), (0.5, 0.5, 0.5), (0, 0, 1))]
+    rng = random.Random(3)
+    done = 0
+    for case in range(24):
+        B = rng.choice([40, 150, 600, 2500, 8000])
+        H, W = rng.choice([64, 77, 128, 200, 333]), rng.choice([64, 130, 176, 256, 401])
+        seed = rng.randrange(10000)
+        curves = S.make_curves(B, seed)
+        curves["width"] = curves["width"] + rng.choice([0.0, 0.8, 1.6, 2.5])
+        curves["opacity"] = curves["opacity"] + rng.choice([-2.0, 0.0, 3.0])
+        cam = S.make_camera(*cams_at[rng.randrange(len(cams_at))], H, W)
+        bg = rng.choice([0.0, 0.0, 0.4])
+        out = {}
+        for name, colors in (("unit", None), ("general", torch.ones(B * 12))):
+            vc = _ViewCalls(curves["curve_points"], curves["width"], curves["opacity"], curves["is_bezier"], cam, 4096, colors=colors, bg=bg)
+            try:
+                vc.forward()
+            except AssertionError:            # tile lists beyond the largest bucket (dense cloud on a tiny image): not this test's subject
+                out = None
+                break
+            g = [vc.f32(B, 4, 3), vc.f32(B, 1), vc.f32(B, 1)]
+            dimg = torch.randn(1, H, W, generator=torch.Generator().manual_seed(seed)).to(DEV)
+            m2d = vc.backward(dimg, *g, 0)
+            out[name] = dict(color=vc.color.clone(), omap=vc.omap.clone(), invd=vc.invd.clone(), radii=vc.radii.clone(), m2d=m2d,
+                             g=[t.clone() for t in g])
+        if out is None:
+            continue
+        u, gen = out["unit"], out["general"]
+        assert torch.equal(u["radii"], gen["radii"])
+        amax = lambda a, b: float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+        l2 = lambda a, b: float((a - b).norm()) / max(float(b.norm()), 1e-30)
+        where = f"case {case}: B={B} {W}x{H} bg={bg} seed={seed}"
+        for k in ("color", "omap", "invd"):
+            assert amax(u[k], gen[k]) < 2e-5, f"{where}: {k} {amax(u[k], gen[k]):.2e}"
+        assert l2(u["m2d"], gen["m2d"]) < 1e-3, f"{where}: dL_dmeans2D {l2(u['m2d'], gen['m2d']):.2e}"
+        for name, a, b in zip(("curve_points", "width", "opacity"), u["g"], gen["g"]):
+            assert l2(a, b) < 1e-3 and bool(torch.isfinite(a).all()), f"{where}: dL/d{name} {l2(a, b):.2e}"
+        done += 1
+        if done == 16:
+            break
+    assert done >= 12
+
+
 def test_graphed_train_step_image_only_forward_follows_the_same_trajectory():
     """GraphedTrainStep(aux_outputs=False): cgs_view_forward without inverse depth / all_map (the iteration reads `render`
     only, train.py:98-107).  Same image, same parameters after ten iterations as with every output, through the mask phase."""
