@@ -4,7 +4,7 @@
 Metric (BASELINE.json): Msplats rasterized/s, forward+backward, plus train-step ms and the HBM-roofline fraction.
 A "step" is one gradient-exchange batch: `--views-per-step` (default 8) independent views per rank through the per-view
 hot path, their curve-parameter gradients summed and (N > 1) all-reduced once -- the unit BASELINE's "train-step" implies.
-The timed region is the K-step region repeated until it lasts >= 0.5 s (`repeats`, `views_timed` in the output; `steps`
+The timed region is the K-step region repeated until it lasts >= --min-seconds (3 s; `repeats`, `views_timed` in the output; `steps`
 and `warmup` are echoed unchanged), so the driver's small K still measures a steady state.  One view is:
     rasterizer forward  (preprocess -> tile binning + per-tile depth sort -> alpha-composite)
   + rasterizer backward (dL/d{mean2D,conic,opacity,colour,all_map} -> dL/d{mean3D,scale,rotation})
@@ -30,6 +30,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise); exported by the image,
+# kept here for launches from a clean environment
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 
