@@ -81,6 +81,9 @@ def committed_profile(config):
     return None
 
 
+ISSUE_PEAK_G = 1024 * 2.4 / 2.0   # G wave-instructions/s: 1024 SIMDs, 2.4 GHz, 2 cycles per wave64 FMA-class instruction
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -588,8 +591,25 @@ def main():
                                     "step s+1)" if n_sets > 1 else "join per step",
                    "parallelism": f"view-parallel x{world}"},
     }
-    if dist is not None:
-        out["rccl_ranks"] = dist.get_world_size()
+    # how many ranks the step's collective really spanned (1: no process group, nothing was exchanged) and how the step
+    # boundary is scheduled -- top-level, whatever N, so a scaling record can be read without the config block
+    out["rccl_ranks"] = dist.get_world_size() if dist is not None else 1
+    out["step_boundary"] = out["config"]["step_boundary"]
+    if world > 1:
+        # what this run should show, machine-readable: per-rank step = G views at the 1-GPU per-view
+        # time, ONE all-reduce of 38 floats per curve off the critical path (double-buffered gradient sets); ring wire time
+        # 2 (N-1)/N S over one xGMI link direction (~64 GB/s) + per-hop latency; efficiency >= 0.95 at N = 8
+        S_bytes = 38 * 4 * B
+        wire_ms = 2.0 * (world - 1) / world * S_bytes / 64e9 * 1e3
+        out["expected_scaling"] = {
+            "all_reduce_bytes": S_bytes, "all_reduce_wire_ms_ring_one_link": round(wire_ms, 4),
+            "all_reduce_latency_ms": round(2 * (world - 1) * 0.008, 3),
+            "overlapped_with_next_step": n_sets > 1,
+            "min_efficiency_vs_1gpu": {2: 0.97, 4: 0.96, 8: 0.95}.get(world, 0.95),
+            "reference_predictions": {"cfg3": {"step_ms": 2.0, "all_reduce_bytes": 2533000},
+                                      "cfg5": {"step_ms": 5.6, "all_reduce_bytes": 12667000}},
+            "if_below": "check step_boundary == double-buffered (else the all-reduce serialises with the views); then "
+                        "NCCL_MAX_NCHANNELS=4 (RCCL channels starving the compositors of CUs)"}
     if vp_train_ms is not None:   # one optimizer step = `world` views (one per rank), gradients summed by ONE all-reduce
         out["train_step_view_parallel_ms"] = round(vp_train_ms, 4)
     if grad_check is not None:
@@ -616,29 +636,43 @@ def main():
                            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                            "kernel_ms": round(kernel_ms[dom], 5), "algorithmic_bytes_per_launch": int(alg_dom)}
         if fused_sort:
+            # a build that removes passes still reports against the reference algorithm's bytes for the work the
+            # launch does (here K4 + K5 + K6: it sorts its tile's bucket, in LDS, before compositing).  The same time on the
+            # K6 bytes alone -- what this launch can actually move through HBM -- is reported beside it, by name.
             k6 = KERNEL_ALG_BYTES["render_fwd"](P, R_mean, H * W, tiles)
-            out["roofline"]["algorithmic_bytes_note"] = ("K4 + K5 + K6: this launch sorts its tile's bucket before compositing; "
-                                                         f"on the K6 bytes alone ({int(k6)}) frac = "
-                                                         f"{k6 / (kernel_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS:.4f}")
+            out["roofline"]["algorithmic_bytes_note"] = "K4 + K5 + K6 of the reference algorithm (SURVEY 8d); frac_k6_only: K6 alone"
+            out["roofline"]["algorithmic_bytes_k6_only"] = int(k6)
+            out["roofline"]["frac_k6_only"] = round(k6 / (kernel_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        if traffic:
+            out["roofline"]["frac_on_measured_traffic"] = round(traffic / (kernel_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         if prof is not None:
             out["roofline"]["traffic_source"] = prof["source"]
             # the counters come from ANOTHER run (another box) than kernel_ms: the kernel's duration in that run, for scale
             pk = prof["traffic"].get(dom, {}).get("kernel_us_in_trace")
             if pk is not None:
                 out["roofline"]["profile_kernel_ms"] = round(pk * 1e-3, 5)
+                # the same fraction with time, traffic and counters from ONE collection (the committed profile run)
+                out["roofline"]["frac_in_profile_run"] = round(alg_dom / (pk * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
             insts = prof["pmc"].get(dom, {})
             if "SQ_INSTS_VALU" in insts:
                 # what binds the dominant kernel: the SIMDs' vector issue.  Instruction counts per
                 # launch from the committed PMC pass, rate from the live kernel time; peak = 1024 SIMDs x 2.4 GHz / 2
                 # cycles per wave64 VALU instruction (v_fma_f32; most other instructions take 4 or more).
+                # ONE peak for this quantity (DESIGN.md section 4 quotes the same): a SIMD issues a wave64 f32 FMA-class
+                # instruction every 2 cycles, everything else (compares, selects, moves, integer) every 4 or more; the peak
+                # is the FMA rate, and the measured mix's average cost is reported beside it so that "frac" can be read.
                 rate = insts["SQ_INSTS_VALU"] / (kernel_ms[dom] * 1e-3) / 1e9
-                peak = 1024 * 2.4 / 2.0
+                peak = ISSUE_PEAK_G
                 out["issue_roofline"] = {"bound": "valu-issue", "kernel": dom, "source": prof["source"],
                                          "valu_wave_instr_per_launch": int(insts["SQ_INSTS_VALU"]),
                                          "salu_instr_per_launch": int(insts.get("SQ_INSTS_SALU", 0)),
                                          "lds_instr_per_launch": int(insts.get("SQ_INSTS_LDS", 0)),
                                          "achieved": round(rate, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
-                                         "frac": round(rate / peak, 4)}
+                                         "frac": round(rate / peak, 4),
+                                         "simd_cycles_per_valu_instr": round(1024 * 2.4 / rate, 3),
+                                         "peak_note": "1024 SIMDs x 2.4 GHz / 2 cycles (wave64 v_fma_f32); 4-cycle "
+                                                      "instructions (v_cmp, v_cndmask, integer) halve it: a mix at "
+                                                      "simd_cycles_per_valu_instr ~3 is issue-saturated"}
         out["kernel_ms_per_view"] = {k: round(v, 5) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])}
         out["whole_path"] = {"algorithmic_bytes_per_view": int(alg_view),
                              "achieved_GBps": round(alg_view / (ms_per_view * 1e-3) / 1e9, 2),   # whole job, per view
@@ -655,6 +689,32 @@ def main():
         tcams = my_cams[:8]
         gg = torch.Generator(device="cpu").manual_seed(7)
         gts = [((torch.rand(1, H, W, generator=gg) > 0.97).float() * torch.rand(1, H, W, generator=gg)).to(dev) for _ in tcams]
+        # the literal drop-in route: gaussian_renderer.render() with the reference's default arguments (train.py:95-97) and
+        # autograd's backward of the image, one view at a time, eager launches.  For a GaussianCurveModel under the default
+        # pipeline flags this is ONE autograd node over cgs_view_forward_checked / cgs_view_backward -- the headline kernels.
+        from curve_gaussian_amd.gaussian_renderer import PipelineParams, render as dropin_render
+        pipe = PipelineParams()
+        def dropin_pass(cams, **kw):
+            for c in cams:
+                pkg = dropin_render(c, gm, pipe, bg, **kw)
+                # (retain_graph: the general route differentiates through the prepare_scaling_rot graph, which train.py
+                # rebuilds after every optimizer step and this loop keeps)
+                torch.autograd.backward(pkg["render"], dL_dcolor.reshape(pkg["render"].shape), retain_graph=True)
+        for name, kw in (("dropin_view_ms", {}), ("dropin_view_no_visibility_ms", {"compute_visibility": False, "compute_rend_dir": False}),
+                         ("dropin_view_general_route_ms", {"fused": False})):
+            dropin_pass(tcams[:3], **kw)
+            torch.cuda.synchronize()
+            td0 = time.perf_counter()
+            for _ in range(4):
+                dropin_pass(tcams, **kw)
+            torch.cuda.synchronize()
+            out[name] = round((time.perf_counter() - td0) / (4 * len(tcams)) * 1e3, 4)
+        out["dropin_note"] = ("dropin_view_ms: render(cam, gaussians, pipe, bg) with the reference's defaults + backward of the "
+                              "image per view, eager (fused view route: cgs_view_forward_checked / cgs_view_backward); "
+                              "..._no_visibility: without the nonzero() host sync and the world-space direction map; "
+                              "..._general_route: fused=False (GaussianRasterizer, the round-3 drop-in path)")
+        for prm in (gm._curve_points, gm._width, gm._opacity, gm._mask):
+            prm.grad = None
         ts = TrainStep(gm, tcams, gts)
         for _ in range(3):
             ts.step()

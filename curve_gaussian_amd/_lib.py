@@ -25,6 +25,9 @@ SIGNATURES = {
                                           _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "cgs_view_forward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _vp, _vp, C.c_size_t, _vp, C.c_uint32,
                               _vp, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cgs_view_forward_checked": (_i64, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _vp, _vp, C.c_size_t, _vp,
+                                        C.c_uint32, _vp, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cgs_bucket_capacity_hint": (C.c_uint32, [_i, _i, _i]),
     "cgs_view_backward_scratch_floats": (C.c_size_t, [_i, _i]),
     "cgs_view_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp,
                                _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
@@ -35,6 +38,7 @@ SIGNATURES = {
     "cgs_adam_state_bytes": (C.c_size_t, []),
     "cgs_set_tile_culling": (_i, [_i]),
     "cgs_set_fused_tile_sort": (_i, [_i]),
+    "cgs_set_forward_pipeline": (_i, [_i]),
     "cgs_set_unit_backward": (_i, [_i]),
     "cgs_reset_binning_hints": (None, []),
     "cgs_last_forward_stats": (None, [C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i)]),

@@ -147,6 +147,10 @@ static hipError_t zero_async(void* p, size_t bytes, hipStream_t s) {
 static std::atomic<int> g_unit_bwd{4};     // backward compositor of the unit-colour view path: 4 = pair-major (render_unit_bwd.hip), 3 = pixel-major k_render_bwd3<UNIT>
 static std::atomic<int> g_fuse_sort{1};    // tile sort inside the forward compositor (cgs_set_fused_tile_sort)
 static inline bool fuse_sort() { return g_fuse_sort.load(std::memory_order_relaxed) != 0; }
+// the fused sort + composite as the persistent producer / walker kernel of render_pipe.hip (cgs_set_forward_pipeline;
+// CGS_FWD_PIPE=1 in the environment selects it for A/B runs; off by default: measured slower, profiles/r04_experiments.md)
+static std::atomic<int> g_fwd_pipe{[] { const char* e = getenv("CGS_FWD_PIPE"); return (e && e[0] == '1') ? 1 : 0; }()};
+static inline bool fwd_pipe() { return g_fwd_pipe.load(std::memory_order_relaxed) != 0; }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace cgs
@@ -183,6 +187,7 @@ void cgs_reset_binning_hints(void) {
 int cgs_set_tile_culling(int on) {
     return g_tile_cull.exchange(on ? 1 : 0, std::memory_order_relaxed);
 }
+int cgs_set_forward_pipeline(int on) { return g_fwd_pipe.exchange(on ? 1 : 0, std::memory_order_relaxed); }
 int cgs_set_fused_tile_sort(int on) {
     return g_fuse_sort.exchange(on ? 1 : 0, std::memory_order_relaxed);
 }
@@ -470,7 +475,11 @@ int cgs_rasterize_forward_static(void* geometry_buffer, void* binning_buffer, si
     const bool defer_big = hints_load(P, width, height).big > 0;   // (from the caller's probing forwards of this shape)
     launch_scatter_bucket(s, P, radii, geom.rec, gx, gy, img.tile_count, bin.keys, (uint32_t)cap, 1, img.total + 3,
                           defer_big ? img.tile_cursor : nullptr, (uint32_t)tiles);
-    if (render_fwd_can_sort((uint32_t)cap) && fuse_sort()) {
+    if (render_fwd_pipe_ok((uint32_t)cap) && fuse_sort() && fwd_pipe()) {
+        launch_render_fwd_pipe(s, render_geo != 0, tiles, img.tile_count, bin.keys, (uint32_t)cap, img.ranges, img.total,
+                               bin.point_list, width, height, gx, geom.rec, img.final_T, img.n_contrib, background, out_color,
+                               out_invdepth, out_all_map, false, img.work);
+    } else if (render_fwd_can_sort((uint32_t)cap) && fuse_sort()) {
         launch_render_fwd_sorting(s, render_geo != 0, tiles, img.tile_count, bin.keys, (uint32_t)cap, img.ranges, img.total,
                                   bin.point_list, width, height, gx, geom.rec, img.final_T, img.n_contrib, background,
                                   out_color, out_invdepth, out_all_map);
@@ -592,7 +601,27 @@ int cgs_sample_curves_forward(int B, int m, const float* curve_points, const flo
 // ---------------------------------------------------------------------------------------------- fused per-view path
 // One view of the training configuration, curve parameters in, image out (and back): the per-splat chains are fused
 // (view.hip), the rasterizer is the sync-free single-pass bucket pipeline of cgs_rasterize_forward_static.
-int cgs_view_forward(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
+// Longest tile list of a finished scatter, for the checked (blocking) view forward: one small launch between the scatter
+// and the compositor, so the host's wait ends when the BINNING is done and the compositor is still running.
+__global__ void __launch_bounds__(256) k_count_stats(const uint32_t* __restrict__ tile_count, int tiles, uint32_t* __restrict__ out2) {
+    uint32_t mx = 0, sum = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < tiles; i += gridDim.x * 256) {
+        const uint32_t c = tile_count[i];
+        mx = max(mx, c);
+        sum += c;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
+        sum += (uint32_t)__shfl_xor((int)sum, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out2[0], sum);   // [0] = num_rendered, [1] = longest list: the exact path's meaning of these two words
+        atomicMax(&out2[1], mx);
+    }
+}
+
+static int64_t view_forward_impl(bool checked, int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
                      float eps, double* norms, const float* opacity_logit, const float* mask_logit, float mask_thr,
                      const float* colors_precomp, void* geometry_buffer, void* binning_buffer, size_t binning_bytes,
                      void* image_buffer, uint32_t bucket_capacity, const float* background, int width_px, int height_px,
@@ -645,7 +674,33 @@ int cgs_view_forward(int B, int m, const float* curve_points, const float* width
     const bool defer_big = hints_load(P, width_px, height_px).big > 0;
     launch_scatter_bucket(s, P, radii, geom.rec, gx, gy, img.tile_count, bin.keys, (uint32_t)cap, 1, img.total + 3,
                           defer_big ? img.tile_cursor : nullptr, (uint32_t)tiles);
-    if (render_fwd_can_sort((uint32_t)cap) && fuse_sort()) {
+    // checked: the longest tile list (and the instance count, oversized-rect count) travel to the host right behind the
+    // scatter; the compositor is queued before the host waits, so the wait overlaps it
+    static thread_local uint32_t* h_stat = nullptr;   // pinned: instances, longest list, overflow flag (not yet set), oversized rects
+    static thread_local hipEvent_t ev = nullptr;
+    if (checked) {
+        if (!h_stat) {
+            if (hipHostMalloc((void**)&h_stat, 4 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
+                hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+                set_error("pinned readback buffer / event creation failed");
+                h_stat = nullptr;
+                return CGS_ERR_HIP;
+            }
+        }
+        // words [0], [1] of the status block are unused on the bucket path (the exact path's R / longest list)
+        hipLaunchKernelGGL(k_count_stats, dim3(std::min(64, (tiles + 255) / 256)), dim3(256), 0, s, img.tile_count, tiles, img.total);
+        hipError_t e = hipMemcpyAsync(h_stat, img.total, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipEventRecord(ev, s);
+        if (e != hipSuccess) {
+            set_error("cgs_view_forward_checked: status readback failed: %s", hipGetErrorString(e));
+            return CGS_ERR_HIP;
+        }
+    }
+    if (render_fwd_pipe_ok((uint32_t)cap) && fuse_sort() && fwd_pipe()) {
+        launch_render_fwd_pipe(s, aux, tiles, img.tile_count, bin.keys, (uint32_t)cap, img.ranges, img.total, bin.point_list,
+                               width_px, height_px, gx, geom.rec, img.final_T, img.n_contrib, background, out_color,
+                               out_invdepth, out_all_map, unit, img.work);
+    } else if (render_fwd_can_sort((uint32_t)cap) && fuse_sort()) {
         launch_render_fwd_sorting(s, aux, tiles, img.tile_count, bin.keys, (uint32_t)cap, img.ranges, img.total,
                                   bin.point_list, width_px, height_px, gx, geom.rec, img.final_T, img.n_contrib, background,
                                   out_color, out_invdepth, out_all_map, unit);
@@ -655,7 +710,50 @@ int cgs_view_forward(int B, int m, const float* curve_points, const float* width
                           img.n_contrib, background, out_color, out_invdepth, out_all_map, unit);
     }
     if (!check_launch("view_forward", false, s)) return CGS_ERR_HIP;
+    if (checked) {
+        const hipError_t e = hipEventSynchronize(ev);
+        if (e != hipSuccess) {
+            set_error("cgs_view_forward_checked: status readback failed: %s", hipGetErrorString(e));
+            return CGS_ERR_HIP;
+        }
+        const uint32_t longest = h_stat[1];
+        hints_update(P, width_px, height_px, (uint64_t)longest <= cap ? (int64_t)h_stat[0] : -1, longest, (int64_t)h_stat[3]);
+        g_last_stats[0] = (int64_t)h_stat[0]; g_last_stats[1] = (int64_t)longest; g_last_stats[2] = 1;
+        return (int64_t)longest;
+    }
     return CGS_OK;
+}
+
+int cgs_view_forward(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
+                     float eps, double* norms, const float* opacity_logit, const float* mask_logit, float mask_thr,
+                     const float* colors_precomp, void* geometry_buffer, void* binning_buffer, size_t binning_bytes,
+                     void* image_buffer, uint32_t bucket_capacity, const float* background, int width_px, int height_px,
+                     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                     float* out_color, float* out_invdepth, float* out_all_map, int* radii, float* xyz, float* rotation,
+                     float* scaling, void* stream_) {
+    return (int)view_forward_impl(false, B, m, curve_points, width, is_bezier, coef, eps, norms, opacity_logit, mask_logit,
+                                  mask_thr, colors_precomp, geometry_buffer, binning_buffer, binning_bytes, image_buffer,
+                                  bucket_capacity, background, width_px, height_px, viewmatrix, projmatrix, cam_pos, tan_fovx,
+                                  tan_fovy, out_color, out_invdepth, out_all_map, radii, xyz, rotation, scaling, stream_);
+}
+int64_t cgs_view_forward_checked(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier,
+                                 const float* coef, float eps, double* norms, const float* opacity_logit,
+                                 const float* mask_logit, float mask_thr, const float* colors_precomp, void* geometry_buffer,
+                                 void* binning_buffer, size_t binning_bytes, void* image_buffer, uint32_t bucket_capacity,
+                                 const float* background, int width_px, int height_px, const float* viewmatrix,
+                                 const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                                 float* out_color, float* out_invdepth, float* out_all_map, int* radii, float* xyz,
+                                 float* rotation, float* scaling, void* stream_) {
+    return view_forward_impl(true, B, m, curve_points, width, is_bezier, coef, eps, norms, opacity_logit, mask_logit, mask_thr,
+                             colors_precomp, geometry_buffer, binning_buffer, binning_bytes, image_buffer, bucket_capacity,
+                             background, width_px, height_px, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, out_color,
+                             out_invdepth, out_all_map, radii, xyz, rotation, scaling, stream_);
+}
+uint32_t cgs_bucket_capacity_hint(int P, int width, int height) {
+    const int64_t mx = hints_load(P, width, height).max;
+    if (mx <= 0) return 0u;
+    const uint64_t cap = (((uint64_t)mx * 5 / 4 + 64) + 63) & ~63ull;
+    return (uint32_t)std::min<uint64_t>(cap, bucket_cap_limit());
 }
 
 size_t cgs_view_backward_scratch_floats(int B, int m) { return (size_t)(B > 0 ? B : 0) * (size_t)(m > 0 ? m : 0) * 15; }

@@ -37,6 +37,7 @@ struct GeomState {            // carved from the geometry buffer
     float* rgb;               // [P]   SH-evaluated colour (SH path only)
     uint8_t* clamped;         // [P]
 };
+constexpr int WORK_WORDS = 64 * 32;   // 64 queue counters, one per 128-byte line (render_pipe.hip)
 constexpr int TOTAL_PARTS = 256;
 constexpr int TOTAL_WORDS = 4 + 2 * TOTAL_PARTS;
 struct ImageState {           // carved from the image buffer
@@ -45,6 +46,7 @@ struct ImageState {           // carved from the image buffer
     uint2* ranges;            // [tiles]  [start,end) in the sorted list
     uint32_t* tile_count;     // [tiles]
     uint32_t* tile_cursor;    // [tiles]
+    uint32_t* work;           // [WORK_WORDS]  cleared with the histogram: the tile-queue counters of the persistent forward compositor
     uint32_t* total;          // [TOTAL_WORDS]  [0] = R, [1] = longest list (exact path); [4 + 2k], [5 + 2k] = partial
                               //                sum / max of the tile lists with tile % TOTAL_PARTS == k (bucket path)
 };
@@ -74,6 +76,7 @@ static inline ImageState image_from_chunk(char*& chunk, size_t npix, size_t tile
     carve(chunk, s.ranges, tiles);
     carve(chunk, s.tile_count, tiles);
     carve(chunk, s.tile_cursor, tiles);
+    carve(chunk, s.work, WORK_WORDS);          // (between the cursors and the status words: inside the span the forward clears)
     carve(chunk, s.total, TOTAL_WORDS + 32);   // + 32 words the library never clears: [TOTAL_WORDS] = sticky overflow count
     return s;
 }

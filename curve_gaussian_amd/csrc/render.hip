@@ -66,6 +66,10 @@ constexpr int GROUP = 16;
 #ifndef CGS_FWD3_WAVES
 #define CGS_FWD3_WAVES 6
 #endif
+// fused rank + stage path of the sorting forward for tiles whose list fits one batch (0: always the general sort)
+#ifndef CGS_FWD_FAST
+#define CGS_FWD_FAST 1
+#endif
 // backward, training configuration: 6 waves per SIMD like the forward (80 VGPRs, 5 spills; 26.2 KB of LDS with the first 104
 // list positions of each quadrant parked).  Alone it runs as fast with 5 waves, 95 VGPRs and all 128 positions parked
 // (176 us); with three views in flight the matching footprints let forward and backward workgroups of neighbouring views
@@ -116,11 +120,16 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
     const int lane = g.lane;
     const float X0 = (float)(g.tx * TILE), Y0 = (float)(g.ty * TILE);
     uint2 range;
+    bool prestaged = false;   // block-uniform: the tile's (single) batch was staged by the fused rank + stage path below
     if (SORT) {
         const uint32_t tid = threadIdx.x;
+        const uint32_t base = g.tile * bs.cap;
+        // the thread's key is requested before the tile's count is known (slot tid exists whenever tid < cap): the two
+        // loads are in flight together instead of one behind the other
+        uint64_t key0 = ~0ull;
+        if (CGS_FWD_FAST && tid < bs.cap) key0 = bs.keys[base + tid];
         const uint32_t cnt = bs.tile_count[g.tile];
         const uint32_t n = min(cnt, bs.cap);
-        const uint32_t base = g.tile * bs.cap;
         range = make_uint2(base, base + n);
         if (tid == 0) {
             bs.ranges[g.tile] = range;
@@ -134,7 +143,49 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
                 }
             }
         }
-        if (n > 0) {   // block-uniform
+        if (CGS_FWD_FAST && n > 0 && n <= (uint32_t)BATCH) {   // block-uniform
+            // ---- single-batch tile (9 tiles in 10 at cfg3): rank and stage in one pass.  Thread t owns key t: its splat's
+            // record is requested BEFORE the ranking loop (the index is in the key), the loop runs while the gather is in
+            // flight, and the thread stages the record straight into slot rank(t) of the batch arrays -- no ordered index
+            // array, no second dependent gather, two workgroup barriers instead of eight.  Equal depths (two keys claiming one
+            // slot: about one tile in 600) are detected by the returning LDS exchange that publishes the quadrant mask, and
+            // the tile is redone by the general path below.
+            const bool has = tid < n;
+            const uint32_t depth = has ? (uint32_t)(key0 >> 32) : ~0u;
+            const uint32_t id = has ? (uint32_t)key0 : 0u;
+            const SplatRec* r = rec + id;
+            float4 ra = make_float4(0.f, 0.f, 1.f, 0.f), rb = make_float4(1.f, 0.f, 0.f, 0.f), rc = ra;
+            float tau2 = -1.f;
+            if (has) {
+                ra = r->a;
+                rb = r->b;
+                if (GEO) rc = r->c;
+                tau2 = r->d.z;
+            }
+            if (has) s_ord[tid] = depth;
+            if (tid < RANK_U) s_ord[n + tid] = ~0u;   // +inf padding of the broadcast loop
+            s_si[tid] = 0u;                           // per list position: 0x100 | quadrant mask once claimed
+            __syncthreads();
+            uint32_t lost = 0u;
+            if (((uint32_t)__builtin_amdgcn_readfirstlane((int)tid) & ~63u) < n) {   // wave-uniform
+                const uint32_t mine[4] = {depth, 0u, 0u, 0u};
+                uint32_t rk[4] = {0u, 0u, 0u, 0u};
+                rank_loop<1>(s_ord, n, mine, rk);
+                if (has) {
+                    float4 sa, sb;
+                    stage_splat(ra, rb, sa, sb);
+                    const uint32_t slot = rk[0] + 1u;
+                    s_geo[slot] = sa;
+                    s_at[slot] = make_float4(sb.z, sb.w, sb.x, __builtin_amdgcn_logf(sb.y));
+                    if (GEO) s_c[GEO ? slot : 0] = UNIT ? make_float4(rc.x, rc.y, rc.z, sb.w) : rc;
+                    const uint32_t qm = quadrant_mask(ra, rb, tau2, X0, Y0);
+                    lost = atomicExch(&s_si[rk[0]], 0x100u | qm);
+                    bs.point_list[base + rk[0]] = UNIT ? (id | (qm << LIST_TAG_SHIFT)) : id;
+                }
+            }
+            prestaged = !__syncthreads_or((int)lost);
+        }
+        if (n > 0 && !prestaged) {   // block-uniform
             uint32_t rank[4], idx[4];
             tile_rank_sort<4>(bs.keys + base, n, RankScratch{s_ord, s_si, s_hist, s_start, s_mm}, rank, idx);
 #pragma unroll
@@ -142,7 +193,10 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
                 const uint32_t i = tid + 256u * q;
                 if (i < n) {
                     s_ord[rank[q]] = idx[q];
-                    if (!UNIT) bs.point_list[base + rank[q]] = idx[q];   // (UNIT: written at staging time, tagged)
+                    // UNIT: the entries are written again, tagged with their quadrant masks, when their batch is staged; a
+                    // batch that is never staged (every pixel terminated before it) keeps these untagged entries: valid
+                    // indices with an empty mask for whoever reads the whole range
+                    if (!UNIT || rank[q] >= (uint32_t)BATCH) bs.point_list[base + rank[q]] = idx[q];
                 }
             }
             __syncthreads();
@@ -171,6 +225,7 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
     const char* const c_bytes = reinterpret_cast<const char*>(s_c);
 
     for (int i = 0; i < rounds; i++) {
+        if (!prestaged) {   // block-uniform (prestaged: one round, staged above)
         if (!__syncthreads_or(!wave_done)) break;
         const int progress = i * BATCH + threadIdx.x;
         uint32_t qm = 0;
@@ -196,12 +251,13 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
             if (lane == 0) s_qmask[q][g.wave] = bal;
         }
         __syncthreads();
+        }
         if (wave_done) continue;
         // ---- this wave's list: the staged entries its quadrant accepted, in list order, padded to a multiple of 16
         int n = 0;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            const uint64_t m = uniform64(s_qmask[g.wave][c]);
+            const uint64_t m = prestaged ? ballot64((s_si[SORT ? c * 64 + lane : 0] >> g.wave) & 1u) : uniform64(s_qmask[g.wave][c]);
             if ((m >> lane) & 1ull) {
                 const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 list[pos] = (uint32_t)((c * 64 + lane + 1) * 16);

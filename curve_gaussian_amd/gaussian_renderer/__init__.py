@@ -29,16 +29,59 @@ def _ones(n, dev):
     return t
 
 
+def _fused_route_ok(pc, pipe, scaling_modifier, override_color):
+    """The fused per-view path (ops/view_render.py) computes exactly what the default configuration of the reference's
+    render() computes -- scales + rotations from the curve model, unit colours, scale modifier 1, no antialiasing, geometry
+    maps on -- and nothing else; the derived splat tensors must be the ones prepare_scaling_rot made from the CURRENT curve
+    parameters (the reference renders `pc.get_xyz` as it finds it)."""
+    if not (hasattr(pc, "_curve_points") and hasattr(pc, "_width") and hasattr(pc, "is_bezier")):
+        return False
+    if (pipe.compute_cov3D_python or pipe.convert_SHs_python or pipe.antialiasing or pipe.debug or not pipe.render_geo or
+            scaling_modifier != 1.0 or override_color is not None):
+        return False
+    if pc._curve_points.dim() != 3 or pc._curve_points.shape[0] == 0 or pc._curve_points.shape[0] * pc.n_gaussians >= (1 << 28):
+        return False
+    return getattr(pc, "_derived_from", None) == _param_stamp(pc)
+
+
+def _param_stamp(pc):
+    return (pc._curve_points.data_ptr(), pc._curve_points._version, pc._width.data_ptr(), pc._width._version,
+            tuple(pc._curve_points.shape))
+
+
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_sh=False, override_color=None,
            use_trained_exp=False, use_mask=False, mask_thr=0.01, compute_visibility=True, clamp=True,
-           compute_rend_dir=True, static_bucket_cap=0, status_sink=None):
+           compute_rend_dir=True, static_bucket_cap=0, status_sink=None, fused=None):
     """Render the scene.  Background tensor (bg_color) must be on the GPU.  Returns the reference's dict
-    {render, viewspace_points, visibility_filter, radii, depth, rend_dir, rend_alpha} (:147-155)."""
+    {render, viewspace_points, visibility_filter, radii, depth, rend_dir, rend_alpha} (:147-155).
+
+    Two routes, same results: for a ``GaussianCurveModel`` under the reference's default pipeline flags the whole view is ONE
+    autograd node over ``cgs_view_forward_checked`` / ``cgs_view_backward`` (curve sampling, splat attributes, projection,
+    binning, unit-colour compositors -- the kernels bench.py times); anything else goes through ``GaussianRasterizer`` like
+    the reference (:96-129).  ``fused``: None = choose automatically, False = always the general route, True = insist.
+    Flags of the reference's signature: ``pipe.compute_cov3D_python`` feeds ``pc.get_covariance`` as cov3D_precomp (:67-68);
+    ``use_trained_exp`` applies the exposure with the reference's own expression (:131-135); ``separate_sh=True`` raises the
+    TypeError the reference raises (its rasterizer has no ``dc`` argument: SURVEY quirk 20); ``override_color`` and
+    ``pipe.convert_SHs_python`` are overwritten by the unit colours upstream (:96-97) and change nothing here either."""
+    if separate_sh:   # (:108-119) GaussianRasterizer.forward() got an unexpected keyword argument 'dc'
+        raise TypeError("GaussianRasterizer.forward() got an unexpected keyword argument 'dc' (render(separate_sh=True): the "
+                        "reference's rasterizer has no separate-SH entry point, gaussian_renderer/__init__.py:108-119)")
     dev = pc.get_xyz.device
     # (:30-34) a zero tensor whose .grad receives the screen-space gradients; a leaf needs no retain_grad()
     screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True, device=dev)
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
+    use_fused = _fused_route_ok(pc, pipe, scaling_modifier, override_color) if fused is None else bool(fused)
+    if fused and not _fused_route_ok(pc, pipe, scaling_modifier, override_color):
+        raise ValueError("render(fused=True): the fused view path needs a GaussianCurveModel whose derived tensors are current "
+                         "and the reference's default pipeline flags")
+    if use_fused:
+        from ..ops.view_render import view_render
+        rendered_image, depth_image, out_all_map, radii = view_render(
+            pc._curve_points, pc._width, pc._opacity, pc._mask if use_mask else None, screenspace_points, pc.is_bezier,
+            pc.n_gaussians, mask_thr, bg_color, viewpoint_camera, tanfovx, tanfovy, static_bucket_cap, status_sink)
+        return _package(viewpoint_camera, pc, rendered_image, radii, depth_image, out_all_map, screenspace_points,
+                        use_trained_exp, clamp, compute_rend_dir, compute_visibility)
     raster_settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
         tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,
@@ -57,9 +100,26 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_
         viewpoint_camera.world_view_transform, pc.n_gaussians, pc._mask if use_mask else None, mask_thr)
     # SH path is dead in the reference (:96-97): single-channel unit colour
     colors_precomp = _ones(means3D.shape[0], dev)
+    cov3D_precomp = None
+    if pipe.compute_cov3D_python:   # (:67-68; the scales / rotations pair is then not passed, :69-71)
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+        # (:72-76) with use_mask the reference still sets `scales`, and its rasterizer then refuses the call (:196-197)
+        scales, rotations = (scales if use_mask else None), None
     rendered_image, radii, depth_image, out_all_map = rasterizer(
         means3D=means3D, means2D=means2D, shs=None, colors_precomp=colors_precomp, opacities=opacity, scales=scales,
-        rotations=rotations, all_map=input_all_map, cov3D_precomp=None)
+        rotations=rotations, all_map=input_all_map, cov3D_precomp=cov3D_precomp)
+    return _package(viewpoint_camera, pc, rendered_image, radii, depth_image, out_all_map, screenspace_points,
+                    use_trained_exp, clamp, compute_rend_dir, compute_visibility)
+
+
+def _package(viewpoint_camera, pc, rendered_image, radii, depth_image, out_all_map, screenspace_points, use_trained_exp,
+             clamp, compute_rend_dir, compute_visibility):
+    """:131-155 -- exposure, clamp, world-space direction map, the result dict."""
+    if use_trained_exp:   # (:131-135) the reference's expression, verbatim in meaning: a [H,W,C] x [3,3] product, i.e. it only
+        # type-checks for a 3-channel image -- with this rasterizer's single channel it raises torch's shape error upstream too
+        exposure = pc.get_exposure_from_name(viewpoint_camera.image_name)
+        rendered_image = (torch.matmul(rendered_image.permute(1, 2, 0), exposure[:3, :3]).permute(2, 0, 1)
+                          + exposure[:3, 3, None, None])
     # clamp=False (extension): hand the raw composite to ops.losses.photometric_loss(clamp=True), which applies the
     # clamp and its gradient mask inside the loss kernels
     if clamp:

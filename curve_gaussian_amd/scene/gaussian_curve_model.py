@@ -265,8 +265,19 @@ class GaussianCurveModel:
     def restore(self, model_args, training_args=None):
         """train.py:49-51 ``gaussians.restore(model_params, opt)``: the inverse of ``capture`` (see there)."""
         a = model_args
+        if isinstance(a, (tuple, list)) and len(a) == 12:
+            # the reference's GaussianModel.capture() tuple (scene/gaussian_model.py:74-88: active_sh_degree, _xyz, _features_dc,
+            # _features_rest, _scaling, _rotation, _opacity, max_radii2D, xyz_gradient_accum, denom, optimizer state_dict,
+            # spatial_lr_scale), i.e. a chkpnt*.pth written by the reference's train.py
+            raise ValueError(
+                "restore: this is a checkpoint in the reference's GaussianModel.capture() layout (12-tuple of DERIVED splat "
+                "tensors).  It does not contain the curve parameters (_curve_points, _width, _mask, is_bezier) -- the reference "
+                "itself cannot resume a curve model from it (scene/gaussian_model.py:74-106 vs gaussian_curve_model.py:54-64) "
+                "-- so there is nothing to rebuild the model from.  Checkpoints written by this package's capture() "
+                "('curvegs-checkpoint-1') round-trip; see INTEGRATION.md, 'Checkpoints'.")
         if not (isinstance(a, dict) and a.get("format") == "curvegs-checkpoint-1"):
-            raise ValueError("restore: not a checkpoint written by GaussianCurveModel.capture()")
+            raise ValueError("restore: not a checkpoint written by GaussianCurveModel.capture() (expected a dict with "
+                             "format == 'curvegs-checkpoint-1')")
         if a["n_gaussians"] != self.n_gaussians:
             raise ValueError(f"restore: checkpoint has {a['n_gaussians']} samples per curve, the model {self.n_gaussians}")
         dev = self.device
@@ -293,6 +304,10 @@ class GaussianCurveModel:
         """:180-198 -- fused HIP sampling kernel (forward + hand-written backward)."""
         self._xyz, self._rotation, self._scaling = curve_sampling.sample_curves(
             self._curve_points, self._width, self.is_bezier, self.n_gaussians, eps)
+        # which parameter state the derived tensors belong to: render() takes its fused per-view route (which samples the
+        # curves itself) only while they are current, so both routes draw the same splats
+        self._derived_from = (self._curve_points.data_ptr(), self._curve_points._version, self._width.data_ptr(),
+                              self._width._version, tuple(self._curve_points.shape))
 
     # ------------------------------------------------------------------ accessors (:66-140)
     @property
@@ -322,6 +337,19 @@ class GaussianCurveModel:
     @property
     def get_curve_width(self):
         return self.scaling_activation(self._width)
+
+    def get_covariance(self, scaling_modifier=1):
+        """scene/gaussian_model.py:32-36,184-185 with utils/general_utils.py:134-181: Sigma = (R S)(R S)^T of the
+        normalised quaternion and `scaling_modifier * scaling`, packed as the upper triangle [xx, xy, xz, yy, yz, zz]
+        (pipe.compute_cov3D_python, gaussian_renderer/__init__.py:67-68)."""
+        q = self._rotation / torch.sqrt((self._rotation * self._rotation).sum(-1, keepdim=True))
+        r, x, y, z = q.unbind(-1)
+        R = torch.stack((1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                         2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                         2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)), -1).view(-1, 3, 3)
+        Lm = R * (scaling_modifier * self.get_scaling).unsqueeze(1)          # R @ diag(s)
+        cov = Lm @ Lm.transpose(1, 2)
+        return torch.stack((cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]), -1)
 
     @property
     def get_features(self):

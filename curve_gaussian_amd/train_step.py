@@ -5,6 +5,7 @@
 
 Only the photometric terms and (from ``densify_until_iter``) the mask regulariser are included; the O(B^2) connection
 loss and the topology edits are out of scope."""
+import os
 import random
 
 import torch
@@ -174,6 +175,10 @@ class GraphedTrainStep(TrainStep):
         # environment).  With more ranks every rank must run the same number of warm-up executions and re-captures -- the
         # captured body issues collectives -- which the fixed two-iteration overflow lag is designed to guarantee.
         self._capture_coll = bool(capture_collectives) and self._collective
+        if self._capture_coll and self.world > 1 and os.environ.get("CGS_ALLOW_CAPTURED_COLLECTIVES") != "1":
+            # never run with two ranks (no multi-GPU box in the build environment): opt in explicitly
+            raise ValueError("GraphedTrainStep(capture_collectives=True) has only been exercised on a single-rank RCCL group; "
+                             "set CGS_ALLOW_CAPTURED_COLLECTIVES=1 to use it with world > 1")
         if self._collective:
             import torch.distributed as dist
             if not (dist.is_available() and dist.is_initialized()):

@@ -147,6 +147,14 @@ size_t cgs_binning_bytes(int64_t R);
  *     dL_dopacity_logit [B,1], dL_dmask_logit [P] (required iff mask_logit) -- overwritten, or added to when `accumulate`
  *     is non-zero (several views summed into one gradient buffer without extra kernels).  scratch:
  *     cgs_view_backward_scratch_floats(B, m) floats.
+ *   cgs_view_forward_checked: the same forward for eager callers (the drop-in render(): gaussian_renderer/__init__.py:18-157
+ *     as train.py:95-97 calls it).  Like the reference's forward it reports how much it binned -- but the host only waits for
+ *     a 16-byte readback queued right behind the SCATTER, with the compositor already enqueued behind it (the reference blocks
+ *     on num_rendered before it can even size its sort buffers, rasterizer_impl.cu:287).  Returns the longest tile list
+ *     (>= 0; cgs_last_forward_stats has num_rendered): when it exceeds bucket_capacity the outputs are INVALID and the call
+ *     must be repeated with a larger capacity; negative = cgs_status.  Updates the per-shape binning hints.
+ *   cgs_bucket_capacity_hint: bucket capacity recommended for the next forward of this workload shape (1.25 x the longest
+ *     list seen recently + 64, rounded up to 64), 0 when nothing is known about it yet.
  * ------------------------------------------------------------------------------------------------ */
 int cgs_view_forward(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
                      float eps, double* norms, const float* opacity_logit, const float* mask_logit, float mask_thr,
@@ -155,6 +163,14 @@ int cgs_view_forward(int B, int m, const float* curve_points, const float* width
                      const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
                      float* out_color, float* out_invdepth, float* out_all_map, int* radii, float* xyz, float* rotation,
                      float* scaling, void* stream);
+int64_t cgs_view_forward_checked(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
+                     float eps, double* norms, const float* opacity_logit, const float* mask_logit, float mask_thr,
+                     const float* colors_precomp, void* geometry_buffer, void* binning_buffer, size_t binning_bytes,
+                     void* image_buffer, uint32_t bucket_capacity, const float* background, int width_px, int height_px,
+                     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                     float* out_color, float* out_invdepth, float* out_all_map, int* radii, float* xyz, float* rotation,
+                     float* scaling, void* stream);
+uint32_t cgs_bucket_capacity_hint(int P, int width, int height);
 size_t cgs_view_backward_scratch_floats(int B, int m);
 int cgs_view_backward(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
                       float eps, double* norms, const float* opacity_logit, const float* mask_logit, float mask_thr,
@@ -316,6 +332,10 @@ int cgs_set_tile_culling(int on);
  *     k_render_bwd3<UNIT>.  Same results to rounding.  Any other value only queries. */
 int cgs_set_fused_tile_sort(int on);
 int cgs_set_unit_backward(int variant);
+/*   cgs_set_forward_pipeline: 1 = the fused sort + composite forward runs as the persistent prefetcher / walker kernel
+ *     (csrc/render_pipe.hip: one wave brings tile t+1 into LDS while four composite tile t); 0 (default) = one workgroup per
+ *     tile (k_render_fwd3<.., SORT>).  Bit-identical results.  CGS_FWD_PIPE=1 in the environment sets the initial value. */
+int cgs_set_forward_pipeline(int on);
 /* Introspection of the calling thread's last cgs_rasterize_forward: num_rendered, the longest per-tile list and
  * which binning path produced it (0 = exact count/scan/scatter layout, 1 = single-pass fixed-capacity buckets). */
 /* ------------------------------------------------------------------------------------------------

@@ -591,8 +591,12 @@ def test_view_entry_points_match_the_oracle_chain_at_full_size(cfg, coloured, bg
     vc = _ViewCalls(curves["curve_points"], curves["width"], curves["opacity"], curves["is_bezier"], cam,
                     4096 if cfg == "cfg5" else 1024, colors=colors.reshape(-1) if coloured else None, bg=bg)
     vc.forward()
-    assert_close("color", vc.color.cpu().numpy(), fw.color)
-    assert_close("all_map", vc.omap.cpu().numpy(), fw.out_all_map, outlier_frac=2e-4)
+    # magnitude cap of the outliers: the two sides' splats differ in their last bits here, so a handful of radii differ by one
+    # pixel -- and the reference's 3-sigma tile rect cuts a splat off at alpha = opacity exp(-4.5) = 6.7e-3 (> 1/255): a pixel
+    # at that rim gains or loses up to 6.7e-3 (identical-input tests keep the 5e-3 default: one 1/255 flip)
+    # (no cluster criterion either: a splat missing from one tile's list moves that tile's whole rim)
+    assert_close("color", vc.color.cpu().numpy(), fw.color, max_outlier=1.2e-2, tile_cluster=None)
+    assert_close("all_map", vc.omap.cpu().numpy(), fw.out_all_map, outlier_frac=2e-4, max_outlier=1.2e-2, tile_cluster=None)
     assert (vc.radii.cpu().numpy() == fw.radii).mean() > 0.9999
     B = vc.B
     g = [vc.f32(B, 4, 3), vc.f32(B, 1), vc.f32(B, 1)]
@@ -685,6 +689,11 @@ def test_headline_instances_meet_the_raster_criterion_on_identical_inputs(cfg, b
         # measured 2e-6 .. 8e-6 (cfg1-4); cfg5: 2.0e-4 -- every pixel of that view terminates early (T < 1e-4) and which splat
         # terminates a pixel flips under the last bits of the exponent far more often than an alpha test does
         assert rel < (3e-4 if cfg == "cfg5" else 3e-5), f"dL/d{name}: relative L2 error {rel:.2e}"
+        # element-wise next to the L2 figure: 1e-4 of the tensor's maximum on all but 1e-3 of the curves, no curve beyond
+        # 2e-3 of it (cfg5, where every pixel terminates early: 1e-2 / 2e-2) -- see the printed worst element
+        worst = assert_close(f"dL/d{name} (element-wise)", got.cpu().numpy(), leaf.grad.numpy(),
+                             outlier_frac=1e-2 if cfg == "cfg5" else 1e-3, max_outlier=2e-2 if cfg == "cfg5" else 2e-3)
+        print(f"{cfg} bg={bg}: dL/d{name} worst element {worst:.2e} of max")
     if cfg == "cfg3" and bg == 0.0:
         # the image-only instance of the forward (no inverse depth, no all_map) at a BASELINE size: same image, bit for bit
         full = vc.color.clone()
@@ -913,6 +922,22 @@ def test_bench_two_rank_control_flow_rehearsal():
     assert out["n_gpus"] == 2 and out["steps"] == 8 and out["value"] > 0
     assert "roofline" in out and out["config"]["parallelism"] == "view-parallel x2"
     assert out["train_step_view_parallel_ms"] > 0
+    # what the first hardware scaling record will be judged against: the collective's span, the step-boundary schedule and
+    # the machine-readable prediction travel with every N > 1 line
+    assert out["rccl_ranks"] == 2 and out["step_boundary"].startswith("double-buffered")
+    es = out["expected_scaling"]
+    assert es["all_reduce_bytes"] == 38 * 4 * out["config"]["curves"] and es["overlapped_with_next_step"] is True
+    assert es["min_efficiency_vs_1gpu"] == 0.97 and es["reference_predictions"]["cfg5"]["step_ms"] == 5.6
+
+
+def test_captured_collectives_need_an_explicit_opt_in_beyond_one_rank(monkeypatch):
+    """GraphedTrainStep(capture_collectives=True) has never seen a second rank: with world > 1 it refuses unless
+    CGS_ALLOW_CAPTURED_COLLECTIVES=1 (the check comes before any process-group use)."""
+    from curve_gaussian_amd.train_step import GraphedTrainStep
+    gm, cams, gts = _train_fixture()
+    monkeypatch.delenv("CGS_ALLOW_CAPTURED_COLLECTIVES", raising=False)
+    with pytest.raises(ValueError, match="CGS_ALLOW_CAPTURED_COLLECTIVES"):
+        GraphedTrainStep(gm, cams, gts, rank=0, world=2, capture_collectives=True, collectives=True)
 
 
 def test_bench_default_schedule_over_single_rank_rccl():
@@ -932,6 +957,7 @@ def test_bench_default_schedule_over_single_rank_rccl():
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["rccl_ranks"] == 1 and out["n_gpus"] == 1 and out["value"] > 0
+    assert out["step_boundary"].startswith("double-buffered") and "expected_scaling" not in out
     assert out["train_step_view_parallel_ms"] > 0
     assert out["step_gradient_rel_l2_vs_serial_eager"] < 1e-3
 
