@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(256) k_tile_rank_sort(const uint2* __restrict_
                                                         const uint32_t* __restrict__ tile_count,
                                                         uint2* __restrict__ ranges_out, uint32_t* __restrict__ total,
                                                         uint32_t min_n) {
-    __shared__ uint32_t sd[256 * KPT + RANK_U];
+    __shared__ __attribute__((aligned(16))) uint32_t sd[256 * KPT + RANK_U];
     __shared__ uint32_t si[256 * KPT];
     __shared__ uint32_t s_hist[RANK_NB], s_start[RANK_NB + 1], s_mm[8];
     const uint2 rg = BUCKET ? bucket_range(tile_count, ranges_out, total, cap, PUBLISH) : ranges[blockIdx.x];

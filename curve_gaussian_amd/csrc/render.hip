@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
     __shared__ uint64_t s_qmask[4][4];
     __shared__ __attribute__((aligned(16))) uint32_t s_list[4][BATCH + GROUP];   // per wave: 16 * (staged index + 1); dwords: a
                                                                                  // broadcast read hands the walk ready LDS addresses
-    __shared__ uint32_t s_ord[SORT ? RANK_MAX + RANK_U : 1];
+    __shared__ __attribute__((aligned(16))) uint32_t s_ord[SORT ? RANK_MAX + RANK_U : 1];
     __shared__ uint32_t s_si[SORT ? RANK_MAX : 1];
     __shared__ uint32_t s_hist[SORT ? RANK_NB : 1], s_start[SORT ? RANK_NB + 1 : 1], s_mm[8];
     if (threadIdx.x == 0) {
@@ -163,14 +163,13 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
                 tau2 = r->d.z;
             }
             if (has) s_ord[tid] = depth;
-            if (tid < RANK_U) s_ord[n + tid] = ~0u;   // +inf padding of the broadcast loop
+            if (tid < 4u) s_ord[n + tid] = 0x7f800000u;   // +inf padding of the broadcast loop
             s_si[tid] = 0u;                           // per list position: 0x100 | quadrant mask once claimed
             __syncthreads();
             uint32_t lost = 0u;
             if (((uint32_t)__builtin_amdgcn_readfirstlane((int)tid) & ~63u) < n) {   // wave-uniform
-                const uint32_t mine[4] = {depth, 0u, 0u, 0u};
-                uint32_t rk[4] = {0u, 0u, 0u, 0u};
-                rank_loop<1>(s_ord, n, mine, rk);
+                // (depths are positive finite floats -- view-space z > 0.2 -- whose order is the order of their bit patterns)
+                const uint32_t rk[1] = {rank_loop_f32(reinterpret_cast<const float*>(s_ord), n, __uint_as_float(depth))};
                 if (has) {
                     float4 sa, sb;
                     stage_splat(ra, rb, sa, sb);

@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(64 * PIPE_WAVES, CGS_PIPE_WAVES_PER_SIMD) k_re
                     p_id[q] = (uint32_t)k4[q];
                     if (i < n) { sd[i] = (uint32_t)(k4[q] >> 32); si[i] = p_id[q]; }
                 }
-                if (lane < (int)RANK_U) sd[n + lane] = ~0u;   // +inf padding of the walkers' broadcast loop
+                if (lane < 4) sd[n + lane] = 0x7f800000u;   // +inf padding of the walkers' broadcast loop
             } else {
                 for (uint32_t i = (uint32_t)lane; i < n; i += 64u) s_key[i] = keys[base + i];
                 wave_fence();
@@ -377,10 +377,7 @@ __global__ void __launch_bounds__(64 * PIPE_WAVES, CGS_PIPE_WAVES_PER_SIMD) k_re
             if (valid) id = si[i];
             if (((uint32_t)__builtin_amdgcn_readfirstlane((int)i) & ~63u) < m) {   // wave-uniform
                 if (!full) {
-                    const uint32_t mine[4] = {d, 0u, 0u, 0u};
-                    uint32_t rk[4] = {0u, 0u, 0u, 0u};
-                    rank_loop<1>(sd, m, mine, rk);
-                    slot = rk[0];
+                    slot = rank_loop_f32(reinterpret_cast<const float*>(sd), m, __uint_as_float(d));
                 } else {
                     uint32_t r = 0u;
                     for (uint32_t u = 0; u < m; u++) {   // uniform addresses: LDS broadcast
