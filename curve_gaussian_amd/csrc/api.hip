@@ -116,6 +116,7 @@ static void hints_update(int P, int W, int H, int64_t R, uint32_t longest, int64
     if (big >= 0) h.big = big;
     h.max = std::max<int64_t>((int64_t)longest, h.max - h.max / 16);
 }
+static thread_local int64_t g_last_visible = -1;   // radii > 0 count of the last cgs_view_forward_checked
 static thread_local int64_t g_last_stats[3] = {0, 0, 0};  // num_rendered, longest tile list, binning path (0 exact, 1 bucket)
 
 // Device-side zero fill.  hipMemsetAsync is NOT used anywhere in the library: captured into a hipGraph (ROCm 7.0 runtime
@@ -603,21 +604,26 @@ int cgs_sample_curves_forward(int B, int m, const float* curve_points, const flo
 // (view.hip), the rasterizer is the sync-free single-pass bucket pipeline of cgs_rasterize_forward_static.
 // Longest tile list of a finished scatter, for the checked (blocking) view forward: one small launch between the scatter
 // and the compositor, so the host's wait ends when the BINNING is done and the compositor is still running.
-__global__ void __launch_bounds__(256) k_count_stats(const uint32_t* __restrict__ tile_count, int tiles, uint32_t* __restrict__ out2) {
-    uint32_t mx = 0, sum = 0;
+__global__ void __launch_bounds__(256) k_count_stats(const uint32_t* __restrict__ tile_count, int tiles, const int* __restrict__ radii,
+                                                     int P, const uint32_t* __restrict__ big, uint32_t* __restrict__ out4) {
+    uint32_t mx = 0, sum = 0, vis = 0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < tiles; i += gridDim.x * 256) {
         const uint32_t c = tile_count[i];
         mx = max(mx, c);
         sum += c;
     }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256) vis += radii[i] > 0 ? 1u : 0u;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
         sum += (uint32_t)__shfl_xor((int)sum, off, 64);
+        vis += (uint32_t)__shfl_xor((int)vis, off, 64);
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&out2[0], sum);   // [0] = num_rendered, [1] = longest list: the exact path's meaning of these two words
-        atomicMax(&out2[1], mx);
+        atomicAdd(&out4[0], sum);   // num_rendered
+        atomicMax(&out4[1], mx);    // longest tile list
+        atomicAdd(&out4[2], vis);   // splats with radii > 0 (sizes render()'s visibility_filter without a host sync)
+        if (blockIdx.x == 0 && threadIdx.x == 0) out4[3] = *big;   // splats with oversized tile rects (final after the scatter)
     }
 }
 
@@ -676,7 +682,7 @@ static int64_t view_forward_impl(bool checked, int B, int m, const float* curve_
                           defer_big ? img.tile_cursor : nullptr, (uint32_t)tiles);
     // checked: the longest tile list (and the instance count, oversized-rect count) travel to the host right behind the
     // scatter; the compositor is queued before the host waits, so the wait overlaps it
-    static thread_local uint32_t* h_stat = nullptr;   // pinned: instances, longest list, overflow flag (not yet set), oversized rects
+    static thread_local uint32_t* h_stat = nullptr;   // pinned: instances, longest list, visible splats, oversized rects
     static thread_local hipEvent_t ev = nullptr;
     if (checked) {
         if (!h_stat) {
@@ -687,9 +693,10 @@ static int64_t view_forward_impl(bool checked, int B, int m, const float* curve_
                 return CGS_ERR_HIP;
             }
         }
-        // words [0], [1] of the status block are unused on the bucket path (the exact path's R / longest list)
-        hipLaunchKernelGGL(k_count_stats, dim3(std::min(64, (tiles + 255) / 256)), dim3(256), 0, s, img.tile_count, tiles, img.total);
-        hipError_t e = hipMemcpyAsync(h_stat, img.total, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+        // four words of the (cleared) work block that the tile queues of render_pipe.hip do not use
+        uint32_t* const stat = img.work + 4;
+        hipLaunchKernelGGL(k_count_stats, dim3(64), dim3(256), 0, s, img.tile_count, tiles, radii, P, img.total + 3, stat);
+        hipError_t e = hipMemcpyAsync(h_stat, stat, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipEventRecord(ev, s);
         if (e != hipSuccess) {
             set_error("cgs_view_forward_checked: status readback failed: %s", hipGetErrorString(e));
@@ -719,6 +726,7 @@ static int64_t view_forward_impl(bool checked, int B, int m, const float* curve_
         const uint32_t longest = h_stat[1];
         hints_update(P, width_px, height_px, (uint64_t)longest <= cap ? (int64_t)h_stat[0] : -1, longest, (int64_t)h_stat[3]);
         g_last_stats[0] = (int64_t)h_stat[0]; g_last_stats[1] = (int64_t)longest; g_last_stats[2] = 1;
+        g_last_visible = (int64_t)h_stat[2];
         return (int64_t)longest;
     }
     return CGS_OK;
@@ -749,6 +757,7 @@ int64_t cgs_view_forward_checked(int B, int m, const float* curve_points, const 
                              background, width_px, height_px, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, out_color,
                              out_invdepth, out_all_map, radii, xyz, rotation, scaling, stream_);
 }
+int64_t cgs_last_forward_visible(void) { return g_last_visible; }
 uint32_t cgs_bucket_capacity_hint(int P, int width, int height) {
     const int64_t mx = hints_load(P, width, height).max;
     if (mx <= 0) return 0u;

@@ -47,6 +47,11 @@ __device__ __forceinline__ float swap32_sum(float v) {      // v(lane) + v(lane 
     auto s = __builtin_amdgcn_permlane32_swap(x, x, false, false);
     return __uint_as_float(s[0]) + __uint_as_float(s[1]);
 }
+// lanes 0..31: lo(lane) + lo(lane + 32);  lanes 32..63: hi(lane - 32) + hi(lane)
+__device__ __forceinline__ float swap32_pair_sum(float lo, float hi) {
+    auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+}
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -343,12 +348,13 @@ __global__ void __launch_bounds__(256, CGS_UBWD_WAVES) k_render_bwd_unit(
             float Sxx = fmaf(Dx, Sx - X1, X2);
             float Syy = fmaf(Dy, Sy - 2.f * Y1, 4.f * Y2);
             float Sxy = fmaf(Dx, Sy, fmaf(-Dy, X1, 2.f * XY));
-            // the other lane half holds the other four pixel rows of the same pair
-            Sg = swap32_sum(Sg); Sx = swap32_sum(Sx); Sy = swap32_sum(Sy);
-            Sxx = swap32_sum(Sxx); Sxy = swap32_sum(Sxy); Syy = swap32_sum(Syy);
-            // ---- the up-to-four pairs of one splat sit in consecutive lanes: lanes 0..31 add fields 0..2 along the run,
-            // lanes 32..63 fields 3..5 (both halves hold all six sums now)
-            float v0 = hh ? Sxx : Sg, v1 = hh ? Sxy : Sx, v2 = hh ? Syy : Sy;
+            // the other lane half holds the other four pixel rows of the same pair; from here on lanes 0..31 carry fields 0..2
+            // of their pair and lanes 32..63 fields 3..5.  ONE v_permlane32_swap per field pair does both: it exchanges the
+            // upper half of its first operand with the lower half of its second, so afterwards the two registers hold, in
+            // the lower lanes, both halves' Sg and, in the upper lanes, both halves' Sxx (three swaps and adds instead of six
+            // plus three selects).
+            float v0 = swap32_pair_sum(Sg, Sxx), v1 = swap32_pair_sum(Sx, Sxy), v2 = swap32_pair_sum(Sy, Syy);
+            // ---- the up-to-four pairs of one splat sit in consecutive lanes: add along the run
             const uint32_t k_eff = min(run_k, (uint32_t)n);       // a run that started in the previous chunk restarts here
             {
                 const float t0 = dpp_wave_shr1(v0), t1 = dpp_wave_shr1(v1), t2 = dpp_wave_shr1(v2);

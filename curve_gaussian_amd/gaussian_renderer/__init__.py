@@ -77,11 +77,11 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_
                          "and the reference's default pipeline flags")
     if use_fused:
         from ..ops.view_render import view_render
-        rendered_image, depth_image, out_all_map, radii = view_render(
+        rendered_image, depth_image, out_all_map, radii, n_visible = view_render(
             pc._curve_points, pc._width, pc._opacity, pc._mask if use_mask else None, screenspace_points, pc.is_bezier,
             pc.n_gaussians, mask_thr, bg_color, viewpoint_camera, tanfovx, tanfovy, static_bucket_cap, status_sink)
         return _package(viewpoint_camera, pc, rendered_image, radii, depth_image, out_all_map, screenspace_points,
-                        use_trained_exp, clamp, compute_rend_dir, compute_visibility)
+                        use_trained_exp, clamp, compute_rend_dir, compute_visibility, n_visible)
     raster_settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
         tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,
@@ -112,8 +112,14 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_
                     use_trained_exp, clamp, compute_rend_dir, compute_visibility)
 
 
+def _visible(radii, n_visible):
+    """(:150) `(radii > 0).nonzero()`; the fused route knows the count from its status readback and skips the host sync."""
+    from ..ops.view_render import visible_indices
+    return visible_indices(radii, n_visible)
+
+
 def _package(viewpoint_camera, pc, rendered_image, radii, depth_image, out_all_map, screenspace_points, use_trained_exp,
-             clamp, compute_rend_dir, compute_visibility):
+             clamp, compute_rend_dir, compute_visibility, n_visible=None):
     """:131-155 -- exposure, clamp, world-space direction map, the result dict."""
     if use_trained_exp:   # (:131-135) the reference's expression, verbatim in meaning: a [H,W,C] x [3,3] product, i.e. it only
         # type-checks for a 3-channel image -- with this rasterizer's single channel it raises torch's shape error upstream too
@@ -131,13 +137,14 @@ def _package(viewpoint_camera, pc, rendered_image, radii, depth_image, out_all_m
     # (extension) leaves the view-space map in place for callers that do not use it (the photometric train step).
     if compute_rend_dir:
         wv = viewpoint_camera.world_view_transform[:3, :3]
-        rendered_dir = (rendered_dir[0:1] * wv[:, 0].view(3, 1, 1) + rendered_dir[1:2] * wv[:, 1].view(3, 1, 1) +
-                        rendered_dir[2:3] * wv[:, 2].view(3, 1, 1))
+        d = rendered_dir
+        rendered_dir = torch.addcmul(torch.addcmul(d[0:1] * wv[:, 0].view(3, 1, 1), d[1:2], wv[:, 1].view(3, 1, 1)),
+                                     d[2:3], wv[:, 2].view(3, 1, 1))
     else:
         rendered_dir = None
     # compute_visibility=False (extension) skips the nonzero(), which is a host sync (train.py only needs it for the
     # densification statistics and the opacity regulariser)
     return {"render": rendered_image, "viewspace_points": screenspace_points,
-            "visibility_filter": (radii > 0).nonzero() if compute_visibility else None, "radii": radii,
+            "visibility_filter": _visible(radii, n_visible) if compute_visibility else None, "radii": radii,
             "depth": depth_image,
             "rend_dir": rendered_dir, "rend_alpha": rendered_alpha}

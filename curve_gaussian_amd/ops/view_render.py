@@ -16,6 +16,7 @@ from .curve_sampling import _bezier_mask, sample_coefficients
 
 _f = C.c_float
 _caps = {}   # (device index, P, W, H) -> bucket capacity that held the last forward of this shape
+_last_visible = [-1]   # radii > 0 count of the last checked forward (read back with its status words), -1: unknown
 
 
 def _capacity(lib, dev, P, W, H):
@@ -83,6 +84,9 @@ class _ViewRender(torch.autograd.Function):
                 cap = min(limit, (int(longest) * 5 // 4 + 64 + 63) & ~63)   # the image just rendered is incomplete: redo
             if not static_cap:
                 _caps[(dev.index, P, W, H)] = cap
+                _last_visible[0] = int(lib.cgs_last_forward_visible())
+            else:
+                _last_visible[0] = -1
         ctx.save_for_backward(cp, w, ol, mk if mk is not None else torch.empty(0, device=dev), geom, binb, img, radii, norms,
                               bgc, view, proj, campos)
         ctx.isb, ctx.coef = isb, coef
@@ -126,5 +130,13 @@ class _ViewRender(torch.autograd.Function):
 
 def view_render(curve_points, width, opacity_logit, mask_logit, means2D, is_bezier, m, mask_thr, bg, cam, tanx, tany,
                 static_cap=0, status_sink=None):
-    return _ViewRender.apply(curve_points, width, opacity_logit, mask_logit, means2D, is_bezier, m, mask_thr, bg, cam, tanx,
-                             tany, static_cap, status_sink)
+    out = _ViewRender.apply(curve_points, width, opacity_logit, mask_logit, means2D, is_bezier, m, mask_thr, bg, cam, tanx,
+                            tany, static_cap, status_sink)
+    return out + (_last_visible[0],)
+
+
+def visible_indices(radii, n_visible):
+    """(radii > 0).nonzero() (gaussian_renderer/__init__.py:150) -- without the device-wide sync when the count is known."""
+    if n_visible is not None and n_visible >= 0:
+        return torch.nonzero_static(radii > 0, size=int(n_visible))
+    return (radii > 0).nonzero()

@@ -171,6 +171,9 @@ int64_t cgs_view_forward_checked(int B, int m, const float* curve_points, const 
                      float* out_color, float* out_invdepth, float* out_all_map, int* radii, float* xyz, float* rotation,
                      float* scaling, void* stream);
 uint32_t cgs_bucket_capacity_hint(int P, int width, int height);
+/* Number of splats with radii > 0 in the calling thread's last cgs_view_forward_checked (-1: none yet): lets the caller size
+ * render()'s visibility_filter = (radii > 0).nonzero() (gaussian_renderer/__init__.py:150) without a device-wide sync. */
+int64_t cgs_last_forward_visible(void);
 size_t cgs_view_backward_scratch_floats(int B, int m);
 int cgs_view_backward(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
                       float eps, double* norms, const float* opacity_logit, const float* mask_logit, float mask_thr,
