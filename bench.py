@@ -840,15 +840,35 @@ def main():
                        "dL_dopacity": nrm(n(g_g[2]), gr["dL_dopacity"]),
                        "radii_equal": bool((n(radii_g) == fw.radii).all())}
             fw.free()
-        tc = t_fwd + t_bwd
+        # the rest of the per-view path on the host: curve sampling (prepare_scaling_rot) and the splat attributes with their
+        # backward, torch restatement (oracle/torch_ref.py) on the same thread count -- `value` times these too
+        t_samp = 0.0
+        if args.mode == "view":
+            from oracle import torch_ref as TR
+            torch.set_num_threads(threads)
+            cpu = lambda t: t.detach().cpu()
+            cam0 = my_cams[0]
+            ts0 = time.perf_counter()
+            lv = [cpu(curves[k]).clone().requires_grad_(True) for k in ("curve_points", "width", "opacity")]
+            x_c, r_c, s_c = TR.prepare_scaling_rot(lv[0], lv[1], cpu(curves["is_bezier"]))
+            rn_c = torch.nn.functional.normalize(r_c)
+            op_c = torch.sigmoid(lv[2]).repeat_interleave(m, 0)
+            am_c = TR.build_all_map(r_c.detach(), x_c.detach(), cpu(cam0.camera_center), cpu(cam0.world_view_transform))
+            (x_c.sum() + s_c.sum() + rn_c.sum() + op_c.sum() + am_c.sum() * 0).backward()
+            t_samp = time.perf_counter() - ts0
+        tc = t_fwd + t_bwd + nv * t_samp
         out["cpu_baseline"] = {"value": round(P * nv / tc / 1e6, 4), "unit": "Msplats/s", "cores": threads,
                                "kind": "port", "fwd_ms_per_view": round(t_fwd / nv * 1e3, 1),
                                "bwd_ms_per_view": round(t_bwd / nv * 1e3, 1),
+                               "sampling_attrs_fwd_bwd_ms_per_view": round(t_samp * 1e3, 1),
                                "gpu_vs_cpu_frac_over_1e-4_of_max": {k: (v if isinstance(v, bool) else float(f"{v:.2e}")) for k, v in err.items()},
-                               "covers": "rasterizer forward + backward only (value times the whole per-view path: curve "
-                                         "sampling + splat attributes + raster + curve-parameter gradients)",
-                               "sample": f"{nv} views of the same workload (raster fwd+bwd), oracle/raster_ref.c with "
-                                         f"OpenMP ({threads} threads of {cores} host cores), {tc:.1f} s"}
+                               "covers": ("the whole per-view path, like value: curve sampling + splat attributes + "
+                                          "raster fwd + bwd + curve-parameter gradients" if args.mode == "view" else
+                                          "rasterizer forward + backward"),
+                               "sample": f"{nv} views of the same workload: raster fwd+bwd through oracle/raster_ref.c with "
+                                         f"OpenMP ({threads} threads of {cores} host cores); sampling + attributes and their "
+                                         f"backward through oracle/torch_ref.py (torch, {threads} threads), timed once and "
+                                         f"charged per view; {tc:.1f} s"}
         if args.config == "cfg1" and args.torch_cpu_splats > 0:
             # SURVEY 8d / north_star: the "PyTorch-CPU raster fallback" beside the C port, on cfg1.  The reference itself has no
             # such fallback; this is the oracle's dense pure-PyTorch differentiable restatement, whose cost is

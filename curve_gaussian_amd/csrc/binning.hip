@@ -277,8 +277,11 @@ constexpr uint32_t BIG_TILES = 96;
 // groups the instances without sorting them: a returning LDS add hands every instance its rank inside its (wave, tile)
 // cell, one lane per non-empty cell claims the cell's run of bucket slots with ONE global atomic, and every instance stores
 // its key at run base + rank.  Instances outside the window (and beyond the list capacity) take one global atomic each.
+// Splats per wave: 12 = the samples of ONE curve (the model's default n_gaussians: their rects share one window by
+// construction).  Round 4, cfg3 / cfg5 / cfg4 / cfg2: 4: 29.7 us; 6: 29.1; 8: 26.2 / 109.7 / 21.8 / 12.4; 12: 24.4 / 97.2 / 23.8 /
+// 13.0; 16: 39.8 / 167 / 23.3 / 16.9 (fewer, longer-running waves).
 #ifndef CGS_GW_SPW
-#define CGS_GW_SPW 8
+#define CGS_GW_SPW 12
 #endif
 constexpr int GW_SPW = CGS_GW_SPW;
 constexpr uint32_t GW_WIN = 16, GW_CELLS = GW_WIN * GW_WIN;

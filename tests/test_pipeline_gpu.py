@@ -704,7 +704,8 @@ def test_headline_instances_meet_the_raster_criterion_on_identical_inputs(cfg, b
 
 @pytest.mark.parametrize("W,H,B,seed,bg,opaque,wide", [(70, 50, 60, 1, 0.0, False, 0.0), (129, 97, 300, 2, 0.35, False, 0.0),
                                                          (160, 128, 900, 3, 0.0, True, 0.0), (48, 16, 40, 4, 0.0, False, 1.5),
-                                                         (333, 211, 2500, 5, 0.2, True, 0.8), (16, 16, 5, 6, 0.0, False, 0.0)])
+                                                         (333, 211, 2500, 5, 0.2, True, 0.8), (16, 16, 5, 6, 0.0, False, 0.0),
+                                                         (64, 48, 110, 7, 0.0, True, 1.5)])
 def test_pair_major_backward_matches_pixel_major(W, H, B, seed, bg, opaque, wide):
     """The two backward compositors of the unit-colour view path -- pair-major `k_render_bwd_unit` (default) and pixel-major
     `k_render_bwd3<UNIT>` (cgs_set_unit_backward(3)) -- on the same forward: image sizes that are not multiples of the tile
@@ -721,13 +722,19 @@ def test_pair_major_backward_matches_pixel_major(W, H, B, seed, bg, opaque, wide
         curves = dict(curves)
         curves["width"] = curves["width"] + wide          # log-width: e^wide times wider splats
     cam = S.make_camera((0.5, -1.5, 0.8), (0.5, 0.5, 0.5), (0, 0, 1), H, W)
-    vc = _ViewCalls(curves["curve_points"], curves["width"], curves["opacity"], curves["is_bezier"], cam, 2048, bg=bg)
+    # (the last case keeps the capacity within the in-kernel sort's reach, so the SORTING forward stages the batches)
+    vc = _ViewCalls(curves["curve_points"], curves["width"], curves["opacity"], curves["is_bezier"], cam,
+                    1024 if seed == 7 else 2048, bg=bg)
     dimg = torch.randn(1, H, W, generator=torch.Generator().manual_seed(seed)).to(DEV)
     res = {}
     prev = lib.cgs_set_unit_backward(4)
     try:
         for v in (3, 4):
             lib.cgs_set_unit_backward(v)
+            # poison the binning buffer: every list entry a backward may read has to be WRITTEN by this forward -- batches
+            # the forward never stages (every pixel terminated before them: the last case, opaque lists of > 256 entries) keep
+            # valid, untagged indices, not whatever the buffer held (the pixel-major kernel stages the whole range)
+            vc.binb.fill_(0xFF)
             vc.forward()
             g = [vc.f32(vc.B, 4, 3), vc.f32(vc.B, 1), vc.f32(vc.B, 1)]
             m2d = vc.backward(dimg, *g, 0)
@@ -735,6 +742,9 @@ def test_pair_major_backward_matches_pixel_major(W, H, B, seed, bg, opaque, wide
     finally:
         lib.cgs_set_unit_backward(prev)
     assert float(res[3][0].abs().max()) > 0
+    if seed == 7:
+        longest = int(vc.status[5::2][:256].max())
+        assert 256 < longest <= 1024, f"case 7 is meant to have tile lists of several batches (longest {longest})"
     for name, a, b in zip(("dL_dmeans2D", "curve_points", "width", "opacity"), res[4], res[3]):
         rel = float((a - b).norm() / b.norm().clamp_min(1e-30))
         assert rel < 2e-4, f"{name}: relative L2 {rel:.2e}"
