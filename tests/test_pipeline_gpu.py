@@ -512,6 +512,10 @@ class _ViewCalls:
         torch.cuda.synchronize()
         assert int(self.status[2]) == 0, "bucket overflow: raise cap"
 
+    def final_T(self):
+        """[H,W] final transmittance the forward left in the image buffer (first carve-out, csrc/common.h)."""
+        return self.img[:4 * self.H * self.W].view(torch.float32).reshape(self.H, self.W).clone()
+
     def backward(self, dimg, g_cp, g_w, g_op, accumulate):
         L, lib, pt, cf, cam = self.L, self.lib, self.L.ptr, self.C.c_float, self.cam
         st = L.raw_stream(torch.device(DEV))
@@ -669,10 +673,20 @@ def test_headline_instances_meet_the_raster_criterion_on_identical_inputs(cfg, b
     assert_close("all_map", vc.omap.cpu().numpy(), fw.out_all_map)
     assert_close("invdepth", vc.invd.cpu().numpy(), fw.invdepth)
     dimg = torch.randn(1, H, W, generator=torch.Generator().manual_seed(17))
+    # Pixels where the two compositors took a DIFFERENT termination decision (the splat that would push T below 1e-4 is not
+    # blended, forward.cu:371-376: under the last bits of the exponent the cut lands one entry earlier or later and the final
+    # transmittance jumps by a factor 1 - alpha) carry no upstream gradient on either side: the gradients are compared on the
+    # pixels both sides composited alike, and the number of excluded pixels is asserted.  At cfg5 EVERY pixel terminates
+    # early; without the exclusion its curve gradients sit at 2e-4 relative L2 instead of the 1e-5 class of the other configs.
+    T_h, T_o = vc.final_T().cpu().numpy(), fw.final_T.reshape(H, W)
+    flipped = np.abs(T_h - T_o) > 1e-3 * np.abs(T_o) + 1e-9
+    print(f"{cfg} bg={bg}: {int(flipped.sum())} of {H * W} pixels took another termination decision ({flipped.mean():.2e})")
+    assert flipped.mean() <= 1e-4          # measured: 0 .. 8.2e-6 (cfg3: 21 pixels, cfg5: 32)
+    dimg = dimg * torch.from_numpy(~flipped)[None]
     gr = ORA.backward(fw, dimg.numpy(), None, None)
     B = vc.B
     g = [vc.f32(B, 4, 3), vc.f32(B, 1), vc.f32(B, 1)]
-    g_m2d = vc.backward(dimg.to(DEV), *g, 0)
+    g_m2d = vc.backward(dimg.to(DEV).contiguous(), *g, 0)
     assert_close("dL_dmeans2D", g_m2d.cpu().numpy(), gr["dL_dmeans2D"], abs_floor=1e-6)
     want = torch.from_numpy(gr["dL_dmeans2D"])
     print(f"{cfg} bg={bg}: dL_dmeans2D relative L2 {float((g_m2d.cpu() - want).norm() / want.norm()):.2e}")
@@ -686,13 +700,14 @@ def test_headline_instances_meet_the_raster_criterion_on_identical_inputs(cfg, b
     for name, got, leaf in zip(("curve_points", "width", "opacity"), g, leaves):
         rel = float((got.cpu() - leaf.grad).norm() / leaf.grad.norm())
         print(f"{cfg} bg={bg}: dL/d{name} relative L2 {rel:.2e}")
-        # measured 2e-6 .. 8e-6 (cfg1-4); cfg5: 2.0e-4 -- every pixel of that view terminates early (T < 1e-4) and which splat
-        # terminates a pixel flips under the last bits of the exponent far more often than an alpha test does
-        assert rel < (3e-4 if cfg == "cfg5" else 3e-5), f"dL/d{name}: relative L2 error {rel:.2e}"
+        # measured 2e-6 .. 8e-6 (cfg1-4)
+        # (cfg5, where every pixel terminates early: 7e-5 on the pixels both sides composited alike -- 2.0e-4 before the
+        # 32 flipped pixels were excluded)
+        assert rel < (1e-4 if cfg == "cfg5" else 3e-5), f"dL/d{name}: relative L2 error {rel:.2e}"
         # element-wise next to the L2 figure: 1e-4 of the tensor's maximum on all but 1e-3 of the curves, no curve beyond
-        # 2e-3 of it (cfg5, where every pixel terminates early: 1e-2 / 2e-2) -- see the printed worst element
+        # 2e-3 of it (measured worst element: <= 5e-5 of the maximum at every config) -- see the printed worst element
         worst = assert_close(f"dL/d{name} (element-wise)", got.cpu().numpy(), leaf.grad.numpy(),
-                             outlier_frac=1e-2 if cfg == "cfg5" else 1e-3, max_outlier=2e-2 if cfg == "cfg5" else 2e-3)
+                             outlier_frac=1e-3, max_outlier=2e-3)
         print(f"{cfg} bg={bg}: dL/d{name} worst element {worst:.2e} of max")
     if cfg == "cfg3" and bg == 0.0:
         # the image-only instance of the forward (no inverse depth, no all_map) at a BASELINE size: same image, bit for bit
