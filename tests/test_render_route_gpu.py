@@ -262,3 +262,26 @@ def test_render_route_matches_the_oracle_at_cfg3_under_the_defaults():
         # sampling backward sums 12 samples per curve with cancellation, and the compositor's float atomics reorder)
         assert_close(f"dL/d{name} (element-wise)", got.numpy(), leaf.grad.numpy(), outlier_frac=1e-3, max_outlier=1e-3)
     fw.free()
+
+
+def test_render_route_on_a_room_scale_scene_with_screen_filling_splats():
+    """cfg4-like geometry (cameras inside the scene box: near-camera splats whose tile rect covers the whole screen, deferred
+    to the one-workgroup-per-splat scatter once a checked forward has counted them): the fused route against the general one,
+    twice in a row (the second call runs with the deferral switched on by the first)."""
+    from curve_gaussian_amd import _lib as L
+    from curve_gaussian_amd.gaussian_renderer import PipelineParams, render
+    L.load().cgs_reset_binning_hints()
+    curves, cams = S.make_config("cfg4", n_views=2)
+    keep = slice(0, 3000)
+    curves = {k: (v[keep] if torch.is_tensor(v) and v.shape[0] > 3000 else v) for k, v in curves.items()}
+    bg = torch.zeros(3, device=DEV)
+    for cam in cams:
+        cam = cam.to(DEV)
+        gm = _model(curves)
+        a = render(cam, gm, PipelineParams(), bg)
+        b = render(cam, gm, PipelineParams(), bg, fused=False)
+        assert torch.equal(a["radii"], b["radii"])
+        assert int(a["radii"].max()) > 100, "scene has no splat whose tile rect exceeds the 96-tile comfort zone of the wave walk"
+        for k in ("render", "depth", "rend_alpha"):
+            assert_close(k, a[k].detach().cpu().numpy(), b[k].detach().cpu().numpy())
+        assert torch.equal(a["visibility_filter"], b["visibility_filter"])
