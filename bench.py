@@ -557,6 +557,19 @@ def main():
                     prof_cams[i].world_view_transform, prof_cams[i].full_proj_transform, tanx, tany, H, W, empty,
                     0, prof_cams[i].camera_center, False, False, True, False)
                 stats["R"] += R_i
+            # ... and the REFERENCE algorithm's instance count for the same views: every tile of the 3-sigma rect, no
+            # alpha >= 1/255 tile culling (SURVEY 8d's byte formula is the reference's compulsory traffic)
+            prev_cull = lib.cgs_set_tile_culling(0)
+            try:
+                for i in range(min(n_prof, 6)):
+                    (R_i, *_rest) = _C.rasterize_gaussians(
+                        bg, xyz, colors, opac, scl, rotn, 1.0, empty, amaps[id(prof_cams[i])],
+                        prof_cams[i].world_view_transform, prof_cams[i].full_proj_transform, tanx, tany, H, W, empty,
+                        0, prof_cams[i].camera_center, False, False, True, False)
+                    stats["R_ref"] = stats.get("R_ref", 0) + R_i
+                stats["R_ref"] /= min(n_prof, 6)
+            finally:
+                lib.cgs_set_tile_culling(prev_cull)
         R_mean = stats["R"] / n_prof
         vis_mean = stats["visible"] / n_prof
     else:
@@ -678,6 +691,13 @@ def main():
                              "achieved_GBps": round(alg_view / (ms_per_view * 1e-3) / 1e9, 2),   # whole job, per view
                              "hbm_roofline_frac": round(alg_view / (ms_per_view * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                              "sum_kernel_ms": round(sum(kernel_ms.values()), 5)}
+        if stats.get("R_ref"):
+            # the same fraction on the instance count the REFERENCE algorithm creates for these views (its 3-sigma tile rects:
+            # tile culling drops the instances that stay below alpha 1/255 on all 256 pixels, the reference bins and sorts them)
+            alg_ref = algorithmic_bytes(P, stats["R_ref"], H, W)
+            out["whole_path"]["reference_instances_per_view"] = round(stats["R_ref"], 1)
+            out["whole_path"]["algorithmic_bytes_per_view_reference_R"] = int(alg_ref)
+            out["whole_path"]["hbm_roofline_frac_reference_R"] = round(alg_ref / (ms_per_view * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
 
     # ---------------------------------------------------------------- train-step ms (the other half of the metric)
     if world == 1 and not args.no_train_step:
