@@ -27,6 +27,11 @@ SIGNATURES = {
                               _vp, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cgs_view_forward_checked": (_i64, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _vp, _vp, C.c_size_t, _vp,
                                         C.c_uint32, _vp, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cgs_view_forward_begin": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _vp, _vp, C.c_size_t, _vp,
+                                    C.c_uint32, _vp, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cgs_view_forward_wait": (_i64, []),
+    "cgs_render_epilogue": (_i, [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "cgs_clamp_backward": (_i, [_i64, _vp, _vp, _vp, _vp]),
     "cgs_bucket_capacity_hint": (C.c_uint32, [_i, _i, _i]),
     "cgs_last_forward_visible": (_i64, []),
     "cgs_view_backward_scratch_floats": (C.c_size_t, [_i, _i]),

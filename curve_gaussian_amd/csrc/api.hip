@@ -602,6 +602,28 @@ int cgs_sample_curves_forward(int B, int m, const float* curve_points, const flo
 // ---------------------------------------------------------------------------------------------- fused per-view path
 // One view of the training configuration, curve parameters in, image out (and back): the per-splat chains are fused
 // (view.hip), the rasterizer is the sync-free single-pass bucket pipeline of cgs_rasterize_forward_static.
+// Status readback of the checked view forward: one outstanding forward per host thread (begin -> wait).
+struct ViewStat { uint32_t* h = nullptr; hipEvent_t ev = nullptr; int P = 0, W = 0, H = 0; uint64_t cap = 0; bool pending = false; };
+static thread_local ViewStat g_view_stat;
+static int64_t view_forward_wait() {
+    ViewStat& v = g_view_stat;
+    if (!v.pending) {
+        set_error("cgs_view_forward_wait: no checked forward outstanding on this thread");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    v.pending = false;
+    const hipError_t e = hipEventSynchronize(v.ev);
+    if (e != hipSuccess) {
+        set_error("cgs_view_forward_checked: status readback failed: %s", hipGetErrorString(e));
+        return CGS_ERR_HIP;
+    }
+    const uint32_t longest = v.h[1];
+    hints_update(v.P, v.W, v.H, (uint64_t)longest <= v.cap ? (int64_t)v.h[0] : -1, longest, (int64_t)v.h[3]);
+    g_last_stats[0] = (int64_t)v.h[0]; g_last_stats[1] = (int64_t)longest; g_last_stats[2] = 1;
+    g_last_visible = (int64_t)v.h[2];
+    return (int64_t)longest;
+}
+
 // Longest tile list of a finished scatter, for the checked (blocking) view forward: one small launch between the scatter
 // and the compositor, so the host's wait ends when the BINNING is done and the compositor is still running.
 __global__ void __launch_bounds__(256) k_count_stats(const uint32_t* __restrict__ tile_count, int tiles, const int* __restrict__ radii,
@@ -627,7 +649,7 @@ __global__ void __launch_bounds__(256) k_count_stats(const uint32_t* __restrict_
     }
 }
 
-static int64_t view_forward_impl(bool checked, int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
+static int64_t view_forward_impl(int mode, int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
                      float eps, double* norms, const float* opacity_logit, const float* mask_logit, float mask_thr,
                      const float* colors_precomp, void* geometry_buffer, void* binning_buffer, size_t binning_bytes,
                      void* image_buffer, uint32_t bucket_capacity, const float* background, int width_px, int height_px,
@@ -682,8 +704,9 @@ static int64_t view_forward_impl(bool checked, int B, int m, const float* curve_
                           defer_big ? img.tile_cursor : nullptr, (uint32_t)tiles);
     // checked: the longest tile list (and the instance count, oversized-rect count) travel to the host right behind the
     // scatter; the compositor is queued before the host waits, so the wait overlaps it
-    static thread_local uint32_t* h_stat = nullptr;   // pinned: instances, longest list, visible splats, oversized rects
-    static thread_local hipEvent_t ev = nullptr;
+    const bool checked = mode != 0;
+    uint32_t*& h_stat = g_view_stat.h;   // pinned: instances, longest list, visible splats, oversized rects
+    hipEvent_t& ev = g_view_stat.ev;
     if (checked) {
         if (!h_stat) {
             if (hipHostMalloc((void**)&h_stat, 4 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
@@ -718,16 +741,8 @@ static int64_t view_forward_impl(bool checked, int B, int m, const float* curve_
     }
     if (!check_launch("view_forward", false, s)) return CGS_ERR_HIP;
     if (checked) {
-        const hipError_t e = hipEventSynchronize(ev);
-        if (e != hipSuccess) {
-            set_error("cgs_view_forward_checked: status readback failed: %s", hipGetErrorString(e));
-            return CGS_ERR_HIP;
-        }
-        const uint32_t longest = h_stat[1];
-        hints_update(P, width_px, height_px, (uint64_t)longest <= cap ? (int64_t)h_stat[0] : -1, longest, (int64_t)h_stat[3]);
-        g_last_stats[0] = (int64_t)h_stat[0]; g_last_stats[1] = (int64_t)longest; g_last_stats[2] = 1;
-        g_last_visible = (int64_t)h_stat[2];
-        return (int64_t)longest;
+        g_view_stat.P = P; g_view_stat.W = width_px; g_view_stat.H = height_px; g_view_stat.cap = cap; g_view_stat.pending = true;
+        if (mode == 1) return view_forward_wait();
     }
     return CGS_OK;
 }
@@ -739,7 +754,7 @@ int cgs_view_forward(int B, int m, const float* curve_points, const float* width
                      const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
                      float* out_color, float* out_invdepth, float* out_all_map, int* radii, float* xyz, float* rotation,
                      float* scaling, void* stream_) {
-    return (int)view_forward_impl(false, B, m, curve_points, width, is_bezier, coef, eps, norms, opacity_logit, mask_logit,
+    return (int)view_forward_impl(0, B, m, curve_points, width, is_bezier, coef, eps, norms, opacity_logit, mask_logit,
                                   mask_thr, colors_precomp, geometry_buffer, binning_buffer, binning_bytes, image_buffer,
                                   bucket_capacity, background, width_px, height_px, viewmatrix, projmatrix, cam_pos, tan_fovx,
                                   tan_fovy, out_color, out_invdepth, out_all_map, radii, xyz, rotation, scaling, stream_);
@@ -752,11 +767,25 @@ int64_t cgs_view_forward_checked(int B, int m, const float* curve_points, const 
                                  const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
                                  float* out_color, float* out_invdepth, float* out_all_map, int* radii, float* xyz,
                                  float* rotation, float* scaling, void* stream_) {
-    return view_forward_impl(true, B, m, curve_points, width, is_bezier, coef, eps, norms, opacity_logit, mask_logit, mask_thr,
+    return view_forward_impl(1, B, m, curve_points, width, is_bezier, coef, eps, norms, opacity_logit, mask_logit, mask_thr,
                              colors_precomp, geometry_buffer, binning_buffer, binning_bytes, image_buffer, bucket_capacity,
                              background, width_px, height_px, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, out_color,
                              out_invdepth, out_all_map, radii, xyz, rotation, scaling, stream_);
 }
+int cgs_view_forward_begin(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier,
+                                 const float* coef, float eps, double* norms, const float* opacity_logit,
+                                 const float* mask_logit, float mask_thr, const float* colors_precomp, void* geometry_buffer,
+                                 void* binning_buffer, size_t binning_bytes, void* image_buffer, uint32_t bucket_capacity,
+                                 const float* background, int width_px, int height_px, const float* viewmatrix,
+                                 const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                                 float* out_color, float* out_invdepth, float* out_all_map, int* radii, float* xyz,
+                                 float* rotation, float* scaling, void* stream_) {
+    return (int)view_forward_impl(2, B, m, curve_points, width, is_bezier, coef, eps, norms, opacity_logit, mask_logit, mask_thr,
+                             colors_precomp, geometry_buffer, binning_buffer, binning_bytes, image_buffer, bucket_capacity,
+                             background, width_px, height_px, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, out_color,
+                             out_invdepth, out_all_map, radii, xyz, rotation, scaling, stream_);
+}
+int64_t cgs_view_forward_wait(void) { return view_forward_wait(); }
 int64_t cgs_last_forward_visible(void) { return g_last_visible; }
 uint32_t cgs_bucket_capacity_hint(int P, int width, int height) {
     const int64_t mx = hints_load(P, width, height).max;
@@ -928,6 +957,59 @@ int cgs_edge_aware_loss(int channels, int height, int width, const float* image,
 size_t cgs_photometric_workspace_bytes(int height, int width) {
     return photometric_workspace_bytes(height > 0 ? height : 1, width > 0 ? width : 1);
 }
+// ---------------------------------------------------------------------------------------------- render() epilogue
+// gaussian_renderer/__init__.py:138-145 for the fused view route in ONE launch: the clamp of the image and the view -> world
+// transform of the direction map (the reference runs a clamp kernel and a [H*W,3] x [3,3] matmul on a 1600^2 image), and the
+// clamp's gradient mask for the way back.
+__global__ void __launch_bounds__(256) k_render_epilogue(size_t npix, const float* __restrict__ color_raw, const float* __restrict__ all_map,
+                                                         const float* __restrict__ wv, int clamp, float* __restrict__ color_out,
+                                                         float* __restrict__ dir_out) {
+    const float w00 = wv[0], w01 = wv[1], w02 = wv[2], w10 = wv[4], w11 = wv[5], w12 = wv[6], w20 = wv[8], w21 = wv[9], w22 = wv[10];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
+        if (color_out) {
+            const float c = color_raw[i];
+            color_out[i] = clamp ? fminf(fmaxf(c, 0.f), 1.f) : c;
+        }
+        if (dir_out) {   // out_i = sum_k d_k wv[i][k]   (rendered_dir.permute(1, 2, 0) @ world_view_transform[:3, :3].T)
+            const float d0 = all_map[i], d1 = all_map[npix + i], d2 = all_map[2 * npix + i];
+            dir_out[i] = d0 * w00 + d1 * w01 + d2 * w02;
+            dir_out[npix + i] = d0 * w10 + d1 * w11 + d2 * w12;
+            dir_out[2 * npix + i] = d0 * w20 + d1 * w21 + d2 * w22;
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_clamp_backward(size_t n, const float* __restrict__ raw, const float* __restrict__ g_in,
+                                                        float* __restrict__ g_out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float x = raw[i];
+        g_out[i] = (x >= 0.f && x <= 1.f) ? g_in[i] : 0.f;   // torch.clamp's backward: the gradient passes where min <= x <= max
+    }
+}
+int cgs_render_epilogue(int height, int width, const float* color_raw, const float* all_map, const float* viewmatrix, int clamp,
+                        float* color_out, float* dir_out, void* stream_) {
+    if (height <= 0 || width <= 0 || (color_out && !color_raw) || (dir_out && (!all_map || !viewmatrix))) {
+        set_error("cgs_render_epilogue: invalid argument");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    if (!color_out && !dir_out) return CGS_OK;
+    const size_t npix = (size_t)height * width;
+    hipLaunchKernelGGL(k_render_epilogue, dim3((unsigned)std::min<size_t>((npix + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream_,
+                       npix, color_raw, all_map, viewmatrix, clamp, color_out, dir_out);
+    if (!check_launch("render_epilogue", false, (hipStream_t)stream_)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
+int cgs_clamp_backward(int64_t n, const float* raw, const float* g_in, float* g_out, void* stream_) {
+    if (n < 0 || (n > 0 && (!raw || !g_in || !g_out))) {
+        set_error("cgs_clamp_backward: invalid argument");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    if (n == 0) return CGS_OK;
+    hipLaunchKernelGGL(k_clamp_backward, dim3((unsigned)std::min<size_t>(((size_t)n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream_,
+                       (size_t)n, raw, g_in, g_out);
+    if (!check_launch("clamp_backward", false, (hipStream_t)stream_)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
+
 int cgs_edge_count(int channels, int height, int width, const float* gt, float threshold, uint32_t* n_pos, void* stream_) {
     if (channels <= 0 || height <= 0 || width <= 0 || !gt || !n_pos) {
         set_error("cgs_edge_count: invalid argument");

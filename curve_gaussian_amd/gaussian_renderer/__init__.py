@@ -76,12 +76,31 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_
         raise ValueError("render(fused=True): the fused view path needs a GaussianCurveModel whose derived tensors are current "
                          "and the reference's default pipeline flags")
     if use_fused:
-        from ..ops.view_render import view_render
-        rendered_image, depth_image, out_all_map, radii, n_visible = view_render(
-            pc._curve_points, pc._width, pc._opacity, pc._mask if use_mask else None, screenspace_points, pc.is_bezier,
-            pc.n_gaussians, mask_thr, bg_color, viewpoint_camera, tanfovx, tanfovy, static_bucket_cap, status_sink)
-        return _package(viewpoint_camera, pc, rendered_image, radii, depth_image, out_all_map, screenspace_points,
-                        use_trained_exp, clamp, compute_rend_dir, compute_visibility, n_visible)
+        from ..ops import view_render as VR
+        while True:
+            # clamp and direction map (:138-145) come out of the same autograd node (one epilogue launch); the exposure of
+            # use_trained_exp sits between compositor and clamp upstream, so that combination keeps the separate ops
+            fold = not use_trained_exp
+            rendered_image, depth_image, out_all_map, radii, rend_dir = VR.view_render(
+                pc._curve_points, pc._width, pc._opacity, pc._mask if use_mask else None, screenspace_points, pc.is_bezier,
+                pc.n_gaussians, mask_thr, bg_color, viewpoint_camera, tanfovx, tanfovy, static_bucket_cap, status_sink,
+                clamp and fold, compute_rend_dir and fold)
+            try:
+                pkg = _package(viewpoint_camera, pc, rendered_image, radii, depth_image, out_all_map, screenspace_points,
+                               use_trained_exp, clamp and not fold, compute_rend_dir and not fold, False)
+            except Exception:
+                VR.finish()   # (use_trained_exp on a one-channel image raises like the reference: no forward left outstanding)
+                raise
+            if compute_rend_dir and fold:
+                pkg["rend_dir"] = rend_dir
+            ok, n_visible = VR.finish()
+            if ok:
+                break
+            # a tile list outgrew its bucket (first view of a new scene, or a much denser one): the capacity has been raised
+            screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True, device=dev)
+        if compute_visibility:
+            pkg["visibility_filter"] = VR.visible_indices(radii, n_visible)
+        return pkg
     raster_settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
         tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,

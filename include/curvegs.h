@@ -170,6 +170,25 @@ int64_t cgs_view_forward_checked(int B, int m, const float* curve_points, const 
                      const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
                      float* out_color, float* out_invdepth, float* out_all_map, int* radii, float* xyz, float* rotation,
                      float* scaling, void* stream);
+/* The same in two halves, so that the caller can queue MORE work behind the forward before it blocks (render() queues its
+ * clamp and direction-map kernels, then waits): cgs_view_forward_begin enqueues everything including the status readback and
+ * returns; cgs_view_forward_wait blocks on that readback and returns what cgs_view_forward_checked returns.  One forward may be
+ * outstanding per host thread. */
+int cgs_view_forward_begin(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
+                     float eps, double* norms, const float* opacity_logit, const float* mask_logit, float mask_thr,
+                     const float* colors_precomp, void* geometry_buffer, void* binning_buffer, size_t binning_bytes,
+                     void* image_buffer, uint32_t bucket_capacity, const float* background, int width_px, int height_px,
+                     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                     float* out_color, float* out_invdepth, float* out_all_map, int* radii, float* xyz, float* rotation,
+                     float* scaling, void* stream);
+int64_t cgs_view_forward_wait(void);
+/* Epilogue of render() on the fused route, /root/reference/gaussian_renderer/__init__.py:138-145 in one launch: color_out [H,W] =
+ * clamp ? clamp(color_raw, 0, 1) : color_raw (NULL: skipped); dir_out [3,H,W] = all_map[0:3] taken from view to world space,
+ * out_i = sum_k all_map[k] * viewmatrix[4 i + k] (viewmatrix = world_view_transform, row-major 4x4; NULL: skipped).
+ * cgs_clamp_backward: g_out = (0 <= raw <= 1) ? g_in : 0, torch.clamp's gradient rule. */
+int cgs_render_epilogue(int height, int width, const float* color_raw, const float* all_map, const float* viewmatrix, int clamp,
+                        float* color_out, float* dir_out, void* stream);
+int cgs_clamp_backward(int64_t n, const float* raw, const float* g_in, float* g_out, void* stream);
 uint32_t cgs_bucket_capacity_hint(int P, int width, int height);
 /* Number of splats with radii > 0 in the calling thread's last cgs_view_forward_checked (-1: none yet): lets the caller size
  * render()'s visibility_filter = (radii > 0).nonzero() (gaussian_renderer/__init__.py:150) without a device-wide sync. */

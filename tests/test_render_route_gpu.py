@@ -52,12 +52,16 @@ def test_default_render_takes_the_fused_route_and_equals_the_general_one(use_mas
     dimg = torch.randn(1, H, W, generator=torch.Generator().manual_seed(1)).to(DEV)
     calls = _count_fused_calls(monkeypatch)
     out = {}
+    ncalls = {}
     for route in (None, False):
         gm = _model(c, mask)
+        before = len(calls)
         pkg = render(cam, gm, PipelineParams(), bg, use_mask=use_mask, mask_thr=0.3, fused=route)
+        ncalls[route] = len(calls) - before
         (pkg["render"] * dimg).sum().backward()
         out[route] = (pkg, gm)
-    assert len(calls) == 1, "render() with default flags must run the fused view path (and fused=False must not)"
+    # (more than one call: the first forward of a new workload shape may outgrow its buckets and is redone)
+    assert ncalls[None] >= 1 and ncalls[False] == 0, "render() with default flags must run the fused view path (and fused=False must not)"
     (pf, gf), (pg, gg) = out[None], out[False]
     assert torch.equal(pf["radii"], pg["radii"]) and torch.equal(pf["visibility_filter"], pg["visibility_filter"])
     for k in ("render", "depth", "rend_dir", "rend_alpha"):
@@ -81,8 +85,10 @@ def test_stale_derived_tensors_send_render_down_the_general_route(monkeypatch):
     gm = _model(c, mask)
     calls = _count_fused_calls(monkeypatch)
     bg = torch.zeros(3, device=DEV)
+    render(cam, gm, PipelineParams(), bg)                      # (sizes the buckets of this shape)
+    calls.clear()
     with torch.no_grad():
-        gm._curve_points.add_(0.01)          # parameters move, prepare_scaling_rot has not run
+        gm._curve_points.add_(0.01)
     stale = render(cam, gm, PipelineParams(), bg)["render"]
     assert len(calls) == 0
     with pytest.raises(ValueError):
