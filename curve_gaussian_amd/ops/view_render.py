@@ -80,7 +80,8 @@ class _ViewRender(torch.autograd.Function):
                     _f(mask_thr), None, L.ptr(geom), L.ptr(binb), nbin, L.ptr(img), cap, L.ptr(bgc), W, H, L.ptr(view),
                     L.ptr(proj), L.ptr(campos), _f(tanx), _f(tany), L.ptr(color), L.ptr(invd), L.ptr(amap), L.ptr(radii),
                     None, None, None, st), "cgs_view_forward_begin")
-                _pending.append((dev.index, P, W, H, cap))
+                del _pending[:]   # one forward outstanding per thread (the library keeps one readback slot): a forward whose
+                _pending.append((dev.index, P, W, H, cap))   # finish() never ran (exception in between) is superseded
             _last_visible[0] = -1
             # render()'s epilogue (:138-145) in the same stream, one launch: clamp of the image, view -> world direction map
             color_raw, rend_dir = color, None
