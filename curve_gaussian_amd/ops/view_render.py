@@ -35,6 +35,8 @@ class _ViewRender(torch.autograd.Function):
     def forward(ctx, curve_points, width, opacity_logit, mask_logit, means2D, is_bezier, m, mask_thr, bg, cam, tanx, tany,
                 static_cap=0, status_sink=None, clamp=False, want_dir=False):
         L.require_gpu_tensor(curve_points, "curve_points")
+        L.require_gpu_tensor(bg, "bg_color")                       # "Background tensor (bg_color) must be on GPU!" (:23)
+        L.require_gpu_tensor(cam.world_view_transform, "viewpoint_camera.world_view_transform")
         lib = L.load()
         dev = curve_points.device
         with L.device_guard(dev):
