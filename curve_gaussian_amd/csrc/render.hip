@@ -419,7 +419,13 @@ __device__ __forceinline__ int sum_field(int f) { return 8 * f + 4 * (f >= 4); }
 // 1 - colour_behind_i = prod_{j > i} (1 - alpha_j) and T_i times that is T_final / (1 - alpha_i).  No state is carried from
 // pair to pair: 5 vector instructions per pair less, and no dependent chain through the walk.
 template <bool GEO, bool INVD, bool COLG, bool UNIT = false>
-__global__ void __launch_bounds__(256, GEO ? 2 : (INVD || COLG) ? 4 : CGS_BWD3_WAVES) k_render_bwd3(
+#ifndef CGS_BWD3_WAVES_GEO
+#define CGS_BWD3_WAVES_GEO 2
+#endif
+#ifndef CGS_BWD3_WAVES_EXTRA
+#define CGS_BWD3_WAVES_EXTRA 4
+#endif
+__global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG) ? CGS_BWD3_WAVES_EXTRA : CGS_BWD3_WAVES) k_render_bwd3(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int grid_x,
     const float* __restrict__ bg_color, const SplatRec* __restrict__ rec, const float* __restrict__ final_Ts,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
