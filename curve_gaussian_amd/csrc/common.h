@@ -270,12 +270,12 @@ __device__ __forceinline__ void rank_loop(const K* s, uint32_t n, const K (&mine
         for (uint32_t e = 0; e < RANK_U; e++) rank[q] += (uint32_t)(k[e] < mine[q]);
 }
 // The same count for ONE key per thread when the keys are positive finite floats (depths): [k < mine] is
-// sat((mine - k) * 2^100) -- the scaling is exact, any non-zero difference of two such floats times 2^100 exceeds 1 -- i.e.
+// sat((mine - k) * 2^64) -- the scaling is exact, any non-zero difference of two depths (> 0.2) times 2^64 exceeds 1 -- i.e.
 // one fma with clamp plus one add per compare (~5 SIMD cycles) instead of v_cmp + add-with-carry (~8: compares and carry
 // adds issue at a quarter of the fma rate; the sorting forward spent 11 of its 122 us in them at cfg3).
 // s is padded with +inf up to a multiple of 4; four independent partial counts keep the adds off one dependency chain.
 __device__ __forceinline__ uint32_t rank_loop_f32(const float* s, uint32_t n, float mine) {
-    float big = 0x1p100f, nbig = -0x1p100f;
+    float big = 0x1p64f, nbig = -0x1p64f;   // depths in (0.2, 1.8e19): no overflow, and ulp(0.2) * 2^64 = 2.7e11 >> 1
     asm volatile("" : "+v"(big), "+v"(nbig));   // in VGPRs: a three-VGPR fma issues faster than one with a literal
     const float mb = mine * big;
     const uint32_t nu = (n + 3u) & ~3u;
