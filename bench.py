@@ -575,6 +575,50 @@ def main():
     else:
         R_mean = vis_mean = 0.0
 
+    # ---- the same per-view body when the curve sampling is SHARED by the views of a step (cgs_set_view_shared_sampling):
+    # the parameters are constant inside a step, so the norm pass of the forward and the last pass of the sampling backward
+    # can run once per step.  Reported separately -- NOT `value`: the reference's iteration is one view per parameter state.
+    shared = None
+    if kernel_ms and args.mode == "view" and cap and world == 1:
+        flat_a, flat_b = torch.zeros_like(flat_grads), torch.zeros_like(flat_grads)
+        body_s, d_s = make_direct_view(flat_a, cap)
+        cp0, w0, _op0 = base
+        isb_u8 = curve_sampling._bezier_mask(isb, dev)
+        Gs = max(1, args.views_per_step)
+        cams_s = my_cams[:Gs]
+
+        def step_shared(flat, on):
+            prev = lib.cgs_set_view_shared_sampling(1 if on else 0)
+            try:
+                st = L.raw_stream(dev)
+                if on:
+                    L.check(lib.cgs_view_shared_begin(B, m, L.ptr(cp0), L.ptr(isb_u8), L.ptr(d_s["coef"]), L.ptr(d_s["norms"]),
+                                                      L.ptr(d_s["scratch"]), st), "cgs_view_shared_begin")
+                for c in cams_s:
+                    body_s(c)
+                if on:
+                    L.check(lib.cgs_view_shared_end(B, m, L.ptr(cp0), L.ptr(w0), L.ptr(isb_u8), L.ptr(d_s["coef"]), C.c_float(1e-8),
+                                                    L.ptr(d_s["norms"]), L.ptr(d_s["scratch"]), L.ptr(flat[0:12 * B]),
+                                                    L.ptr(flat[12 * B:13 * B]), 1, st), "cgs_view_shared_end")
+            finally:
+                lib.cgs_set_view_shared_sampling(prev)
+        flat_a.zero_(); step_shared(flat_a, False); torch.cuda.synchronize(); ref_s = flat_a.clone()
+        flat_a.zero_(); step_shared(flat_a, True); torch.cuda.synchronize()
+        rel_s = float((flat_a - ref_s).norm() / ref_s.norm().clamp_min(1e-30))
+        lib.cgs_prof_reset(); lib.cgs_prof_enable(1)
+        for _ in range(2):
+            step_shared(flat_a, True)
+        torch.cuda.synchronize(); lib.cgs_prof_enable(0)
+        ks = {name: ms / (2 * Gs) for name, (ms, n) in L.prof_collect().items()}   # per VIEW (step kernels amortised)
+        shared = {"views_per_step": Gs, "kernel_ms_per_view": {k: round(v, 5) for k, v in sorted(ks.items(), key=lambda kv: -kv[1])},
+                  "sum_kernel_ms": round(sum(ks.values()), 5),
+                  "non_compositor_kernel_ms": round(sum(v for k, v in ks.items() if k not in ("render_fwd", "render_bwd")), 5),
+                  "step_gradient_rel_l2_vs_per_view_sampling": float(f"{rel_s:.3e}"),
+                  "note": "serial eager launches, HIP events per kernel; k_sample_f12 and k_sample_bwd<3> run once per step of "
+                          f"{Gs} views (their time is divided by {Gs}); NOT part of value"}
+        if not rel_s < 1e-3:
+            raise RuntimeError(f"bench: shared sampling changed the step gradient (relative L2 {rel_s:.3e})")
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -687,6 +731,8 @@ def main():
                                                       "instructions (v_cmp, v_cndmask, integer) halve it: a mix at "
                                                       "simd_cycles_per_valu_instr ~3 is issue-saturated"}
         out["kernel_ms_per_view"] = {k: round(v, 5) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])}
+        if shared is not None:
+            out["shared_sampling"] = shared
         out["whole_path"] = {"algorithmic_bytes_per_view": int(alg_view),
                              "achieved_GBps": round(alg_view / (ms_per_view * 1e-3) / 1e9, 2),   # whole job, per view
                              "hbm_roofline_frac": round(alg_view / (ms_per_view * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),

@@ -152,6 +152,11 @@ static inline bool fuse_sort() { return g_fuse_sort.load(std::memory_order_relax
 // CGS_FWD_PIPE=1 in the environment selects it for A/B runs; off by default: measured slower, profiles/r04_experiments.md)
 static std::atomic<int> g_fwd_pipe{[] { const char* e = getenv("CGS_FWD_PIPE"); return (e && e[0] == '1') ? 1 : 0; }()};
 static inline bool fwd_pipe() { return g_fwd_pipe.load(std::memory_order_relaxed) != 0; }
+// Shared curve sampling for several views of ONE parameter state (cgs_set_view_shared_sampling): the grid-wide norm pass of
+// the forward and the last pass of the sampling backward run once per view BATCH (cgs_view_shared_begin / _end) instead of
+// once per view -- the parameters do not change inside a batch and that backward pass is linear in the per-splat gradients
+static std::atomic<int> g_shared_sampling{0};
+static inline bool shared_sampling() { return g_shared_sampling.load(std::memory_order_relaxed) != 0; }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace cgs
@@ -188,6 +193,7 @@ void cgs_reset_binning_hints(void) {
 int cgs_set_tile_culling(int on) {
     return g_tile_cull.exchange(on ? 1 : 0, std::memory_order_relaxed);
 }
+int cgs_set_view_shared_sampling(int on) { return g_shared_sampling.exchange(on ? 1 : 0, std::memory_order_relaxed); }
 int cgs_set_forward_pipeline(int on) { return g_fwd_pipe.exchange(on ? 1 : 0, std::memory_order_relaxed); }
 int cgs_set_fused_tile_sort(int on) {
     return g_fuse_sort.exchange(on ? 1 : 0, std::memory_order_relaxed);
@@ -687,11 +693,13 @@ static int64_t view_forward_impl(int mode, int B, int m, const float* curve_poin
     ImageState img = image_from_chunk(ichunk, npix, (size_t)tiles);
     const size_t clear_bytes = (size_t)((char*)(img.total + TOTAL_WORDS) - (char*)img.tile_count);
     // all five grid-wide sums (forward norms AND the backward's two) start from zero here: one launch per view
-    if (zero_async(norms, (size_t)sample_norm_words() * sizeof(double), s) != hipSuccess) {
-        set_error("zero_async(norms) failed");
-        return CGS_ERR_HIP;
+    if (!shared_sampling()) {
+        if (zero_async(norms, (size_t)sample_norm_words() * sizeof(double), s) != hipSuccess) {
+            set_error("zero_async(norms) failed");
+            return CGS_ERR_HIP;
+        }
+        launch_sample_norms(s, B, m, curve_points, is_bezier, coef, norms);
     }
-    launch_sample_norms(s, B, m, curve_points, is_bezier, coef, norms);
     launch_view_forward(s, B, m, curve_points, width, is_bezier, coef, eps, norms, opacity_logit, mask_logit, mask_thr,
                         colors_precomp, cam_pos, viewmatrix, projmatrix, tan_fovx, tan_fovy, focal_x, focal_y, width_px,
                         height_px, gx, gy, xyz, rotation, scaling, radii, geom.rec, geom.grad_acc, img.tile_count,
@@ -839,10 +847,46 @@ int cgs_view_backward(int B, int m, const float* curve_points, const float* widt
     launch_view_backward(s, B, m, curve_points, width, is_bezier, coef, eps, norms, opacity_logit, mask_logit, mask_thr,
                          cam_pos, viewmatrix, projmatrix, tan_fovx, tan_fovy, focal_x, focal_y, width_px, height_px, radii,
                          geom.rec, geom.grad_acc, dL_drotation_extra, dL_dmeans2D, dL_dopacity_logit, dL_dmask_logit, g_xyz,
-                         g_scl, gv, accumulate);
-    launch_sample_backward_pass3(s, B, m, curve_points, width, is_bezier, coef, eps, norms, g_xyz, gv, g_scl,
-                                 dL_dcurve_points, dL_dwidth, gv, accumulate);
+                         g_scl, gv, (accumulate ? 1 : 0) | (shared_sampling() ? 2 : 0));
+    if (!shared_sampling())
+        launch_sample_backward_pass3(s, B, m, curve_points, width, is_bezier, coef, eps, norms, g_xyz, gv, g_scl,
+                                     dL_dcurve_points, dL_dwidth, gv, accumulate);
     if (!check_launch("view_backward", false, s)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
+
+int cgs_view_shared_begin(int B, int m, const float* curve_points, const uint8_t* is_bezier, const float* coef, double* norms,
+                          float* scratch, void* stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    if (B <= 0 || m <= 0 || m > 32 || !curve_points || !coef || !norms || !scratch || !aligned16(curve_points) || !aligned16(coef)) {
+        set_error("cgs_view_shared_begin: invalid argument");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    if (zero_async(norms, (size_t)sample_norm_words() * sizeof(double), s) != hipSuccess ||
+        zero_async(scratch, cgs_view_backward_scratch_floats(B, m) * sizeof(float), s) != hipSuccess) {
+        set_error("zero_async failed");
+        return CGS_ERR_HIP;
+    }
+    launch_sample_norms(s, B, m, curve_points, is_bezier, coef, norms);
+    if (!check_launch("view_shared_begin", false, s)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
+int cgs_view_shared_end(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
+                        float eps, double* norms, float* scratch, float* dL_dcurve_points, float* dL_dwidth, int accumulate,
+                        void* stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    if (B <= 0 || m <= 0 || m > 32 || !curve_points || !width || !coef || !norms || !scratch || !dL_dcurve_points || !dL_dwidth ||
+        !aligned16(curve_points) || !aligned16(coef) || !aligned16(dL_dcurve_points)) {
+        set_error("cgs_view_shared_end: invalid argument");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    const int P = B * m;
+    float* gv = scratch;
+    float* g_xyz = scratch + (size_t)P * 9;
+    float* g_scl = scratch + (size_t)P * 12;
+    launch_sample_backward_pass3(s, B, m, curve_points, width, is_bezier, coef, eps, norms, g_xyz, gv, g_scl, dL_dcurve_points,
+                                 dL_dwidth, gv, accumulate);
+    if (!check_launch("view_shared_end", false, s)) return CGS_ERR_HIP;
     return CGS_OK;
 }
 

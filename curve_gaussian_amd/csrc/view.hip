@@ -80,7 +80,11 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK, CGS_VIEW_BWD_WAVES) k_view_bwd(
     const float* __restrict__ campos, ViewParams vp, const int* __restrict__ radii, const SplatRec* __restrict__ rec,
     float* __restrict__ grad_acc, const float* __restrict__ g_rot_raw_extra, float* __restrict__ dL_dmean2D,
     float* __restrict__ g_opacity_logit, float* __restrict__ g_mask_logit, float* __restrict__ g_xyz,
-    float* __restrict__ g_scaling, float* __restrict__ gv_cache, int accumulate) {
+    float* __restrict__ g_scaling, float* __restrict__ gv_cache, int accumulate_flags) {
+    // bit 0: add to the caller's gradient outputs; bit 1: add to the per-splat scratch as well (shared-sampling mode: the
+    // sampling backward's last pass runs once for several views and is linear in these per-splat gradients)
+    const int accumulate = accumulate_flags & 1;
+    const bool acc_scr = (accumulate_flags & 2) != 0;
     __shared__ SampleCoef s_coef[MAX_M];
     __shared__ BlockConst s_bc;
     __shared__ float s_go[SAMPLE_BLOCK];
@@ -146,12 +150,17 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK, CGS_VIEW_BWD_WAVES) k_view_bwd(
         const V3 g_v2 = {gM[0][2], gM[1][2], gM[2][2]};
         float* gv = gv_cache + p;             // planes [9][P]: a wave's accesses are contiguous
         const size_t PS = (size_t)B * m;
-        gv[0] = g_v0.x; gv[PS] = g_v0.y; gv[2 * PS] = g_v0.z; gv[3 * PS] = g_v1.x; gv[4 * PS] = g_v1.y; gv[5 * PS] = g_v1.z;
-        gv[6 * PS] = g_v2.x; gv[7 * PS] = g_v2.y; gv[8 * PS] = g_v2.z;
+        const float gvv[9] = {g_v0.x, g_v0.y, g_v0.z, g_v1.x, g_v1.y, g_v1.z, g_v2.x, g_v2.y, g_v2.z};
+#pragma unroll
+        for (int e = 0; e < 9; e++) gv[e * PS] = acc_scr ? gv[e * PS] + gvv[e] : gvv[e];
         acc_d2 = (double)dot(g_v2, s.c2v);
         acc_a = (double)dot(g_v1, s.c1v) + (double)((1.f / N2) * dot(cross(g_v2, s.tan), s.c1v));
-        g_xyz[3 * p] = o.dmean.x; g_xyz[3 * p + 1] = o.dmean.y; g_xyz[3 * p + 2] = o.dmean.z;
-        g_scaling[3 * p] = gs.x * ab.mk; g_scaling[3 * p + 1] = gs.y * ab.mk; g_scaling[3 * p + 2] = gs.z * ab.mk;
+        const float gxs[6] = {o.dmean.x, o.dmean.y, o.dmean.z, gs.x * ab.mk, gs.y * ab.mk, gs.z * ab.mk};
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            g_xyz[3 * p + e] = acc_scr ? g_xyz[3 * p + e] + gxs[e] : gxs[e];
+            g_scaling[3 * p + e] = acc_scr ? g_scaling[3 * p + e] + gxs[3 + e] : gxs[3 + e];
+        }
     }
     s_go[threadIdx.x] = g_op_term;
     const double acc2v[2] = {acc_d2, acc_a};

@@ -193,6 +193,19 @@ uint32_t cgs_bucket_capacity_hint(int P, int width, int height);
 /* Number of splats with radii > 0 in the calling thread's last cgs_view_forward_checked (-1: none yet): lets the caller size
  * render()'s visibility_filter = (radii > 0).nonzero() (gaussian_renderer/__init__.py:150) without a device-wide sync. */
 int64_t cgs_last_forward_visible(void);
+/* Several views of ONE parameter state (a view batch between two optimizer steps; not the reference's one-view iteration):
+ * with cgs_set_view_shared_sampling(1) cgs_view_forward no longer runs the grid-wide norm pass of prepare_scaling_rot and
+ * cgs_view_backward adds its per-splat gradients into `scratch` and skips the last pass of the sampling backward (linear in
+ * them); the caller brackets the batch with cgs_view_shared_begin (zeroes norms and scratch, computes the norms once) and
+ * cgs_view_shared_end (that last pass, once: dL/dcurve_points, dL/dwidth written or added to).  Every view of the batch must
+ * use the SAME norms and scratch buffers; opacity / mask gradients keep coming from cgs_view_backward (accumulate = 1 to sum
+ * them over the batch).  The setter is process-wide and returns the previous value. */
+int cgs_set_view_shared_sampling(int on);
+int cgs_view_shared_begin(int B, int m, const float* curve_points, const uint8_t* is_bezier, const float* coef, double* norms,
+                          float* scratch, void* stream);
+int cgs_view_shared_end(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
+                        float eps, double* norms, float* scratch, float* dL_dcurve_points, float* dL_dwidth, int accumulate,
+                        void* stream);
 size_t cgs_view_backward_scratch_floats(int B, int m);
 int cgs_view_backward(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
                       float eps, double* norms, const float* opacity_logit, const float* mask_logit, float mask_thr,

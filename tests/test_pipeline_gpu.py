@@ -1087,3 +1087,44 @@ def test_persistent_forward_pipeline_is_bit_identical(W, H, B, seed, opaque, wid
     assert torch.equal(a["lists"][tagged], b["lists"][tagged])
     rel = float((a["m2d"] - b["m2d"]).norm() / a["m2d"].norm().clamp_min(1e-30))
     assert rel < 1e-4, f"backward on the two forwards' lists: {rel:.2e}"   # (float atomics order; same lists)
+
+
+def test_shared_sampling_over_a_view_batch_gives_the_summed_gradient():
+    """cgs_set_view_shared_sampling(1) + cgs_view_shared_begin / _end: the grid-wide norm pass and the last pass of the sampling
+    backward once per view BATCH (same parameters for every view of it) instead of once per view.  The batch gradient must be
+    the sum of the per-view gradients of the default mode -- that backward pass is linear in the per-splat gradients."""
+    import ctypes as C
+    from curve_gaussian_amd import _lib as L
+    lib = L.load()
+    curves = S.make_curves(700, 21)
+    curves["width"] = curves["width"] + 0.6
+    cams = [S.make_camera((0.5 + 1.8 * math.cos(a), 0.5 + 1.8 * math.sin(a), 0.8), (0.5, 0.5, 0.5), (0, 0, 1), 144, 176).to(DEV)
+            for a in (0.2, 1.9, 3.7)]
+    vc = _ViewCalls(curves["curve_points"], curves["width"], curves["opacity"], curves["is_bezier"], cams[0], 1024)
+    dimgs = [torch.randn(1, vc.H, vc.W, generator=torch.Generator().manual_seed(30 + k)).to(DEV) for k in range(3)]
+    pt, st = L.ptr, L.raw_stream(torch.device(DEV))
+
+    def batch(shared):
+        g = [vc.f32(vc.B, 4, 3), vc.f32(vc.B, 1), vc.f32(vc.B, 1)]
+        prev = lib.cgs_set_view_shared_sampling(1 if shared else 0)
+        try:
+            if shared:
+                L.check(lib.cgs_view_shared_begin(vc.B, vc.m, pt(vc.cp), pt(vc.isb), pt(vc.coef), pt(vc.norms), pt(vc.scratch), st),
+                        "cgs_view_shared_begin")
+            for cam, d in zip(cams, dimgs):
+                vc.cam = cam
+                vc.forward()
+                vc.backward(d, *g, 1)
+            if shared:
+                L.check(lib.cgs_view_shared_end(vc.B, vc.m, pt(vc.cp), pt(vc.w), pt(vc.isb), pt(vc.coef), C.c_float(1e-8),
+                                                pt(vc.norms), pt(vc.scratch), pt(g[0]), pt(g[1]), 0, st), "cgs_view_shared_end")
+            torch.cuda.synchronize()
+        finally:
+            lib.cgs_set_view_shared_sampling(prev)
+        return [t.cpu().double() for t in g]
+
+    ref, got = batch(False), batch(True)
+    for name, a, b in zip(("curve_points", "width", "opacity"), got, ref):
+        assert float(b.abs().max()) > 0
+        rel = float((a - b).norm() / b.norm())
+        assert rel < 2e-4, f"shared sampling, dL/d{name}: relative L2 {rel:.2e} against the per-view sum"
