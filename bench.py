@@ -13,8 +13,11 @@ dL_dinvdepth = dL_dall_map = 0 as in training).  Default workload = BASELINE cfg
 target is quoted on): 16 667 curves x 12 = 200 004 splats, 1600x1600, Fibonacci-sphere cameras.
 
     python bench.py --gpus 1 --steps 64 --warmup 8
+    python bench.py --gpus N --steps K --warmup W        # launches N ranks itself (torch.distributed.run underneath)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
+`--gpus` must equal the number of ranks (WORLD_SIZE) and must not exceed the GPUs visible on the node: both are checked
+and the run exits non-zero with a message instead of silently timing one rank.
 
 Multi-GPU: views shard across ranks (rank r renders views r, r+N, ...), weak scaling (K views per rank); the
 per-step exchange is ONE RCCL all-reduce of the flat curve-level gradient buffer.
@@ -127,15 +130,36 @@ def main():
                     help="A/B: backward compositor of the unit-colour view path (cgs_set_unit_backward); 0 = library default")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # Control-flow rehearsal of the multi-rank path on a box with ONE GPU (tests only): every rank uses device 0 and the
     # collectives go through gloo (RCCL refuses two ranks on one device).  Never set for a measurement.
     rehearsal = os.environ.get("CGS_BENCH_REHEARSAL") == "1"
+    if args.gpus < 1:
+        sys.exit(f"bench.py: --gpus {args.gpus}: need at least one GPU")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    n_dev = torch.cuda.device_count()
+    if args.gpus > n_dev and not rehearsal:
+        sys.exit(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible on this node: one rank per GPU, no "
+                 f"oversubscription (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES = "
+                 f"{os.environ.get('HIP_VISIBLE_DEVICES', os.environ.get('ROCR_VISIBLE_DEVICES', 'unset'))})")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: become the launcher -- one process per GPU over RCCL, exactly the
+        # torch.distributed.run command line the docstring gives; the ranks print, this process only relays the exit code
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if rehearsal:
         local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    if world != args.gpus and not os.environ.get("CGS_BENCH_FORCE_DIST"):
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): the two must agree -- "
+                 f"`n_gpus` in the output line is the real world size")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None   # the process group is created after the hipGraph captures (below): no RCCL thread runs during capture
@@ -651,6 +675,8 @@ def main():
     # how many ranks the step's collective really spanned (1: no process group, nothing was exchanged) and how the step
     # boundary is scheduled -- top-level, whatever N, so a scaling record can be read without the config block
     out["rccl_ranks"] = dist.get_world_size() if dist is not None else 1
+    assert out["rccl_ranks"] == world == args.gpus or os.environ.get("CGS_BENCH_FORCE_DIST"), \
+        f"--gpus {args.gpus}, WORLD_SIZE {world}, collective spans {out['rccl_ranks']} rank(s)"
     out["step_boundary"] = out["config"]["step_boundary"]
     if world > 1:
         # what this run should show, machine-readable: per-rank step = G views at the 1-GPU per-view

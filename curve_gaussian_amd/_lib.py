@@ -49,6 +49,7 @@ SIGNATURES = {
     "cgs_set_fused_tile_sort": (_i, [_i]),
     "cgs_set_forward_pipeline": (_i, [_i]),
     "cgs_set_unit_backward": (_i, [_i]),
+    "cgs_set_operator_unit_route": (_i, [_i]),
     "cgs_reset_binning_hints": (None, []),
     "cgs_last_forward_stats": (None, [C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i)]),
     "cgs_prof_enable": (None, [_i]),

@@ -145,6 +145,13 @@ static hipError_t zero_async(void* p, size_t bytes, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Operator API (cgs_rasterize_forward / _backward): the forward tags its tile lists and lets the scatter raise a device word
+// when some visible splat's colour or all_map[3] is not exactly 1; a backward that needs neither colour nor depth / all_map
+// gradients then launches the pair-major unit-colour kernel AND the general training instance, and that word decides on the
+// device which of the two runs (no host sync).  cgs_set_operator_unit_route(0) keeps the general instance only (A/B, tests).
+static std::atomic<int> g_op_unit{1};
+static inline bool list_tags_fit(int P) { return (long long)P < (1ll << LIST_TAG_SHIFT); }
+constexpr int NONUNIT_WORD = 8;            // index into ImageState::work (cleared with the tile histogram)
 static std::atomic<int> g_unit_bwd{4};     // backward compositor of the unit-colour view path: 4 = pair-major (render_unit_bwd.hip), 3 = pixel-major k_render_bwd3<UNIT>
 static std::atomic<int> g_fuse_sort{1};    // tile sort inside the forward compositor (cgs_set_fused_tile_sort)
 static inline bool fuse_sort() { return g_fuse_sort.load(std::memory_order_relaxed) != 0; }
@@ -198,6 +205,7 @@ int cgs_set_forward_pipeline(int on) { return g_fwd_pipe.exchange(on ? 1 : 0, st
 int cgs_set_fused_tile_sort(int on) {
     return g_fuse_sort.exchange(on ? 1 : 0, std::memory_order_relaxed);
 }
+int cgs_set_operator_unit_route(int on) { return g_op_unit.exchange(on ? 1 : 0, std::memory_order_relaxed); }
 int cgs_set_unit_backward(int variant) {
     if (variant != 3 && variant != 4) return g_unit_bwd.load(std::memory_order_relaxed);
     return g_unit_bwd.exchange(variant, std::memory_order_relaxed);
@@ -321,9 +329,11 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
                               tile_count ? 0 : clear_bytes / sizeof(uint32_t));
         return check_launch("preprocess_fwd", debug, s);
     };
+    const bool tag = list_tags_fit(P);
+    uint32_t* const nonunit = img.work + NONUNIT_WORD;
     auto render = [&](const uint32_t* point_list) -> bool {
         launch_render_fwd(s, render_geo != 0, tiles, img.ranges, point_list, width, height, gx, geom.rec, img.final_T,
-                          img.n_contrib, background, out_color, out_invdepth, out_all_map);
+                          img.n_contrib, background, out_color, out_invdepth, out_all_map, false, tag);
         return check_launch("render_fwd", debug, s);
     };
 
@@ -348,7 +358,7 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
             BinState bin = bin_from_chunk(bchunk, (size_t)(cap * tiles));
             const bool defer_big = hints.big > 0;
             launch_scatter_bucket(s, P, radii, geom.rec, gx, gy, img.tile_count, bin.keys, (uint32_t)cap, cull, img.total + 3,
-                                  defer_big ? img.tile_cursor : nullptr, (uint32_t)tiles);   // (cursors: unused here)
+                                  defer_big ? img.tile_cursor : nullptr, (uint32_t)tiles, nonunit);   // (cursors: unused here)
             // (the fused sort+composite kernel is for the sync-free forward only: here num_rendered has to come back to
             // the host, and with the separate sort kernel that readback overlaps the compositor instead of following it)
             launch_tile_sort_bucket(s, tiles, img.tile_count, img.ranges, img.total, bin.keys, bin.point_list, (uint32_t)cap);
@@ -399,7 +409,7 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
             return CGS_ERR_ALLOC;
         }
         bin = bin_from_chunk(bchunk, (size_t)cap);
-        launch_scatter(s, P, radii, geom.rec, gx, gy, img.ranges, img.tile_cursor, bin.keys, (uint32_t)cap, cull);
+        launch_scatter(s, P, radii, geom.rec, gx, gy, img.ranges, img.tile_cursor, bin.keys, (uint32_t)cap, cull, nonunit);
         launch_tile_sort_small(s, tiles, img.ranges, bin.keys, bin.point_list, (uint32_t)cap);
     }
     if (!wait_totals()) return CGS_ERR_HIP;
@@ -419,7 +429,7 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
         }
         bin = bin_from_chunk(bchunk, (size_t)(R > 0 ? R : 1));
         if (R > 0) {
-            launch_scatter(s, P, radii, geom.rec, gx, gy, img.ranges, img.tile_cursor, bin.keys, (uint32_t)cap, cull);
+            launch_scatter(s, P, radii, geom.rec, gx, gy, img.ranges, img.tile_cursor, bin.keys, (uint32_t)cap, cull, nonunit);
             if (!check_launch("scatter", debug, s)) return CGS_ERR_HIP;
             launch_tile_sort_small(s, tiles, img.ranges, bin.keys, bin.point_list, (uint32_t)cap);
             if (!check_launch("tile_sort", debug, s)) return CGS_ERR_HIP;
@@ -480,8 +490,9 @@ int cgs_rasterize_forward_static(void* geometry_buffer, void* binning_buffer, si
                           width, height, tan_fovx, tan_fovy, focal_x, focal_y, radii, geom.rec, geom.rgb, gx, gy, nullptr,
                           antialiasing, 1, geom.grad_acc, img.tile_count, clear_bytes / sizeof(uint32_t));
     const bool defer_big = hints_load(P, width, height).big > 0;   // (from the caller's probing forwards of this shape)
+    const bool tag = list_tags_fit(P);
     launch_scatter_bucket(s, P, radii, geom.rec, gx, gy, img.tile_count, bin.keys, (uint32_t)cap, 1, img.total + 3,
-                          defer_big ? img.tile_cursor : nullptr, (uint32_t)tiles);
+                          defer_big ? img.tile_cursor : nullptr, (uint32_t)tiles, img.work + NONUNIT_WORD);
     if (render_fwd_pipe_ok((uint32_t)cap) && fuse_sort() && fwd_pipe()) {
         launch_render_fwd_pipe(s, render_geo != 0, tiles, img.tile_count, bin.keys, (uint32_t)cap, img.ranges, img.total,
                                bin.point_list, width, height, gx, geom.rec, img.final_T, img.n_contrib, background, out_color,
@@ -489,11 +500,11 @@ int cgs_rasterize_forward_static(void* geometry_buffer, void* binning_buffer, si
     } else if (render_fwd_can_sort((uint32_t)cap) && fuse_sort()) {
         launch_render_fwd_sorting(s, render_geo != 0, tiles, img.tile_count, bin.keys, (uint32_t)cap, img.ranges, img.total,
                                   bin.point_list, width, height, gx, geom.rec, img.final_T, img.n_contrib, background,
-                                  out_color, out_invdepth, out_all_map);
+                                  out_color, out_invdepth, out_all_map, false, tag);
     } else {
         launch_tile_sort_bucket(s, tiles, img.tile_count, img.ranges, img.total, bin.keys, bin.point_list, (uint32_t)cap);
         launch_render_fwd(s, render_geo != 0, tiles, img.ranges, bin.point_list, width, height, gx, geom.rec, img.final_T,
-                          img.n_contrib, background, out_color, out_invdepth, out_all_map);
+                          img.n_contrib, background, out_color, out_invdepth, out_all_map, false, tag);
     }
     if (!check_launch("rasterize_forward_static", false, s)) return CGS_ERR_HIP;
     return CGS_OK;
@@ -559,9 +570,22 @@ int cgs_rasterize_backward(int P, int D, int M, int64_t R, const float* backgrou
     // geom.grad_acc is zero here: the forward's preprocess kernel cleared it and k_preprocess_bwd clears it after use
     if (R > 0) {
         const bool geo = render_geo && dL_dout_all_map;
-        launch_render_bwd(s, geo, dL_dout_invdepth != nullptr, dL_dcolor != nullptr, tiles, img.ranges, bin.point_list,
-                          width, height, gx, background, geom.rec, img.final_T, img.n_contrib, dL_dout_color,
-                          dL_dout_invdepth, dL_dout_all_map, geom.grad_acc);
+        const bool invd = dL_dout_invdepth != nullptr, colg = dL_dcolor != nullptr;
+        const bool tagged = list_tags_fit(P);   // (the forward's own condition: both sides derive it from P)
+        const uint32_t id_mask = tagged ? LIST_ID_MASK : 0xffffffffu;
+        // Training instance (only dL/dcolour upstream, the colours themselves need no gradient): the reference's own call
+        // (gaussian_renderer/__init__.py:96-129) passes all-ones colours and all_map[:, 3] == 1, for which dL/dalpha has the
+        // closed form of render_unit_bwd.hip.  The ABI receives tensors and cannot know that on the host; the scatter of the
+        // forward raised img.work[NONUNIT_WORD] if any visible splat deviates, and the two kernels test that word on entry.
+        const uint32_t* gate = nullptr;
+        if (tagged && !geo && !invd && !colg && g_op_unit.load(std::memory_order_relaxed)) {
+            gate = img.work + NONUNIT_WORD;
+            launch_render_bwd_unit(s, tiles, img.ranges, bin.point_list, width, height, gx, background, geom.rec, img.final_T,
+                                   img.n_contrib, dL_dout_color, geom.grad_acc, ACC_STRIDE, gate);
+        }
+        launch_render_bwd(s, geo, invd, colg, tiles, img.ranges, bin.point_list, width, height, gx, background, geom.rec,
+                          img.final_T, img.n_contrib, dL_dout_color, dL_dout_invdepth, dL_dout_all_map, geom.grad_acc, false,
+                          ACC_STRIDE, id_mask, gate);
         if (!check_launch("render_bwd", debug, s)) return CGS_ERR_HIP;
     }
     launch_preprocess_bwd(s, P, D, M, means3D, radii, shs, geom.clamped, opacities, scales, rotations, scale_modifier,

@@ -74,7 +74,8 @@ template <bool BUCKET>
 __global__ void __launch_bounds__(256) k_scatter(int P, const int* __restrict__ radii,
                                                  const SplatRec* __restrict__ rec, int grid_x, int grid_y,
                                                  const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_cursor,
-                                                 uint64_t* __restrict__ keys, uint32_t cap, int cull) {
+                                                 uint64_t* __restrict__ keys, uint32_t cap, int cull,
+                                                 uint32_t* __restrict__ nonunit) {
     const int lane = threadIdx.x & 63;
     const int idx = (blockIdx.x * 4 + (threadIdx.x >> 6)) * SCATTER_SPW + lane;
     const int radius = (lane < SCATTER_SPW && idx < P) ? radii[idx] : 0;
@@ -88,6 +89,7 @@ __global__ void __launch_bounds__(256) k_scatter(int P, const int* __restrict__ 
         const float4 d = rec[idx].d;
         key_hi = __float_as_uint(d.x);  // depth bits (positive floats order like unsigned ints)
         key_lo = (uint32_t)idx;
+        if (nonunit && d.w != 0.f) *nonunit = 1u;   // a visible splat whose colour / all_map[3] is not 1 (splat_record)
         if (cull) {
             conic_z = rec[idx].b.x;
             tau2 = d.z;
@@ -194,6 +196,7 @@ __device__ __forceinline__ uint2 bucket_range(const uint32_t* __restrict__ tile_
 // group), and the per-splat constants reach the group through ds_bpermute.
 struct SplatWalk {                  // per-lane: this lane's own splat; fetch(): the splat of lane `src`
     uint32_t x0, y0, w, nt;
+    bool nonunit;                   // (own splat only) colour or all_map[3] differs from 1
     float cx, cy, A, B, C, tau2;
     uint32_t khi, klo;
     __device__ __forceinline__ SplatWalk fetch(int src) const {
@@ -203,6 +206,7 @@ struct SplatWalk {                  // per-lane: this lane's own splat; fetch():
         o.cx = __shfl(cx, src, 64); o.cy = __shfl(cy, src, 64); o.A = __shfl(A, src, 64); o.B = __shfl(B, src, 64);
         o.C = __shfl(C, src, 64); o.tau2 = __shfl(tau2, src, 64);
         o.khi = (uint32_t)__shfl((int)khi, src, 64); o.klo = (uint32_t)__shfl((int)klo, src, 64);
+        o.nonunit = false;
         return o;
     }
 };
@@ -220,6 +224,7 @@ __device__ __forceinline__ SplatWalk load_splat_walk(bool owner, int idx, int P,
         s.cx = a.x; s.cy = a.y; s.A = a.z; s.B = a.w; s.C = rec[idx].b.x; s.tau2 = d.z;
         s.khi = __float_as_uint(d.x);  // depth bits (positive floats order like unsigned ints)
         s.klo = (uint32_t)idx;
+        s.nonunit = d.w != 0.f;
     }
     return s;
 }
@@ -293,7 +298,8 @@ __global__ void __launch_bounds__(256) k_scatter_window(int P, const int* __rest
                                                         const SplatRec* __restrict__ rec, int grid_x, int grid_y,
                                                         uint32_t* __restrict__ tile_count, uint64_t* __restrict__ keys,
                                                         uint32_t cap, int cull, uint32_t* __restrict__ big_count,
-                                                        uint32_t* __restrict__ big_queue, uint32_t big_cap) {
+                                                        uint32_t* __restrict__ big_queue, uint32_t big_cap,
+                                                        uint32_t* __restrict__ nonunit) {
     __shared__ uint32_t s_cell[4][GW_CELLS];   // per wave: instances per window cell; then the cell's first bucket slot
     __shared__ uint16_t s_ent[4][GW_LCAP];     // per wave and instance: cell | rank inside the cell << 8
     __shared__ uint64_t s_key[4][GW_LCAP];
@@ -303,6 +309,9 @@ __global__ void __launch_bounds__(256) k_scatter_window(int P, const int* __rest
     uint64_t* wkey = s_key[wave];
     const int idx = (blockIdx.x * 4 + (int)wave) * GW_SPW + (int)lane;
     SplatWalk me = load_splat_walk((int)lane < GW_SPW, idx, P, radii, rec, grid_x, grid_y);
+    // the operator API's device-side "unit colours" decision: any visible splat whose colour or all_map[3] is not exactly 1
+    // raises the word (benign race: every writer stores the same value)
+    if (nonunit && me.nonunit) *nonunit = 1u;
     if (me.nt > BIG_TILES) {
         const uint32_t q = atomicAdd(big_count, 1u);
         if (big_queue && q < big_cap) {
@@ -468,10 +477,10 @@ void launch_scan_tiles(hipStream_t s, int tiles, const uint32_t* tile_count, uin
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tiles, tile_count, ranges, total);
 }
 void launch_scatter(hipStream_t s, int P, const int* radii, const SplatRec* rec, int grid_x, int grid_y,
-                    const uint2* ranges, uint32_t* tile_cursor, uint64_t* keys, uint32_t cap, int cull) {
+                    const uint2* ranges, uint32_t* tile_cursor, uint64_t* keys, uint32_t cap, int cull, uint32_t* nonunit) {
     ProfScope p("scatter", s);
     hipLaunchKernelGGL(k_scatter<false>, dim3((P + 4 * SCATTER_SPW - 1) / (4 * SCATTER_SPW)), dim3(256), 0, s, P,
-                       radii, rec, grid_x, grid_y, ranges, tile_cursor, keys, cap, cull);
+                       radii, rec, grid_x, grid_y, ranges, tile_cursor, keys, cap, cull, nonunit);
 }
 void launch_tile_sort_small(hipStream_t s, int tiles, const uint2* ranges, uint64_t* keys, uint32_t* point_list,
                             uint32_t cap) {
@@ -497,10 +506,10 @@ void launch_tile_sort_big(hipStream_t s, int tiles, const uint2* ranges, uint64_
 // ranges / num_rendered / longest list / overflow flag from the sort kernel.
 void launch_scatter_bucket(hipStream_t s, int P, const int* radii, const SplatRec* rec, int grid_x, int grid_y,
                            uint32_t* tile_count, uint64_t* keys, uint32_t cap, int cull, uint32_t* big_count,
-                           uint32_t* big_queue, uint32_t big_cap) {
+                           uint32_t* big_queue, uint32_t big_cap, uint32_t* nonunit) {
     ProfScope p("scatter", s);
     hipLaunchKernelGGL(k_scatter_window, dim3((P + 4 * GW_SPW - 1) / (4 * GW_SPW)), dim3(256), 0, s, P, radii, rec, grid_x,
-                       grid_y, tile_count, keys, cap, cull, big_count, big_queue, big_cap);
+                       grid_y, tile_count, keys, cap, cull, big_count, big_queue, big_cap, nonunit);
     if (big_queue)
         hipLaunchKernelGGL(k_scatter_big, dim3(512), dim3(256), 0, s, big_count, big_queue, big_cap, radii, rec, grid_x,
                            grid_y, tile_count, keys, cap, cull);

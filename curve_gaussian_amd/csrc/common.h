@@ -31,6 +31,12 @@ constexpr int ACC_STRIDE = 16;
 constexpr int ACC_STRIDE_VIEW = 8;
 constexpr int ACC_COL = 6, ACC_INVD = 7, ACC_MAP = 8;
 
+// The forward compositors tag every tile-list entry they stage with the splat's quadrant mask (which of the tile's four 8x8
+// quadrants its alpha >= 1/255 ellipse reaches): bits 28..31; the splat index keeps bits 0..27.  The view entry points always
+// do (cgs_view_forward rejects P >= 2^28), the operator API whenever P < 2^28 (k_render_fwd3<.., TAG>).
+constexpr uint32_t LIST_TAG_SHIFT = 28u;
+constexpr uint32_t LIST_ID_MASK = (1u << LIST_TAG_SHIFT) - 1u;
+
 struct GeomState {            // carved from the geometry buffer
     SplatRec* rec;            // [P]
     float* grad_acc;          // [P][ACC_STRIDE]  zeroed and filled by the backward

@@ -6,11 +6,6 @@
 namespace cgs {
 
 constexpr float ALPHA_MIN = 1.0f / 255.0f;
-// The unit-colour forward of the view entry points tags every tile-list entry it stages with the splat's quadrant mask (which
-// of the tile's four 8x8 quadrants its alpha >= 1/255 ellipse reaches): bits 28..31; the splat index keeps bits 0..27
-// (cgs_view_forward rejects P >= 2^28).
-constexpr uint32_t LIST_TAG_SHIFT = 28u;
-constexpr uint32_t LIST_ID_MASK = (1u << LIST_TAG_SHIFT) - 1u;
 constexpr float L2_NEVER = -1000.f;   // log2 "opacity" of the padding entry: alpha = exp2(-1000) = 0
 
 struct TileGeom {

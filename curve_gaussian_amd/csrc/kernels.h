@@ -28,12 +28,13 @@ void launch_preprocess_bwd(hipStream_t s, int P, int D, int M, const float* mean
 void launch_scan_tiles(hipStream_t s, int tiles, const uint32_t* tile_count, uint2* ranges, uint32_t* total);
 // `cap` = number of instances the binning buffer can hold: tiles whose range does not fit are skipped (speculative launch)
 void launch_scatter(hipStream_t s, int P, const int* radii, const SplatRec* rec, int grid_x, int grid_y,
-                    const uint2* ranges, uint32_t* tile_cursor, uint64_t* keys, uint32_t cap, int cull);
+                    const uint2* ranges, uint32_t* tile_cursor, uint64_t* keys, uint32_t cap, int cull,
+                    uint32_t* nonunit = nullptr);   // nonunit: word raised when a visible splat's colour / all_map[3] is not 1
 // big_count: status word counting the splats whose rect exceeds the wave walk's comfort zone; big_queue (nullable,
 // big_cap entries): where they are deferred to for a one-workgroup-per-splat second kernel
 void launch_scatter_bucket(hipStream_t s, int P, const int* radii, const SplatRec* rec, int grid_x, int grid_y,
                            uint32_t* tile_count, uint64_t* keys, uint32_t cap, int cull, uint32_t* big_count,
-                           uint32_t* big_queue, uint32_t big_cap);
+                           uint32_t* big_queue, uint32_t big_cap, uint32_t* nonunit = nullptr);
 void launch_tile_sort_bucket(hipStream_t s, int tiles, const uint32_t* tile_count, uint2* ranges, uint32_t* total,
                              uint64_t* keys, uint32_t* point_list, uint32_t cap);
 uint32_t bucket_cap_limit();
@@ -46,13 +47,14 @@ void launch_tile_sort_big(hipStream_t s, int tiles, const uint2* ranges, uint64_
 void launch_render_fwd(hipStream_t s, bool geo, int tiles, const uint2* ranges, const uint32_t* point_list, int W,
                        int H, int grid_x, const SplatRec* rec, float* final_T, uint32_t* n_contrib,
                        const float* bg_color, float* out_color, float* out_invdepth, float* out_all_map,
-                       bool unit = false);   // unit: colour == 1 and all_map[3] == 1 for every splat (render.hip, UNIT)
+                       bool unit = false,    // unit: colour == 1 and all_map[3] == 1 for every splat (render.hip, UNIT)
+                       bool tag = false);    // tag: staged list entries get the quadrant masks in their top bits (TAG)
 bool render_fwd_can_sort(uint32_t cap);
 void launch_render_fwd_sorting(hipStream_t s, bool geo, int tiles, const uint32_t* tile_count, const uint64_t* keys,
                                uint32_t cap, uint2* ranges, uint32_t* total, uint32_t* point_list, int W, int H,
                                int grid_x, const SplatRec* rec, float* final_T, uint32_t* n_contrib,
                                const float* bg_color, float* out_color, float* out_invdepth, float* out_all_map,
-                               bool unit = false);
+                               bool unit = false, bool tag = false);
 // render_pipe.hip: the same sorting forward as a persistent kernel -- a producer wave sorts and stages tile t+1 while four
 // walker waves composite tile t; `work`: one zeroed u32 (the tile counter)
 bool render_fwd_pipe_ok(uint32_t cap);
@@ -65,13 +67,18 @@ void launch_render_bwd(hipStream_t s, bool geo, bool invd, bool colg, int tiles,
                        const SplatRec* rec, const float* final_Ts, const uint32_t* n_contrib, const float* dL_dpixels,
                        const float* dL_dout_invdepth, const float* dL_dout_all_map, float* grad_acc,
                        bool unit = false,    // unit: colour == 1 for every splat (render.hip, UNIT)
-                       int acc_stride = ACC_STRIDE);   // floats per accumulator record (ACC_STRIDE_VIEW on the view path)
+                       int acc_stride = ACC_STRIDE,    // floats per accumulator record (ACC_STRIDE_VIEW on the view path)
+                       uint32_t id_mask = 0xffffffffu,           // strips the forward's list tags (LIST_ID_MASK when it tagged)
+                       const uint32_t* nonunit_gate = nullptr);  // device word: the kernel returns at once when it is zero
 
 
 // render_unit_bwd.hip: the unit-colour training instance (colour == 1, only dL/dcolour flowing in), lane = (splat, quadrant)
+// acc_stride: ACC_STRIDE_VIEW (view path) or ACC_STRIDE (operator API); nonunit_gate: device word, the kernel returns at
+// once when it is NOT zero (the general training instance launched beside it takes over)
 void launch_render_bwd_unit(hipStream_t s, int tiles, const uint2* ranges, const uint32_t* point_list, int W, int H,
                             int grid_x, const float* bg_color, const SplatRec* rec, const float* final_Ts,
-                            const uint32_t* n_contrib, const float* dL_dpixels, float* grad_acc);
+                            const uint32_t* n_contrib, const float* dL_dpixels, float* grad_acc,
+                            int acc_stride = ACC_STRIDE_VIEW, const uint32_t* nonunit_gate = nullptr);
 
 // sampling.hip
 int sample_norm_words();

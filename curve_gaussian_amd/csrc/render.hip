@@ -90,7 +90,10 @@ constexpr uint32_t PAD_OFF = (BATCH + 1) * 16;   // byte offset of the padding e
 // UNIT: the caller guarantees colour == 1 and all_map[3] == 1 for every splat (the view entry point builds both itself:
 // unit features, gaussian_renderer/__init__.py:97,104).  Then sum w c = sum w = 1 - T (w_i = T_i - T_{i+1} telescopes), and
 // the two accumulators are not carried through the walk -- two of the six fmas per pair.
-template <bool GEO, bool SORT, bool UNIT = false>
+// TAG: every list entry this kernel stages is rewritten with the splat's quadrant mask in its top four bits (composite.h,
+// LIST_TAG_SHIFT) for a pair-major backward of the same forward; UNIT implies it.  The operator API sets it whenever P < 2^28
+// so that the device-side "unit colours" decision (api.hip) can hand the backward to k_render_bwd_unit.
+template <bool GEO, bool SORT, bool UNIT = false, bool TAG = UNIT>
 __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2* __restrict__ ranges,
                                                      const uint32_t* __restrict__ point_list, int W, int H, int grid_x,
                                                      const SplatRec* __restrict__ rec, float* __restrict__ final_T,
@@ -179,7 +182,7 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
                     if (GEO) s_c[GEO ? slot : 0] = UNIT ? make_float4(rc.x, rc.y, rc.z, sb.w) : rc;
                     const uint32_t qm = quadrant_mask(ra, rb, tau2, X0, Y0);
                     lost = atomicExch(&s_si[rk[0]], 0x100u | qm);
-                    bs.point_list[base + rk[0]] = UNIT ? (id | (qm << LIST_TAG_SHIFT)) : id;
+                    bs.point_list[base + rk[0]] = TAG ? (id | (qm << LIST_TAG_SHIFT)) : id;
                 }
             }
             prestaged = !__syncthreads_or((int)lost);
@@ -195,7 +198,7 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
                     // UNIT: the entries are written again, tagged with their quadrant masks, when their batch is staged; a
                     // batch that is never staged (every pixel terminated before it) keeps these untagged entries: valid
                     // indices with an empty mask for whoever reads the whole range
-                    if (!UNIT || rank[q] >= (uint32_t)BATCH) bs.point_list[base + rank[q]] = idx[q];
+                    if (!TAG || rank[q] >= (uint32_t)BATCH) bs.point_list[base + rank[q]] = idx[q];
                 }
             }
             __syncthreads();
@@ -242,7 +245,7 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
             // UNIT (view entry points): the list entry carries the quadrant mask in its top four bits for the backward of the
             // same view (LIST_ID_MASK / LIST_TAG_SHIFT, composite.h) -- its staging then needs no reach test.  Entries of
             // batches this workgroup never stages (every pixel terminated before) lie behind every pixel's cut.
-            if (UNIT) const_cast<uint32_t*>(SORT ? bs.point_list : point_list)[range.x + progress] = id | (qm << LIST_TAG_SHIFT);
+            if (TAG) const_cast<uint32_t*>(SORT ? bs.point_list : point_list)[range.x + progress] = id | (qm << LIST_TAG_SHIFT);
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -430,7 +433,10 @@ __global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG)
     const float* __restrict__ bg_color, const SplatRec* __restrict__ rec, const float* __restrict__ final_Ts,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
     const float* __restrict__ dL_dout_invdepth, const float* __restrict__ dL_dout_all_map,
-    float* __restrict__ grad_acc, int acc_stride) {
+    float* __restrict__ grad_acc, int acc_stride, uint32_t id_mask, const uint32_t* __restrict__ nonunit_gate) {
+    // nonunit_gate (operator API, training instance): the forward's device-side verdict on the colours; zero = every visible
+    // splat has unit colour and all_map[3] == 1, and k_render_bwd_unit -- launched beside this kernel -- does the work
+    if (nonunit_gate && *nonunit_gate == 0u) return;
     constexpr bool EXTRA = COLG || INVD || GEO;   // sums beyond the six geometric ones
     constexpr int NF = GEO ? 12 : EXTRA ? 8 : 6;  // fields of the packed per-splat accumulator record that can be non-zero
     constexpr int BB = BWD_BATCH, NC = BB / 64;
@@ -517,7 +523,7 @@ __global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG)
         const int progress = i * BB + threadIdx.x;
         uint32_t qm = 0;
         if (threadIdx.x < BB && progress < total) {
-            const uint32_t id = point_list[range.y - progress - 1] & (UNIT ? LIST_ID_MASK : 0xffffffffu);  // back to front (backward.cu:554)
+            const uint32_t id = point_list[range.y - progress - 1] & id_mask;  // back to front (backward.cu:554); id_mask strips the forward's tags
             const SplatRec* r = rec + id;
             const float4 a = r->a, b = r->b;
             float4 sa, sb;
@@ -752,47 +758,53 @@ __global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG)
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
-#define CGS_FWD3(G, S, U, R, PL, BS)                                                                                  \
-    hipLaunchKernelGGL((k_render_fwd3<G, S, U>), dim3(tiles), dim3(256), 0, s, R, PL, W, H, grid_x, rec, final_T,     \
+#define CGS_FWD3(G, S, U, T, R, PL, BS)                                                                               \
+    hipLaunchKernelGGL((k_render_fwd3<G, S, U, T>), dim3(tiles), dim3(256), 0, s, R, PL, W, H, grid_x, rec, final_T,  \
                        n_contrib, bg_color, out_color, out_invdepth, out_all_map, BS)
 void launch_render_fwd(hipStream_t s, bool geo, int tiles, const uint2* ranges, const uint32_t* point_list, int W,
                        int H, int grid_x, const SplatRec* rec, float* final_T, uint32_t* n_contrib,
-                       const float* bg_color, float* out_color, float* out_invdepth, float* out_all_map, bool unit) {
+                       const float* bg_color, float* out_color, float* out_invdepth, float* out_all_map, bool unit, bool tag) {
     ProfScope p("render_fwd", s);
-    if (geo && unit) CGS_FWD3(true, false, true, ranges, point_list, BucketSort{});
-    else if (unit) CGS_FWD3(false, false, true, ranges, point_list, BucketSort{});
-    else if (geo) CGS_FWD3(true, false, false, ranges, point_list, BucketSort{});
-    else CGS_FWD3(false, false, false, ranges, point_list, BucketSort{});
+    if (geo && unit) CGS_FWD3(true, false, true, true, ranges, point_list, BucketSort{});
+    else if (unit) CGS_FWD3(false, false, true, true, ranges, point_list, BucketSort{});
+    else if (geo && tag) CGS_FWD3(true, false, false, true, ranges, point_list, BucketSort{});
+    else if (tag) CGS_FWD3(false, false, false, true, ranges, point_list, BucketSort{});
+    else if (geo) CGS_FWD3(true, false, false, false, ranges, point_list, BucketSort{});
+    else CGS_FWD3(false, false, false, false, ranges, point_list, BucketSort{});
 }
 bool render_fwd_can_sort(uint32_t cap) { return cap <= RANK_MAX; }
 void launch_render_fwd_sorting(hipStream_t s, bool geo, int tiles, const uint32_t* tile_count, const uint64_t* keys,
                                uint32_t cap, uint2* ranges, uint32_t* total, uint32_t* point_list, int W, int H,
                                int grid_x, const SplatRec* rec, float* final_T, uint32_t* n_contrib,
-                               const float* bg_color, float* out_color, float* out_invdepth, float* out_all_map, bool unit) {
+                               const float* bg_color, float* out_color, float* out_invdepth, float* out_all_map, bool unit,
+                               bool tag) {
     ProfScope p("render_fwd", s);
     const BucketSort bs{tile_count, keys, point_list, ranges, total, cap};
     const uint2* no_ranges = nullptr;
     const uint32_t* no_list = nullptr;
-    if (geo && unit) CGS_FWD3(true, true, true, no_ranges, no_list, bs);
-    else if (unit) CGS_FWD3(false, true, true, no_ranges, no_list, bs);
-    else if (geo) CGS_FWD3(true, true, false, no_ranges, no_list, bs);
-    else CGS_FWD3(false, true, false, no_ranges, no_list, bs);
+    if (geo && unit) CGS_FWD3(true, true, true, true, no_ranges, no_list, bs);
+    else if (unit) CGS_FWD3(false, true, true, true, no_ranges, no_list, bs);
+    else if (geo && tag) CGS_FWD3(true, true, false, true, no_ranges, no_list, bs);
+    else if (tag) CGS_FWD3(false, true, false, true, no_ranges, no_list, bs);
+    else if (geo) CGS_FWD3(true, true, false, false, no_ranges, no_list, bs);
+    else CGS_FWD3(false, true, false, false, no_ranges, no_list, bs);
 }
 #undef CGS_FWD3
 void launch_render_bwd(hipStream_t s, bool geo, bool invd, bool colg, int tiles, const uint2* ranges,
                        const uint32_t* point_list, int W, int H, int grid_x, const float* bg_color,
                        const SplatRec* rec, const float* final_Ts, const uint32_t* n_contrib, const float* dL_dpixels,
                        const float* dL_dout_invdepth, const float* dL_dout_all_map, float* grad_acc, bool unit,
-                       int acc_stride) {
+                       int acc_stride, uint32_t id_mask, const uint32_t* nonunit_gate) {
     ProfScope p("render_bwd", s);
     if (unit && !geo && !invd && !colg) {
         hipLaunchKernelGGL((k_render_bwd3<false, false, false, true>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H,
-                           grid_x, bg_color, rec, final_Ts, n_contrib, dL_dpixels, dL_dout_invdepth, dL_dout_all_map, grad_acc, acc_stride);
+                           grid_x, bg_color, rec, final_Ts, n_contrib, dL_dpixels, dL_dout_invdepth, dL_dout_all_map, grad_acc, acc_stride,
+                           LIST_ID_MASK, nullptr);
         return;
     }
 #define CGS_BWD(G, I, C)                                                                                         \
     hipLaunchKernelGGL((k_render_bwd3<G, I, C>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H, grid_x, \
-                       bg_color, rec, final_Ts, n_contrib, dL_dpixels, dL_dout_invdepth, dL_dout_all_map, grad_acc, acc_stride)
+                       bg_color, rec, final_Ts, n_contrib, dL_dpixels, dL_dout_invdepth, dL_dout_all_map, grad_acc, acc_stride, id_mask, nonunit_gate)
     if (geo && invd) CGS_BWD(true, true, true);        // full-gradient configuration
     else if (geo) CGS_BWD(true, false, true);
     else if (invd) CGS_BWD(false, true, true);

@@ -168,10 +168,16 @@ __device__ __forceinline__ void ub_walk_row(const f32x16& nP, int r0, const floa
     R2 = (w + w) - u;
 }
 
+// STRIDE: floats per accumulator record -- ACC_STRIDE_VIEW on the view path (32-byte records), ACC_STRIDE behind the operator
+// API (the 64-byte records k_preprocess_bwd reads).  GATED (operator API): the forward's device-side verdict on the colours
+// decides at run time between this kernel and the general training instance launched beside it.
+template <int STRIDE, bool GATED>
 __global__ void __launch_bounds__(256, CGS_UBWD_WAVES) k_render_bwd_unit(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int grid_x,
     const float* __restrict__ bg_color, const SplatRec* __restrict__ rec, const float* __restrict__ final_Ts,
-    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels, float* __restrict__ grad_acc) {
+    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels, float* __restrict__ grad_acc,
+    const uint32_t* __restrict__ nonunit_gate) {
+    if (GATED && *nonunit_gate != 0u) return;   // some visible splat has a colour or all_map[3] other than 1
     __shared__ float4 s_geo[UB + 1];     // {cx, cy, A2, B2}; entry UB: padding (never blended)
     __shared__ float4 s_at[UB + 1];      // {C2, log2 opacity, splat id bits, -}
     __shared__ uint16_t s_list[UB * 4 + CH];
@@ -378,7 +384,7 @@ __global__ void __launch_bounds__(256, CGS_UBWD_WAVES) k_render_bwd_unit(
                 if (e < n_lead && f < 6) {
                     const float v = outw[e * 8 + f];
                     const uint32_t id = __float_as_uint(outw[e * 8 + 6]);
-                    if (v != 0.f) atomicAdd(grad_acc + (size_t)id * ACC_STRIDE_VIEW + f, v);
+                    if (v != 0.f) atomicAdd(grad_acc + (size_t)id * STRIDE + f, v);
                 }
             }
             wave_lds_fence();   // the array is rewritten by the next chunk
@@ -388,10 +394,17 @@ __global__ void __launch_bounds__(256, CGS_UBWD_WAVES) k_render_bwd_unit(
 
 void launch_render_bwd_unit(hipStream_t s, int tiles, const uint2* ranges, const uint32_t* point_list, int W, int H,
                             int grid_x, const float* bg_color, const SplatRec* rec, const float* final_Ts,
-                            const uint32_t* n_contrib, const float* dL_dpixels, float* grad_acc) {
-    ProfScope p("render_bwd", s);
-    hipLaunchKernelGGL(k_render_bwd_unit, dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H, grid_x, bg_color, rec,
-                       final_Ts, n_contrib, dL_dpixels, grad_acc);
+                            const uint32_t* n_contrib, const float* dL_dpixels, float* grad_acc, int acc_stride,
+                            const uint32_t* nonunit_gate) {
+    ProfScope p(nonunit_gate ? "render_bwd_unit_gated" : "render_bwd", s);
+    if (acc_stride == ACC_STRIDE_VIEW && !nonunit_gate)
+        hipLaunchKernelGGL((k_render_bwd_unit<ACC_STRIDE_VIEW, false>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H,
+                           grid_x, bg_color, rec, final_Ts, n_contrib, dL_dpixels, grad_acc, nullptr);
+    else if (acc_stride == ACC_STRIDE && nonunit_gate)
+        hipLaunchKernelGGL((k_render_bwd_unit<ACC_STRIDE, true>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H, grid_x,
+                           bg_color, rec, final_Ts, n_contrib, dL_dpixels, grad_acc, nonunit_gate);
+    else
+        set_error("launch_render_bwd_unit: unsupported (stride %d, gate %p) combination", acc_stride, (const void*)nonunit_gate);
 }
 
 }  // namespace cgs

@@ -67,7 +67,9 @@ __device__ __forceinline__ SplatRec splat_record(const SplatGeom& g, float opaci
     r.b = make_float4(g.conic.z, op_eff, color, 1.f / g.depth);
     r.c = all_map;
     // tau2 = 2 ln(255 * opacity): alpha >= 1/255  <=>  conic quadratic form <= tau2 (used by the quadrant culling)
-    r.d = make_float4(g.depth, g.radius, 2.f * logf(255.f * op_eff), 0.f);
+    // d.w: 1 when the splat's colour or all_map[3] is not exactly 1 -- the bucket scatter ORs it into the image buffer's
+    // "non-unit" word, which decides on the device whether the unit-colour backward may run (api.hip, cgs_rasterize_backward)
+    r.d = make_float4(g.depth, g.radius, 2.f * logf(255.f * op_eff), (color != 1.f || all_map.w != 1.f) ? 1.f : 0.f);
     return r;
 }
 

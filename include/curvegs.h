@@ -367,6 +367,12 @@ int cgs_set_tile_culling(int on);
  *     k_render_bwd3<UNIT>.  Same results to rounding.  Any other value only queries. */
 int cgs_set_fused_tile_sort(int on);
 int cgs_set_unit_backward(int variant);
+/*   cgs_set_operator_unit_route: 1 (default) = a cgs_rasterize_backward that is asked for neither colour nor depth / all_map
+ *     gradients (the training configuration of the reference's own call, gaussian_renderer/__init__.py:96-129) lets the GPU choose
+ *     between the pair-major unit-colour compositor and the general one: the forward's scatter raises a word of the image buffer
+ *     when some visible splat's colour or all_map[3] is not exactly 1, and both kernels test it on entry (no host sync; the
+ *     forward tags its tile-list entries with quadrant masks whenever P < 2^28).  0 = always the general instance. */
+int cgs_set_operator_unit_route(int on);
 /*   cgs_set_forward_pipeline: 1 = the fused sort + composite forward runs as the persistent prefetcher / walker kernel
  *     (csrc/render_pipe.hip: one wave brings tile t+1 into LDS while four composite tile t); 0 (default) = one workgroup per
  *     tile (k_render_fwd3<.., SORT>).  Bit-identical results.  CGS_FWD_PIPE=1 in the environment sets the initial value. */

@@ -922,11 +922,12 @@ def test_graphed_train_step_view_parallel_mode_single_rank_group():
             dist.destroy_process_group()
 
 
-def test_bench_two_rank_control_flow_rehearsal():
-    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank), as a
-    rehearsal on ONE GPU: both ranks on device 0, collectives through gloo (CGS_BENCH_REHEARSAL).  Guards the control
-    flow of the multi-rank path -- every rank reaches every collective, rank 0 finishes its rank-0-only sections
-    without one, exactly one JSON line comes out -- not its performance."""
+@pytest.mark.parametrize("launcher", ["torchrun", "self"])
+def test_bench_two_rank_control_flow_rehearsal(launcher):
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank) and the way
+    a plain `python bench.py --gpus 2` launches ITSELF, as a rehearsal on ONE GPU: both ranks on device 0, collectives through
+    gloo (CGS_BENCH_REHEARSAL).  Guards the control flow of the multi-rank path -- every rank reaches every collective, rank
+    0 finishes its rank-0-only sections without one, exactly one JSON line comes out -- not its performance."""
     import json
     import socket
     import subprocess
@@ -936,9 +937,15 @@ def test_bench_two_rank_control_flow_rehearsal():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, CGS_BENCH_REHEARSAL="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "8",
-           "--warmup", "2", "--config", "cfg1", "--no-cpu-baseline", "--train-step-multi"]
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--config", "cfg1",
+            "--no-cpu-baseline", "--train-step-multi"]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port)] + tail
+    else:
+        cmd = [sys.executable] + tail
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -953,6 +960,49 @@ def test_bench_two_rank_control_flow_rehearsal():
     es = out["expected_scaling"]
     assert es["all_reduce_bytes"] == 38 * 4 * out["config"]["curves"] and es["overlapped_with_next_step"] is True
     assert es["min_efficiency_vs_1gpu"] == 0.97 and es["reference_predictions"]["cfg5"]["step_ms"] == 5.6
+
+
+def _bench_cmd(*flags):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                             "CGS_BENCH_REHEARSAL", "CGS_BENCH_FORCE_DIST")}
+    return [sys.executable, os.path.join(root, "bench.py")] + list(flags), root, env
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` on a node with fewer than N GPUs must exit non-zero with a message -- not print a 1-rank line
+    that a scaling table would mistake for an N-GPU measurement."""
+    import subprocess
+    n = torch.cuda.device_count()
+    cmd, root, env = _bench_cmd("--gpus", str(n + 1), "--steps", "2", "--warmup", "1", "--config", "cfg1", "--no-cpu-baseline")
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert f"--gpus {n + 1}" in r.stderr and "visible" in r.stderr, r.stderr[-1000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    # ... and a launcher / flag disagreement is an error too (WORLD_SIZE says 1 rank, --gpus says the whole node)
+    if n >= 2:
+        env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+        r = subprocess.run(cmd[:2] + ["--gpus", str(n)] + cmd[4:], cwd=root, env=env2, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "must agree" in r.stderr
+
+
+def test_bench_two_rank_rccl_self_launch():
+    """The real thing on a box with >= 2 GPUs: `python bench.py --gpus 2` starts two ranks itself, the step's all-reduce runs
+    over RCCL, and the line says so."""
+    import json
+    import subprocess
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs (one rank per GPU; RCCL refuses two ranks on one device)")
+    cmd, root, env = _bench_cmd("--gpus", "2", "--steps", "4", "--warmup", "1", "--min-seconds", "0.5", "--config", "cfg1",
+                                "--no-cpu-baseline", "--train-step-multi")
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["value"] > 0
+    assert out["train_step_view_parallel_ms"] > 0
 
 
 def test_captured_collectives_need_an_explicit_opt_in_beyond_one_rank(monkeypatch):

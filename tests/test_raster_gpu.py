@@ -135,6 +135,93 @@ def test_training_configuration_only_colour_grad():
     np.testing.assert_allclose(hip["color"][0], hip["all_map"][3], rtol=0, atol=1e-6)
 
 
+@pytest.fixture
+def general_backward_only():
+    from curve_gaussian_amd import _lib
+    prev = _lib.load().cgs_set_operator_unit_route(0)
+    yield
+    _lib.load().cgs_set_operator_unit_route(prev)
+
+
+def _reference_call_splats(P, seed, H, W):
+    """What the reference's render() hands the rasterizer (gaussian_renderer/__init__.py:96-104): all-ones colours that need
+    no gradient and all_map = [axis, 1]."""
+    sp = S.random_splats(P, seed, scale_range=(0.004, 0.05))
+    sp["colors"] = torch.ones_like(sp["colors"])
+    assert bool((sp["all_map"][:, 3] == 1).all())
+    return sp
+
+
+@pytest.mark.parametrize("P,H,W,seed,cam_i", [(2500, 96, 144, 21, 0), (20000, 208, 304, 23, 1), (3000, 77, 130, 24, 2)])
+@pytest.mark.parametrize("bg0", [0.0, 0.3])
+def test_operator_api_reaches_the_unit_backward_on_the_reference_call(P, H, W, seed, cam_i, bg0):
+    """GaussianRasterizer called the way the reference calls it -- unit colours without a gradient, all_map[:, 3] == 1, only
+    `render` in the loss -- runs the pair-major unit-colour backward (chosen on the DEVICE from the forward's colour verdict)
+    and meets the raster criterion against the oracle; the general instance on the same inputs agrees with it."""
+    sp = _reference_call_splats(P, seed, H, W)
+    cam = S.make_camera(*CAMS[cam_i], H, W)
+    bg = torch.tensor([bg0, 0.0, 0.0])
+    grads = rand_grads(H, W, seed + 5, (True, False, False))
+    hip = compare(sp, cam, bg, grads, colour_grad=False, debug=False)
+    from curve_gaussian_amd import _lib
+    prev = _lib.load().cgs_set_operator_unit_route(0)
+    try:
+        gen = run_hip(sp, cam, bg, grads, colour_grad=False, debug=False)
+    finally:
+        _lib.load().cgs_set_operator_unit_route(prev)
+    for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dscales", "dL_drotations"):
+        assert_close("unit vs general " + k, hip["g"][k], gen["g"][k], abs_floor=1e-6)
+    assert np.abs(hip["g"]["dL_dall_map"]).max() == 0.0
+
+
+def test_unit_verdict_word_follows_the_visible_splats():
+    """The word the backward kernels test: 0 for unit colours, raised by ONE visible non-unit splat (colour or all_map[3]),
+    NOT raised by a non-unit splat that is culled -- in both binning layouts."""
+    dev = torch.device(DEV)
+    H, W, P = 96, 144, 2500
+    cam = S.make_camera(*CAMS[0], H, W)
+    base = _reference_call_splats(P, 21, H, W)
+    fw = oracle_forward(base, cam, torch.zeros(3))
+    vis = np.nonzero(fw.radii > 0)[0]
+    fw.free()
+    behind = dict(base)
+    behind["means3D"] = base["means3D"].clone()
+    behind["means3D"][7] = torch.tensor([0.5, -6.0, 0.7])   # behind the camera: culled
+    behind["colors"] = base["colors"].clone()
+    behind["colors"][7] = 0.25
+    col = dict(base)
+    col["colors"] = base["colors"].clone()
+    col["colors"][int(vis[3])] = 0.999
+    am = dict(base)
+    am["all_map"] = base["all_map"].clone()
+    am["all_map"][int(vis[5]), 3] = 0.5
+    for name, sp, want in (("unit", base, 0), ("culled non-unit", behind, 0), ("colour", col, 1), ("all_map[3]", am, 1)):
+        out = _raster_raw(sp, cam, H, W, dev, reset_hints=True)       # exact layout
+        assert _forward_stats()[2] == 0
+        assert _nonunit_word(out[5], H, W) == want, (name, "exact layout")
+        out = _raster_raw(sp, cam, H, W, dev)                         # bucket layout
+        assert _forward_stats()[2] == 1
+        assert _nonunit_word(out[5], H, W) == want, (name, "bucket layout")
+
+
+@pytest.mark.parametrize("which", ["colour", "all_map"])
+def test_one_non_unit_splat_sends_the_backward_to_the_general_instance(which):
+    """A single visible splat with colour 3 (or all_map[3] = 0.2) in an otherwise unit cloud: the closed form of the unit kernel
+    would be wrong for every pixel it touches -- the device-side gate must pick the general instance."""
+    H, W, P = 96, 144, 2500
+    cam = S.make_camera(*CAMS[0], H, W)
+    sp = _reference_call_splats(P, 21, H, W)
+    fw = oracle_forward(sp, cam, torch.zeros(3))
+    # the visible splat with the largest footprint
+    i = int(np.argmax(np.where(fw.radii > 0, fw.radii, 0)))
+    fw.free()
+    if which == "colour":
+        sp["colors"][i] = 3.0
+    else:
+        sp["all_map"][i, 3] = 0.2
+    compare(sp, cam, torch.tensor([0.2, 0.0, 0.0]), rand_grads(H, W, 9, (True, False, False)), colour_grad=False, debug=False)
+
+
 def test_no_geo_and_antialiasing():
     H, W = 80, 112
     sp = S.random_splats(1500, 31)
@@ -197,8 +284,16 @@ def _decode_state(geomBuffer, binningBuffer, imgBuffer, P, H, W, R):
     # fixed-capacity bucket per tile in the single-pass layout)
     n_entries = max(int(ranges[:, 1].max()) if len(ranges) else 0, R)
     ob = carve_offsets(binningBuffer.data_ptr(), [(max(n_entries, 1), 4)])
-    point_list = bb[ob[0]:ob[0] + n_entries * 4].view(np.uint32)
+    # (entries the forward staged carry the splat's quadrant mask in bits 28..31 -- csrc/common.h, LIST_TAG_SHIFT)
+    point_list = bb[ob[0]:ob[0] + n_entries * 4].view(np.uint32) & np.uint32(0x0FFFFFFF)
     return ranges, point_list, n_contrib, final_T
+
+
+def _nonunit_word(imgBuffer, H, W):
+    """The forward's device-side verdict on the colours (ImageState::work[8], csrc/api.hip NONUNIT_WORD)."""
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    o = carve_offsets(imgBuffer.data_ptr(), [(H * W, 4), (H * W, 4), (tiles, 8), (tiles, 4), (tiles, 4), (2048, 4)])
+    return int(imgBuffer[o[5] + 32:o[5] + 36].cpu().numpy().view(np.uint32)[0])
 
 
 def _forward_stats():
@@ -352,6 +447,53 @@ def test_binning_bit_exact(case, no_tile_culling):
         assert mism <= 2e-3, mism
     assert_close("color", color.cpu().numpy(), fw.color)
     fw.free()
+
+
+GOLDEN = ["small", "ties", "opaque", "room"]
+
+
+def _golden(name):
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_raster_golden import load_scene
+    return load_scene(name)
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_hip_path_matches_the_frozen_raster_fixtures(name):
+    """The HIP rasterizer against tests/golden/raster_*.npz -- the oracle's outputs FROZEN in the repository (the oracle itself
+    is not called here): forward images and radii, all nine gradients with every upstream gradient flowing, and the training
+    configuration.  The CPU suite holds today's oracle build to the same files, so oracle and kernels cannot drift together."""
+    sp, cam, bg, z = _golden(name)
+    t = lambda k: torch.from_numpy(z[k].copy())
+    hip = run_hip(sp, cam, bg, (t("dL_dcolor"), t("dL_dinvdepth"), t("dL_dout_all_map")), debug=False)
+    assert_radii(hip["radii"], z["radii"])
+    assert_close("color", hip["color"], z["color"])
+    assert_close("invdepth", hip["invdepth"], z["invdepth"])
+    assert_close("all_map", hip["all_map"], z["out_all_map"])
+    for k, v in hip["g"].items():
+        assert_close(k, v, z["g_" + k], abs_floor=1e-6)
+    tr = run_hip(sp, cam, bg, (t("dL_dcolor"), None, None), debug=False, colour_grad=False)
+    for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dscales", "dL_drotations"):
+        assert_close("training " + k, tr["g"][k], z["gt_" + k], abs_floor=1e-6)
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_binning_matches_the_frozen_tile_lists(name, no_tile_culling):
+    """Integer work against the file, tile culling off (= the reference's binning; the exact layout, first and repeated
+    forward): num_rendered, tile ranges and the per-tile order are bit-exact."""
+    dev = torch.device(DEV)
+    sp, cam, bg, z = _golden(name)
+    H, W, P = cam.image_height, cam.image_width, sp["means3D"].shape[0]
+    lens_ref = (z["ranges"][:, 1] - z["ranges"][:, 0]).astype(np.int64)
+    for it in range(2):
+        (R, color, radii, geomB, binB, imgB, invd, amap) = _raster_raw(sp, cam, H, W, dev, reset_hints=(it == 0))
+        assert R == int(z["num_rendered"][0])
+        ranges, point_list, n_contrib, final_T = _decode_state(geomB, binB, imgB, P, H, W, R)
+        assert ((ranges[:, 1] - ranges[:, 0]) == lens_ref).all()
+        for k in range(len(lens_ref)):
+            assert (point_list[ranges[k, 0]:ranges[k, 1]] == z["point_list"][z["ranges"][k, 0]:z["ranges"][k, 1]]).all(), (name, k)
 
 
 def test_bucket_overflow_falls_back_to_exact_layout():
