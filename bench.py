@@ -126,8 +126,6 @@ def main():
                          "step's view batch per rank)")
     ap.add_argument("--fused-sort", type=int, default=-1, choices=[-1, 0, 1],
                     help="A/B: tile sort inside the forward compositor (cgs_set_fused_tile_sort); -1 = library default")
-    ap.add_argument("--unit-backward", type=int, default=0, choices=[0, 3, 4],
-                    help="A/B: backward compositor of the unit-colour view path (cgs_set_unit_backward); 0 = library default")
     args = ap.parse_args()
 
     # Control-flow rehearsal of the multi-rank path on a box with ONE GPU (tests only): every rank uses device 0 and the
@@ -170,8 +168,6 @@ def main():
     from curve_gaussian_amd.diff_cur_rasterization import _C
     from curve_gaussian_amd.ops import curve_sampling
     lib = L.load()
-    if args.unit_backward:
-        lib.cgs_set_unit_backward(args.unit_backward)
     if args.fused_sort >= 0:
         lib.cgs_set_fused_tile_sort(args.fused_sort)
 
@@ -282,9 +278,10 @@ def main():
         isb_u8 = curve_sampling._bezier_mask(isb, dev)
         pt, cf = L.ptr, C.c_float
 
-        def body(cam):
+        def body(cam, shared=False):   # shared: the view-batch mode (cgs_view_forward_shared / CGS_VIEW_SHARED), per call
             st = L.raw_stream(dev)
-            L.check(lib.cgs_view_forward(B, m, pt(cp0), pt(w0), pt(isb_u8), pt(d["coef"]), cf(1e-8), pt(d["norms"]), pt(op0), None,
+            fwd = lib.cgs_view_forward_shared if shared else lib.cgs_view_forward
+            L.check(fwd(B, m, pt(cp0), pt(w0), pt(isb_u8), pt(d["coef"]), cf(1e-8), pt(d["norms"]), pt(op0), None,
                                          cf(0.01), None, pt(d["geom"]), pt(d["bin"]), d["nbin"], pt(d["img"]), cap, pt(bg), W, H,
                                          pt(cam.world_view_transform), pt(cam.full_proj_transform), pt(cam.camera_center),
                                          tanx, tany, pt(d["color"]), pt(d["invd"]), pt(d["omap"]), pt(d["radii"]), None, None,
@@ -293,7 +290,7 @@ def main():
                                           cf(0.01), None, pt(d["geom"]), pt(d["bin"]), pt(d["img"]), pt(bg), W, H,
                                           pt(cam.world_view_transform), pt(cam.full_proj_transform), pt(cam.camera_center),
                                           tanx, tany, pt(d["radii"]), pt(dL_dcolor), None, pt(d["g_m2d"]), pt(g_cp), pt(g_w),
-                                          pt(g_op), None, pt(d["scratch"]), 1, st), "cgs_view_backward")
+                                          pt(g_op), None, pt(d["scratch"]), 3 if shared else 1, st), "cgs_view_backward")
         return body, d
 
     # One optimizer step's view batch per rank: `views_per_step` independent views, up to `streams` of them in flight,
@@ -599,7 +596,7 @@ def main():
     else:
         R_mean = vis_mean = 0.0
 
-    # ---- the same per-view body when the curve sampling is SHARED by the views of a step (cgs_set_view_shared_sampling):
+    # ---- the same per-view body when the curve sampling is SHARED by the views of a step (cgs_view_forward_shared):
     # the parameters are constant inside a step, so the norm pass of the forward and the last pass of the sampling backward
     # can run once per step.  Reported separately -- NOT `value`: the reference's iteration is one view per parameter state.
     shared = None
@@ -612,20 +609,16 @@ def main():
         cams_s = my_cams[:Gs]
 
         def step_shared(flat, on):
-            prev = lib.cgs_set_view_shared_sampling(1 if on else 0)
-            try:
-                st = L.raw_stream(dev)
-                if on:
-                    L.check(lib.cgs_view_shared_begin(B, m, L.ptr(cp0), L.ptr(isb_u8), L.ptr(d_s["coef"]), L.ptr(d_s["norms"]),
-                                                      L.ptr(d_s["scratch"]), st), "cgs_view_shared_begin")
-                for c in cams_s:
-                    body_s(c)
-                if on:
-                    L.check(lib.cgs_view_shared_end(B, m, L.ptr(cp0), L.ptr(w0), L.ptr(isb_u8), L.ptr(d_s["coef"]), C.c_float(1e-8),
-                                                    L.ptr(d_s["norms"]), L.ptr(d_s["scratch"]), L.ptr(flat[0:12 * B]),
-                                                    L.ptr(flat[12 * B:13 * B]), 1, st), "cgs_view_shared_end")
-            finally:
-                lib.cgs_set_view_shared_sampling(prev)
+            st = L.raw_stream(dev)
+            if on:
+                L.check(lib.cgs_view_shared_begin(B, m, L.ptr(cp0), L.ptr(isb_u8), L.ptr(d_s["coef"]), L.ptr(d_s["norms"]),
+                                                  L.ptr(d_s["scratch"]), st), "cgs_view_shared_begin")
+            for c in cams_s:
+                body_s(c, on)
+            if on:
+                L.check(lib.cgs_view_shared_end(B, m, L.ptr(cp0), L.ptr(w0), L.ptr(isb_u8), L.ptr(d_s["coef"]), C.c_float(1e-8),
+                                                L.ptr(d_s["norms"]), L.ptr(d_s["scratch"]), L.ptr(flat[0:12 * B]),
+                                                L.ptr(flat[12 * B:13 * B]), 1, st), "cgs_view_shared_end")
         flat_a.zero_(); step_shared(flat_a, False); torch.cuda.synchronize(); ref_s = flat_a.clone()
         flat_a.zero_(); step_shared(flat_a, True); torch.cuda.synchronize()
         rel_s = float((flat_a - ref_s).norm() / ref_s.norm().clamp_min(1e-30))

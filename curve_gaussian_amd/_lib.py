@@ -29,12 +29,14 @@ SIGNATURES = {
                                         C.c_uint32, _vp, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cgs_view_forward_begin": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _vp, _vp, C.c_size_t, _vp,
                                     C.c_uint32, _vp, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "cgs_view_forward_wait": (_i64, []),
+    "cgs_view_forward_shared": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _vp, _vp, C.c_size_t, _vp,
+                                     C.c_uint32, _vp, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cgs_view_forward_wait": (_i64, [_i, C.POINTER(_i64)]),
+    "cgs_view_forward_abandon": (None, [_i]),
     "cgs_render_epilogue": (_i, [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "cgs_clamp_backward": (_i, [_i64, _vp, _vp, _vp, _vp]),
     "cgs_bucket_capacity_hint": (C.c_uint32, [_i, _i, _i]),
     "cgs_last_forward_visible": (_i64, []),
-    "cgs_set_view_shared_sampling": (_i, [_i]),
     "cgs_view_shared_begin": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cgs_view_shared_end": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _vp]),
     "cgs_view_backward_scratch_floats": (C.c_size_t, [_i, _i]),
@@ -47,8 +49,6 @@ SIGNATURES = {
     "cgs_adam_state_bytes": (C.c_size_t, []),
     "cgs_set_tile_culling": (_i, [_i]),
     "cgs_set_fused_tile_sort": (_i, [_i]),
-    "cgs_set_forward_pipeline": (_i, [_i]),
-    "cgs_set_unit_backward": (_i, [_i]),
     "cgs_set_operator_unit_route": (_i, [_i]),
     "cgs_reset_binning_hints": (None, []),
     "cgs_last_forward_stats": (None, [C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i)]),
@@ -107,6 +107,32 @@ def load() -> C.CDLL:
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+_shim = None
+SHIM_PATH = os.path.join(_HERE, "_cgs_torch.so")
+
+
+def use_shim() -> bool:
+    """The compiled torch <-> C-ABI host shim (csrc/torch_shim.cpp) is the default binding of the operator API and of the fused
+    view route; CGS_TORCH_SHIM=0 selects the ctypes bindings instead (A/B measurements of the host floor).  Same library, same
+    kernels either way."""
+    return os.environ.get("CGS_TORCH_SHIM", "1") != "0"
+
+
+def shim():
+    """import curve_gaussian_amd._cgs_torch (built by `make -C curve_gaussian_amd/csrc`).  Raises if it has not been built."""
+    global _shim
+    if _shim is not None:
+        return _shim
+    load()   # libcurvegs.so first, through the path CGS_LIB may override: the shim binds to that same library instance
+    if not os.path.exists(SHIM_PATH):
+        raise CurveGSError(
+            f"{SHIM_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C curve_gaussian_amd/csrc`); CGS_TORCH_SHIM=0 selects the ctypes bindings.")
+    import importlib
+    _shim = importlib.import_module("curve_gaussian_amd._cgs_torch")
+    return _shim
 
 
 def last_error() -> str:

@@ -152,18 +152,14 @@ static hipError_t zero_async(void* p, size_t bytes, hipStream_t s) {
 static std::atomic<int> g_op_unit{1};
 static inline bool list_tags_fit(int P) { return (long long)P < (1ll << LIST_TAG_SHIFT); }
 constexpr int NONUNIT_WORD = 8;            // index into ImageState::work (cleared with the tile histogram)
-static std::atomic<int> g_unit_bwd{4};     // backward compositor of the unit-colour view path: 4 = pair-major (render_unit_bwd.hip), 3 = pixel-major k_render_bwd3<UNIT>
 static std::atomic<int> g_fuse_sort{1};    // tile sort inside the forward compositor (cgs_set_fused_tile_sort)
 static inline bool fuse_sort() { return g_fuse_sort.load(std::memory_order_relaxed) != 0; }
-// the fused sort + composite as the persistent producer / walker kernel of render_pipe.hip (cgs_set_forward_pipeline;
-// CGS_FWD_PIPE=1 in the environment selects it for A/B runs; off by default: measured slower, profiles/r04_experiments.md)
-static std::atomic<int> g_fwd_pipe{[] { const char* e = getenv("CGS_FWD_PIPE"); return (e && e[0] == '1') ? 1 : 0; }()};
-static inline bool fwd_pipe() { return g_fwd_pipe.load(std::memory_order_relaxed) != 0; }
-// Shared curve sampling for several views of ONE parameter state (cgs_set_view_shared_sampling): the grid-wide norm pass of
-// the forward and the last pass of the sampling backward run once per view BATCH (cgs_view_shared_begin / _end) instead of
-// once per view -- the parameters do not change inside a batch and that backward pass is linear in the per-splat gradients
-static std::atomic<int> g_shared_sampling{0};
-static inline bool shared_sampling() { return g_shared_sampling.load(std::memory_order_relaxed) != 0; }
+// Shared curve sampling for several views of ONE parameter state (cgs_view_forward_shared, CGS_VIEW_SHARED in
+// cgs_view_backward's flags): the grid-wide norm pass of the forward and the last pass of the sampling backward run once per
+// view BATCH (cgs_view_shared_begin / _end) instead of once per view -- the parameters do not change inside a batch and that
+// backward pass is linear in the per-splat gradients.  A per-call choice: nothing process-wide changes what another caller's
+// cgs_view_forward / cgs_view_backward does.
+constexpr int VIEW_MODE_MASK = 3, VIEW_MODE_SHARED = 4;
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace cgs
@@ -200,16 +196,10 @@ void cgs_reset_binning_hints(void) {
 int cgs_set_tile_culling(int on) {
     return g_tile_cull.exchange(on ? 1 : 0, std::memory_order_relaxed);
 }
-int cgs_set_view_shared_sampling(int on) { return g_shared_sampling.exchange(on ? 1 : 0, std::memory_order_relaxed); }
-int cgs_set_forward_pipeline(int on) { return g_fwd_pipe.exchange(on ? 1 : 0, std::memory_order_relaxed); }
 int cgs_set_fused_tile_sort(int on) {
     return g_fuse_sort.exchange(on ? 1 : 0, std::memory_order_relaxed);
 }
 int cgs_set_operator_unit_route(int on) { return g_op_unit.exchange(on ? 1 : 0, std::memory_order_relaxed); }
-int cgs_set_unit_backward(int variant) {
-    if (variant != 3 && variant != 4) return g_unit_bwd.load(std::memory_order_relaxed);
-    return g_unit_bwd.exchange(variant, std::memory_order_relaxed);
-}
 void cgs_prof_enable(int on) { g_prof_on = on != 0; }
 void cgs_prof_reset(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -493,11 +483,7 @@ int cgs_rasterize_forward_static(void* geometry_buffer, void* binning_buffer, si
     const bool tag = list_tags_fit(P);
     launch_scatter_bucket(s, P, radii, geom.rec, gx, gy, img.tile_count, bin.keys, (uint32_t)cap, 1, img.total + 3,
                           defer_big ? img.tile_cursor : nullptr, (uint32_t)tiles, img.work + NONUNIT_WORD);
-    if (render_fwd_pipe_ok((uint32_t)cap) && fuse_sort() && fwd_pipe()) {
-        launch_render_fwd_pipe(s, render_geo != 0, tiles, img.tile_count, bin.keys, (uint32_t)cap, img.ranges, img.total,
-                               bin.point_list, width, height, gx, geom.rec, img.final_T, img.n_contrib, background, out_color,
-                               out_invdepth, out_all_map, false, img.work);
-    } else if (render_fwd_can_sort((uint32_t)cap) && fuse_sort()) {
+    if (render_fwd_can_sort((uint32_t)cap) && fuse_sort()) {
         launch_render_fwd_sorting(s, render_geo != 0, tiles, img.tile_count, bin.keys, (uint32_t)cap, img.ranges, img.total,
                                   bin.point_list, width, height, gx, geom.rec, img.final_T, img.n_contrib, background,
                                   out_color, out_invdepth, out_all_map, false, tag);
@@ -584,7 +570,7 @@ int cgs_rasterize_backward(int P, int D, int M, int64_t R, const float* backgrou
                                    img.n_contrib, dL_dout_color, geom.grad_acc, ACC_STRIDE, gate);
         }
         launch_render_bwd(s, geo, invd, colg, tiles, img.ranges, bin.point_list, width, height, gx, background, geom.rec,
-                          img.final_T, img.n_contrib, dL_dout_color, dL_dout_invdepth, dL_dout_all_map, geom.grad_acc, false,
+                          img.final_T, img.n_contrib, dL_dout_color, dL_dout_invdepth, dL_dout_all_map, geom.grad_acc,
                           ACC_STRIDE, id_mask, gate);
         if (!check_launch("render_bwd", debug, s)) return CGS_ERR_HIP;
     }
@@ -632,18 +618,47 @@ int cgs_sample_curves_forward(int B, int m, const float* curve_points, const flo
 // ---------------------------------------------------------------------------------------------- fused per-view path
 // One view of the training configuration, curve parameters in, image out (and back): the per-splat chains are fused
 // (view.hip), the rasterizer is the sync-free single-pass bucket pipeline of cgs_rasterize_forward_static.
-// Status readback of the checked view forward: one outstanding forward per host thread (begin -> wait).
-struct ViewStat { uint32_t* h = nullptr; hipEvent_t ev = nullptr; int P = 0, W = 0, H = 0; uint64_t cap = 0; bool pending = false; };
-static thread_local ViewStat g_view_stat;
-static int64_t view_forward_wait() {
-    ViewStat& v = g_view_stat;
-    if (!v.pending) {
-        set_error("cgs_view_forward_wait: no checked forward outstanding on this thread");
+// Status readback of the checked view forward.  Every cgs_view_forward_begin takes a slot of a small pool (pinned 16-byte
+// buffer + event, created on first use) and returns its handle; cgs_view_forward_wait(handle) blocks on that slot's event and
+// releases it.  Forwards begun by different threads, on different devices or streams, or for different models are
+// independent; a caller that drops a handle (an exception between begin and wait) leaks nothing but the slot until
+// cgs_view_forward_abandon(handle).
+struct ViewStat { uint32_t* h = nullptr; hipEvent_t ev = nullptr; int P = 0, W = 0, H = 0; uint64_t cap = 0; bool busy = false; };
+constexpr int VIEW_SLOTS = 64;
+static ViewStat g_view_slots[VIEW_SLOTS];
+static std::mutex g_view_mu;
+static int view_slot_acquire() {   // -> slot index, or a negative status
+    std::lock_guard<std::mutex> lk(g_view_mu);
+    for (int i = 0; i < VIEW_SLOTS; i++) {
+        ViewStat& v = g_view_slots[i];
+        if (v.busy) continue;
+        if (!v.h) {
+            if (hipHostMalloc((void**)&v.h, 4 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
+                hipEventCreateWithFlags(&v.ev, hipEventDisableTiming) != hipSuccess) {
+                set_error("pinned readback buffer / event creation failed");
+                v.h = nullptr;
+                return CGS_ERR_HIP;
+            }
+        }
+        v.busy = true;
+        return i;
+    }
+    set_error("cgs_view_forward_begin: %d checked forwards outstanding (every begin needs its cgs_view_forward_wait)", VIEW_SLOTS);
+    return CGS_ERR_INVALID_ARGUMENT;
+}
+static void view_slot_release(int i) {
+    std::lock_guard<std::mutex> lk(g_view_mu);
+    g_view_slots[i].busy = false;
+}
+static int64_t view_forward_wait(int handle, int64_t* n_visible) {
+    if (handle < 0 || handle >= VIEW_SLOTS || !g_view_slots[handle].busy) {
+        set_error("cgs_view_forward_wait: handle %d is not an outstanding checked forward", handle);
         return CGS_ERR_INVALID_ARGUMENT;
     }
-    v.pending = false;
+    ViewStat& v = g_view_slots[handle];
     const hipError_t e = hipEventSynchronize(v.ev);
     if (e != hipSuccess) {
+        view_slot_release(handle);
         set_error("cgs_view_forward_checked: status readback failed: %s", hipGetErrorString(e));
         return CGS_ERR_HIP;
     }
@@ -651,6 +666,8 @@ static int64_t view_forward_wait() {
     hints_update(v.P, v.W, v.H, (uint64_t)longest <= v.cap ? (int64_t)v.h[0] : -1, longest, (int64_t)v.h[3]);
     g_last_stats[0] = (int64_t)v.h[0]; g_last_stats[1] = (int64_t)longest; g_last_stats[2] = 1;
     g_last_visible = (int64_t)v.h[2];
+    if (n_visible) *n_visible = (int64_t)v.h[2];
+    view_slot_release(handle);
     return (int64_t)longest;
 }
 
@@ -716,8 +733,10 @@ static int64_t view_forward_impl(int mode, int B, int m, const float* curve_poin
     BinState bin = bin_from_chunk(bchunk, (size_t)(cap * tiles));
     ImageState img = image_from_chunk(ichunk, npix, (size_t)tiles);
     const size_t clear_bytes = (size_t)((char*)(img.total + TOTAL_WORDS) - (char*)img.tile_count);
+    const bool shared = (mode & VIEW_MODE_SHARED) != 0;
+    mode &= VIEW_MODE_MASK;
     // all five grid-wide sums (forward norms AND the backward's two) start from zero here: one launch per view
-    if (!shared_sampling()) {
+    if (!shared) {
         if (zero_async(norms, (size_t)sample_norm_words() * sizeof(double), s) != hipSuccess) {
             set_error("zero_async(norms) failed");
             return CGS_ERR_HIP;
@@ -737,32 +756,24 @@ static int64_t view_forward_impl(int mode, int B, int m, const float* curve_poin
     // checked: the longest tile list (and the instance count, oversized-rect count) travel to the host right behind the
     // scatter; the compositor is queued before the host waits, so the wait overlaps it
     const bool checked = mode != 0;
-    uint32_t*& h_stat = g_view_stat.h;   // pinned: instances, longest list, visible splats, oversized rects
-    hipEvent_t& ev = g_view_stat.ev;
+    int slot = -1;
     if (checked) {
-        if (!h_stat) {
-            if (hipHostMalloc((void**)&h_stat, 4 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
-                hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
-                set_error("pinned readback buffer / event creation failed");
-                h_stat = nullptr;
-                return CGS_ERR_HIP;
-            }
-        }
-        // four words of the (cleared) work block that the tile queues of render_pipe.hip do not use
+        slot = view_slot_acquire();
+        if (slot < 0) return slot;
+        ViewStat& vs = g_view_slots[slot];
+        // four words of the (cleared) work block
         uint32_t* const stat = img.work + 4;
         hipLaunchKernelGGL(k_count_stats, dim3(64), dim3(256), 0, s, img.tile_count, tiles, radii, P, img.total + 3, stat);
-        hipError_t e = hipMemcpyAsync(h_stat, stat, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipEventRecord(ev, s);
+        hipError_t e = hipMemcpyAsync(vs.h, stat, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipEventRecord(vs.ev, s);
         if (e != hipSuccess) {
+            view_slot_release(slot);
             set_error("cgs_view_forward_checked: status readback failed: %s", hipGetErrorString(e));
             return CGS_ERR_HIP;
         }
+        vs.P = P; vs.W = width_px; vs.H = height_px; vs.cap = cap;
     }
-    if (render_fwd_pipe_ok((uint32_t)cap) && fuse_sort() && fwd_pipe()) {
-        launch_render_fwd_pipe(s, aux, tiles, img.tile_count, bin.keys, (uint32_t)cap, img.ranges, img.total, bin.point_list,
-                               width_px, height_px, gx, geom.rec, img.final_T, img.n_contrib, background, out_color,
-                               out_invdepth, out_all_map, unit, img.work);
-    } else if (render_fwd_can_sort((uint32_t)cap) && fuse_sort()) {
+    if (render_fwd_can_sort((uint32_t)cap) && fuse_sort()) {
         launch_render_fwd_sorting(s, aux, tiles, img.tile_count, bin.keys, (uint32_t)cap, img.ranges, img.total,
                                   bin.point_list, width_px, height_px, gx, geom.rec, img.final_T, img.n_contrib, background,
                                   out_color, out_invdepth, out_all_map, unit);
@@ -771,11 +782,11 @@ static int64_t view_forward_impl(int mode, int B, int m, const float* curve_poin
         launch_render_fwd(s, aux, tiles, img.ranges, bin.point_list, width_px, height_px, gx, geom.rec, img.final_T,
                           img.n_contrib, background, out_color, out_invdepth, out_all_map, unit);
     }
-    if (!check_launch("view_forward", false, s)) return CGS_ERR_HIP;
-    if (checked) {
-        g_view_stat.P = P; g_view_stat.W = width_px; g_view_stat.H = height_px; g_view_stat.cap = cap; g_view_stat.pending = true;
-        if (mode == 1) return view_forward_wait();
+    if (!check_launch("view_forward", false, s)) {
+        if (checked) view_slot_release(slot);
+        return CGS_ERR_HIP;
     }
+    if (checked) return mode == 1 ? view_forward_wait(slot, nullptr) : (int64_t)slot;
     return CGS_OK;
 }
 
@@ -817,7 +828,22 @@ int cgs_view_forward_begin(int B, int m, const float* curve_points, const float*
                              background, width_px, height_px, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, out_color,
                              out_invdepth, out_all_map, radii, xyz, rotation, scaling, stream_);
 }
-int64_t cgs_view_forward_wait(void) { return view_forward_wait(); }
+int64_t cgs_view_forward_wait(int handle, int64_t* n_visible) { return view_forward_wait(handle, n_visible); }
+void cgs_view_forward_abandon(int handle) {
+    if (handle >= 0 && handle < VIEW_SLOTS) view_slot_release(handle);
+}
+int cgs_view_forward_shared(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
+                     float eps, double* norms, const float* opacity_logit, const float* mask_logit, float mask_thr,
+                     const float* colors_precomp, void* geometry_buffer, void* binning_buffer, size_t binning_bytes,
+                     void* image_buffer, uint32_t bucket_capacity, const float* background, int width_px, int height_px,
+                     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                     float* out_color, float* out_invdepth, float* out_all_map, int* radii, float* xyz, float* rotation,
+                     float* scaling, void* stream_) {
+    return (int)view_forward_impl(VIEW_MODE_SHARED, B, m, curve_points, width, is_bezier, coef, eps, norms, opacity_logit, mask_logit,
+                                  mask_thr, colors_precomp, geometry_buffer, binning_buffer, binning_bytes, image_buffer,
+                                  bucket_capacity, background, width_px, height_px, viewmatrix, projmatrix, cam_pos, tan_fovx,
+                                  tan_fovy, out_color, out_invdepth, out_all_map, radii, xyz, rotation, scaling, stream_);
+}
 int64_t cgs_last_forward_visible(void) { return g_last_visible; }
 uint32_t cgs_bucket_capacity_hint(int P, int width, int height) {
     const int64_t mx = hints_load(P, width, height).max;
@@ -834,7 +860,7 @@ int cgs_view_backward(int B, int m, const float* curve_points, const float* widt
                       int width_px, int height_px, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                       float tan_fovx, float tan_fovy, const int* radii, const float* dL_dout_color,
                       const float* dL_drotation_extra, float* dL_dmeans2D, float* dL_dcurve_points, float* dL_dwidth,
-                      float* dL_dopacity_logit, float* dL_dmask_logit, float* scratch, int accumulate, void* stream_) {
+                      float* dL_dopacity_logit, float* dL_dmask_logit, float* scratch, int flags, void* stream_) {
     hipStream_t s = (hipStream_t)stream_;
     const int P = B * m;
     if (B <= 0 || m <= 0 || m > 32 || width_px <= 0 || height_px <= 0 || !curve_points || !width || !coef || !norms ||
@@ -861,20 +887,19 @@ int cgs_view_backward(int B, int m, const float* curve_points, const float* widt
     float* g_scl = scratch + (size_t)P * 12;   // [P,3]
     // training configuration: only dL/dcolour flows in, the colours themselves need no gradient; the forward wrote unit
     // colours unless it was given colors_precomp (same argument here): closed-form dL/dalpha, no recurrences (render.hip, UNIT)
-    if (colors_precomp == nullptr && g_unit_bwd.load(std::memory_order_relaxed) == 4)
+    if (colors_precomp == nullptr)
         launch_render_bwd_unit(s, tiles, img.ranges, bin.point_list, width_px, height_px, gx, background, geom.rec, img.final_T,
                                img.n_contrib, dL_dout_color, geom.grad_acc);
-    else
+    else   // arbitrary colours: the general training instance (the forward did not tag the lists)
         launch_render_bwd(s, false, false, false, tiles, img.ranges, bin.point_list, width_px, height_px, gx, background, geom.rec,
-                          img.final_T, img.n_contrib, dL_dout_color, nullptr, nullptr, geom.grad_acc, colors_precomp == nullptr,
-                          ACC_STRIDE_VIEW);
+                          img.final_T, img.n_contrib, dL_dout_color, nullptr, nullptr, geom.grad_acc, ACC_STRIDE_VIEW);
     launch_view_backward(s, B, m, curve_points, width, is_bezier, coef, eps, norms, opacity_logit, mask_logit, mask_thr,
                          cam_pos, viewmatrix, projmatrix, tan_fovx, tan_fovy, focal_x, focal_y, width_px, height_px, radii,
                          geom.rec, geom.grad_acc, dL_drotation_extra, dL_dmeans2D, dL_dopacity_logit, dL_dmask_logit, g_xyz,
-                         g_scl, gv, (accumulate ? 1 : 0) | (shared_sampling() ? 2 : 0));
-    if (!shared_sampling())
+                         g_scl, gv, ((flags & CGS_VIEW_ACCUMULATE) ? 1 : 0) | ((flags & CGS_VIEW_SHARED) ? 2 : 0));
+    if (!(flags & CGS_VIEW_SHARED))
         launch_sample_backward_pass3(s, B, m, curve_points, width, is_bezier, coef, eps, norms, g_xyz, gv, g_scl,
-                                     dL_dcurve_points, dL_dwidth, gv, accumulate);
+                                     dL_dcurve_points, dL_dwidth, gv, (flags & CGS_VIEW_ACCUMULATE) ? 1 : 0);
     if (!check_launch("view_backward", false, s)) return CGS_ERR_HIP;
     return CGS_OK;
 }
@@ -1032,7 +1057,10 @@ size_t cgs_photometric_workspace_bytes(int height, int width) {
 __global__ void __launch_bounds__(256) k_render_epilogue(size_t npix, const float* __restrict__ color_raw, const float* __restrict__ all_map,
                                                          const float* __restrict__ wv, int clamp, float* __restrict__ color_out,
                                                          float* __restrict__ dir_out) {
-    const float w00 = wv[0], w01 = wv[1], w02 = wv[2], w10 = wv[4], w11 = wv[5], w12 = wv[6], w20 = wv[8], w21 = wv[9], w22 = wv[10];
+    float w00 = 0.f, w01 = 0.f, w02 = 0.f, w10 = 0.f, w11 = 0.f, w12 = 0.f, w20 = 0.f, w21 = 0.f, w22 = 0.f;
+    if (dir_out) {   // (viewmatrix may be NULL for a clamp-only call)
+        w00 = wv[0]; w01 = wv[1]; w02 = wv[2]; w10 = wv[4]; w11 = wv[5]; w12 = wv[6]; w20 = wv[8]; w21 = wv[9]; w22 = wv[10];
+    }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
         if (color_out) {
             const float c = color_raw[i];

@@ -55,18 +55,10 @@ void launch_render_fwd_sorting(hipStream_t s, bool geo, int tiles, const uint32_
                                int grid_x, const SplatRec* rec, float* final_T, uint32_t* n_contrib,
                                const float* bg_color, float* out_color, float* out_invdepth, float* out_all_map,
                                bool unit = false, bool tag = false);
-// render_pipe.hip: the same sorting forward as a persistent kernel -- a producer wave sorts and stages tile t+1 while four
-// walker waves composite tile t; `work`: one zeroed u32 (the tile counter)
-bool render_fwd_pipe_ok(uint32_t cap);
-void launch_render_fwd_pipe(hipStream_t s, bool geo, int tiles, const uint32_t* tile_count, const uint64_t* keys, uint32_t cap,
-                            uint2* ranges, uint32_t* total, uint32_t* point_list, int W, int H, int grid_x,
-                            const SplatRec* rec, float* final_T, uint32_t* n_contrib, const float* bg_color, float* out_color,
-                            float* out_invdepth, float* out_all_map, bool unit, uint32_t* work);
 void launch_render_bwd(hipStream_t s, bool geo, bool invd, bool colg, int tiles, const uint2* ranges,
                        const uint32_t* point_list, int W, int H, int grid_x, const float* bg_color,
                        const SplatRec* rec, const float* final_Ts, const uint32_t* n_contrib, const float* dL_dpixels,
                        const float* dL_dout_invdepth, const float* dL_dout_all_map, float* grad_acc,
-                       bool unit = false,    // unit: colour == 1 for every splat (render.hip, UNIT)
                        int acc_stride = ACC_STRIDE,    // floats per accumulator record (ACC_STRIDE_VIEW on the view path)
                        uint32_t id_mask = 0xffffffffu,           // strips the forward's list tags (LIST_ID_MASK when it tagged)
                        const uint32_t* nonunit_gate = nullptr);  // device word: the kernel returns at once when it is zero

@@ -415,18 +415,36 @@ constexpr int SSTRIDE = 80, LSTRIDE = 68;
 __device__ __forceinline__ int slot_row(int q) { return 8 * q + 4 * (q >= 2) + 4 * (q >= 6); }
 __device__ __forceinline__ int sum_field(int f) { return 8 * f + 4 * (f >= 4); }
 
-// UNIT (only with the training instance): the caller guarantees colour == 1 for every splat (the view entry points build
-// unit colours themselves).  Then the image is C = 1 - T_final (+ T_final bg), and for a blended splat i
-//     dC/dalpha_i = (1 - bg) T_final / (1 - alpha_i)
-// in closed form -- the reference's two recurrences (T_i = T_{i+1} / (1 - alpha_i), colour behind) collapse:
-// 1 - colour_behind_i = prod_{j > i} (1 - alpha_j) and T_i times that is T_final / (1 - alpha_i).  No state is carried from
-// pair to pair: 5 vector instructions per pair less, and no dependent chain through the walk.
-template <bool GEO, bool INVD, bool COLG, bool UNIT = false>
+// (The unit-colour training instance -- colour == 1, only dL/dcolour flowing in -- has a closed form without recurrences and
+// its own pair-major kernel, render_unit_bwd.hip; the operator API reaches it through a device-side verdict on the colours.)
+//
+// Instances with extra sums (round 5; COLG / INVD / GEO: dL/dcolour, dL/d(1/depth), dL/dall_map of the splats):
+//   * ONE recurrence whatever the number of channels.  The reference carries a "colour behind" accumulator per channel
+//     (backward.cu:605-640) and adds (c_ch - behind_ch) dL/dchannel_ch over the channels.  That sum is the colour-behind
+//     recurrence of the single PROJECTED colour  c^ = sum_ch c_ch dL/dchannel_ch(pixel)  (the recurrence is linear in the
+//     colour, the upstream gradient is a per-pixel constant): one 6-term dot product and one accumulator per pair instead of
+//     six subtract / fma / fma triples.
+//   * every channel's per-splat gradient is  sum_pixels w dL/dchannel_ch  with the SAME blend weight w = alpha T, so the walk
+//     parks w next to g (one more LDS store per pair) and the splat-parallel flush folds the row of eight w against the eight
+//     upstream gradients of its pixel row, which lane (slot, row) holds in registers for the whole kernel: the extra sums are
+//     extra moment rows.  (Before: one multiply, a four-step DPP row reduction and a select per channel and PAIR -- the
+//     all-gradient instance took 675 us at cfg3 against 200 for the training instance.)  With the colour as the only channel
+//     the parked value is w dL/dpixel itself and the flush only adds.
+//   * the sums are parked per (quadrant, list position) and combined like the training instance's: one 8- or 12-float atomic
+//     request per (tile, splat) instance instead of one per (quadrant, splat) pair.
+// TAGGED (id_mask strips bits): the list entries carry the forward's quadrant masks (composite.h) -- no reach test here.
+template <bool GEO, bool INVD, bool COLG>
 #ifndef CGS_BWD3_WAVES_GEO
-#define CGS_BWD3_WAVES_GEO 2
+#define CGS_BWD3_WAVES_GEO 3
 #endif
 #ifndef CGS_BWD3_WAVES_EXTRA
 #define CGS_BWD3_WAVES_EXTRA 4
+#endif
+#ifndef CGS_BWD3_CAP_EXTRA
+#define CGS_BWD3_CAP_EXTRA 96
+#endif
+#ifndef CGS_BWD3_CAP_GEO
+#define CGS_BWD3_CAP_GEO 64
 #endif
 __global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG) ? CGS_BWD3_WAVES_EXTRA : CGS_BWD3_WAVES) k_render_bwd3(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int grid_x,
@@ -438,9 +456,14 @@ __global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG)
     // splat has unit colour and all_map[3] == 1, and k_render_bwd_unit -- launched beside this kernel -- does the work
     if (nonunit_gate && *nonunit_gate == 0u) return;
     constexpr bool EXTRA = COLG || INVD || GEO;   // sums beyond the six geometric ones
+    constexpr bool MULTI = INVD || GEO;           // more than one channel flows in: projected colour, w parked
+    static_assert(!MULTI || COLG, "the instances with depth / all_map gradients also produce the colour gradient");
     constexpr int NF = GEO ? 12 : EXTRA ? 8 : 6;  // fields of the packed per-splat accumulator record that can be non-zero
+    constexpr int NX = (COLG ? 1 : 0) + (INVD ? 1 : 0) + (GEO ? 4 : 0);   // channels
     constexpr int BB = BWD_BATCH, NC = BB / 64;
-    constexpr int CAP = EXTRA ? 0 : CGS_BWD3_CAP; // list positions per wave whose sums are combined in LDS (see s_res)
+    // list positions per wave whose sums are combined in LDS (see s_res)
+    constexpr int CAP = GEO ? CGS_BWD3_CAP_GEO : EXTRA ? CGS_BWD3_CAP_EXTRA : CGS_BWD3_CAP;
+    static_assert(CAP % 8 == 0 && CAP <= BB, "CAP: a multiple of SLOTS (8), at most BWD_BATCH");
     // staged entry j of the batch lives at index j + 1; index BB + 1 is the padding entry (alpha = 0)
     __shared__ float4 s_geo[BB + 2];   // {cx, cy, A2, B2}
     __shared__ float4 s_at[BB + 2];    // {colour, 1/depth (INVD) or the splat id's bits, C2, log2 opacity}
@@ -450,15 +473,20 @@ __global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG)
     __shared__ uint64_t s_tmask[4][NC];   // the same, minus the entries behind everything the quadrant blended = its list
     __shared__ __attribute__((aligned(16))) uint32_t s_list[4][BB + GROUP];   // per wave: 16 * (staged index + 1)
     __shared__ __attribute__((aligned(16))) float s_g[4][SLOTS * SSTRIDE];    // per wave: g of 8 slots x 64 pixels; then the row sums
-    __shared__ float s_x[EXTRA ? 4 : 1][SLOTS][8];                            // per wave: colour / inv-depth / all_map sums per slot
+    // per wave: the blend weight w = alpha T of the same 8 x 64 pairs (COLG alone: w dL/dpixel); then the row sums of fields 8..11
+    __shared__ __attribute__((aligned(16))) float s_w[EXTRA ? 4 : 1][EXTRA ? SLOTS * SSTRIDE : 1];
     // Per-(quadrant, list position) gradient sums of the batch.  The L2 executes ~20 scattered atomic requests per ns
     // chip-wide, whatever their scope or width up to a line; one request per (quadrant, splat) pair -- 3.8 M per cfg3 view --
     // is a 190 us floor (no-atomics experiment: 231 -> 144 us).  The four quadrant waves therefore park their sums here with
     // plain stores (consecutive list positions = consecutive addresses), and after the batch lane (entry, field) adds the
     // up-to-four quadrant sums of its entry -- list positions recomputed from the quadrant masks -- and issues ONE request per
     // tile instance (1.6 M per view).  Adding in LDS with ds_add_f32 instead costs more than it saves (63 us of this kernel).
-    // List positions >= CAP (and the configurations with extra sums) keep the direct one-request-per-pair path.
-    __shared__ __attribute__((aligned(16))) float s_res[4][CAP > 0 ? CAP * NF : 1];
+    // List positions >= CAP keep the direct one-request-per-pair path.
+    __shared__ __attribute__((aligned(16))) float s_res[4][CAP * NF];
+    // MULTI: the upstream gradients of the wave's 64 pixels, per channel, row-major (pixel (x, row q) at 8 q + x): the flush
+    // reads its row of eight per channel from here (registers instead: 48 more live VGPRs = one wave per SIMD less, and these
+    // instances are latency-bound -- 3 waves: 375 us, 2 waves: 447 us for the colour + all_map instance at cfg3)
+    __shared__ __attribute__((aligned(16))) float s_d[MULTI ? 4 : 1][MULTI ? NX : 1][64];
     const TileGeom g = tile_geom(W, H, grid_x);
     const int lane = g.lane;
     const float X0 = (float)(g.tx * TILE), Y0 = (float)(g.ty * TILE);
@@ -467,6 +495,7 @@ __global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG)
     if (total == 0) return;
     const int rounds = (total + BB - 1) / BB;
     const size_t HW = (size_t)H * W;
+    const bool tagged = id_mask != 0xffffffffu;
     if (threadIdx.x == 0) {
         s_geo[BB + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
         s_at[BB + 1] = make_float4(0.f, 0.f, 0.f, L2_NEVER);
@@ -483,7 +512,7 @@ __global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG)
     for (int off = 32; off >= 1; off >>= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, off, 64));
     wave_last = __builtin_amdgcn_readfirstlane(wave_last);
 
-    float accum_rec = 0.f, accum_invd = 0.f, accum_m0 = 0.f, accum_m1 = 0.f, accum_m2 = 0.f, accum_m3 = 0.f;
+    float accum_rec = 0.f;   // colour behind (MULTI: of the projected colour)
     float dL_dpixel = 0.f, dL_invd = 0.f, dm0 = 0.f, dm1 = 0.f, dm2 = 0.f, dm3 = 0.f;
     if (g.inside) {
         dL_dpixel = dL_dpixels[g.pix_id];
@@ -497,11 +526,10 @@ __global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG)
     }
     const float nTf_bg = -T_final * (bg_color[0] * dL_dpixel);             // backward.cu:649-652
     float Tp = T_final * dL_dpixel;                                        // T dL/dpixel (single-channel configurations)
-    const float unit_k = Tp + nTf_bg;                                      // (1 - bg) T_final dL/dpixel (UNIT)
-    static_assert(!UNIT || (!GEO && !INVD && !COLG), "UNIT is a variant of the training instance");
-    const int col = lane & 15;
     uint32_t* const list = s_list[g.wave];
+    const StepConsts k = step_consts();
     float* const sg = s_g[g.wave];
+    float* const sw = s_w[EXTRA ? g.wave : 0];
     float* const res = s_res[g.wave];
     const char* const geo_bytes = reinterpret_cast<const char*>(s_geo);
     const char* const at_bytes = reinterpret_cast<const char*>(s_at);
@@ -517,13 +545,21 @@ __global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG)
     const int fs = lane >> 3, ff = lane & 7;
     const float qyr = (float)(g.ty * TILE + ((g.wave >> 1) << 3) + q);
     const int pix_off = slot_row(lane >> 3) + (lane & 7);   // where this lane's pixel sits inside a slot
+    if (MULTI) {
+        const float mine[6] = {dL_dpixel, INVD ? dL_invd : dm0, INVD ? dm0 : dm1, INVD ? dm1 : dm2, INVD ? dm2 : dm3, dm3};
+#pragma unroll
+        for (int c = 0; c < NX; c++) s_d[MULTI ? g.wave : 0][MULTI ? c : 0][lane] = mine[c];   // (lane = 8 y + x)
+        // (read by this wave only, after the first batch's __syncthreads)
+    }
+    const float* const drow = &s_d[MULTI ? g.wave : 0][0][8 * q];
 
     for (int i = 0; i < rounds; i++) {
         if (i > 0) __syncthreads();  // every wave is done with the previous batch's staged data
         const int progress = i * BB + threadIdx.x;
         uint32_t qm = 0;
         if (threadIdx.x < BB && progress < total) {
-            const uint32_t id = point_list[range.y - progress - 1] & id_mask;  // back to front (backward.cu:554); id_mask strips the forward's tags
+            const uint32_t ent = point_list[range.y - progress - 1];  // back to front (backward.cu:554)
+            const uint32_t id = ent & id_mask;                        // id_mask strips the forward's tags
             const SplatRec* r = rec + id;
             const float4 a = r->a, b = r->b;
             float4 sa, sb;
@@ -532,7 +568,8 @@ __global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG)
             s_geo[threadIdx.x + 1] = sa;
             s_at[threadIdx.x + 1] = make_float4(sb.z, INVD ? sb.w : __uint_as_float(id), sb.x, __builtin_amdgcn_logf(sb.y));   // v_log_f32 = log2
             if (GEO) s_c[threadIdx.x + 1] = r->c;
-            qm = quadrant_mask(a, b, r->d.z, X0, Y0);
+            // (an entry of a batch the forward never staged is untagged = empty mask: it lies behind every pixel's cut)
+            qm = tagged ? (ent >> LIST_TAG_SHIFT) : quadrant_mask(a, b, r->d.z, X0, Y0);
         }
         if (g.wave < NC) {   // (wave-uniform)
 #pragma unroll
@@ -552,7 +589,7 @@ __global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG)
             const int lo = first_J - c * 64;
             if (lo >= 64) m = 0;
             else if (lo > 0) m &= ~((1ull << lo) - 1ull);
-            if (CAP > 0 && lane == 0) s_tmask[g.wave][c] = m;
+            if (lane == 0) s_tmask[g.wave][c] = m;
             if ((m >> lane) & 1ull) {
                 const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 list[pos] = (uint32_t)((c * 64 + lane + 1) * 16);
@@ -561,8 +598,9 @@ __global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG)
         }
         if (lane < GROUP) list[n + lane] = BWD_PAD_OFF;
         // lane-private: staged entry J matters to this pixel iff its list position < last_contributor  <=>  J >= first_lane
+        // <=>  16 (J + 1) - 16 max(first_lane, 0) >= 16: on these integer-valued floats the saturated difference IS the 0 / 1 step
         const int first_lane = total - (int)last_contributor - i * BB;
-        const uint32_t jmin_off = (uint32_t)(max(first_lane, 0) + 1) * 16u;
+        const float jmin_f = (float)(16 * max(first_lane, 0));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -581,66 +619,53 @@ __global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG)
                     const uint4 wa4 = *reinterpret_cast<const uint4*>(list + k0);      // eight offsets, same address in every lane
                     const uint4 wb4 = *reinterpret_cast<const uint4*>(list + k0 + 4);
                     const uint32_t wv[SLOTS] = {wa4.x, wa4.y, wa4.z, wa4.w, wb4.x, wb4.y, wb4.z, wb4.w};
-                    float t_c = 0.f, t_invd = 0.f, t_m0 = 0.f, t_m1 = 0.f, t_m2 = 0.f, t_m3 = 0.f;
+                    // the eight splats' colours: requested together, ahead of the walk (inside it every read would expose an LDS
+                    // round trip behind the previous pair's arithmetic)
+                    float2 ci[SLOTS];
+                    float4 cm[GEO ? SLOTS : 1];
 #pragma unroll
                     for (int u = 0; u < SLOTS; u++) {
-                        const uint32_t joff = wv[u];
-                        const float alpha_u = __builtin_amdgcn_exp2f(P[half * SLOTS + u]);
+                        if (MULTI) ci[u] = *reinterpret_cast<const float2*>(at_bytes + wv[u]);   // {colour, 1/depth}
+                        else ci[u] = make_float2(*reinterpret_cast<const float*>(at_bytes + wv[u]), 0.f);
+                        if (GEO) cm[GEO ? u : 0] = *reinterpret_cast<const float4*>(c_bytes + wv[u]);
+                    }
+                    // Branch-free walk: the reference's two tests (backward.cu:576-578 position, :595 alpha < 1/255) become 0 / 1
+                    // factors on the float pipe -- [e >= 1/255] = sat(e 2^100 - pred(1/255) 2^100) like the forward,
+                    // [position in front of the pixel's cut] = sat(16 (J + 1) - 16 jmin) -- and a pair that fails either runs the
+                    // recurrences with alpha = 0, which leaves every carried quantity bit for bit as it was (1 / (1 - 0) = 1).
+#pragma unroll
+                    for (int u = 0; u < SLOTS; u++) {
+                        const float e = __builtin_amdgcn_exp2f(P[half * SLOTS + u]);
+                        const float m = sat01(fmaf(e, k.big, k.cA)) * sat01((float)wv[u] - jmin_f);
+                        const float alpha_u = e * m;
                         const float alpha = fminf(0.99f, alpha_u);
-                        const bool active = (joff >= jmin_off) && !(alpha < ALPHA_MIN);
-                        float v_g = 0.f, v_c = 0.f, v_invd = 0.f, v_m0 = 0.f, v_m1 = 0.f, v_m2 = 0.f, v_m3 = 0.f;
-                        if (active) {
-                            // The reference keeps (last_alpha, last_colour) and folds them into the "colour behind"
-                            // accumulator at the start of the next step (backward.cu:605,620,631); folding right after use
-                            // is the same recurrence -- acc' = acc + alpha (c - acc) -- with one fma per channel.
-                            const float rcp_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-                            const float colour = UNIT ? 1.f : *reinterpret_cast<const float*>(at_bytes + joff);
-                            float dL_dalpha;
-                            if (UNIT) {
-                                dL_dalpha = unit_k * rcp_1ma;
-                            } else if (!INVD && !GEO) {   // one channel: carry Tp = T dL/dpixel instead of T
-                                Tp = Tp * rcp_1ma;
-                                const float d_c = colour - accum_rec;
-                                accum_rec = fmaf(alpha, d_c, accum_rec);
-                                if (COLG) v_c = alpha * Tp;
-                                dL_dalpha = fmaf(nTf_bg, rcp_1ma, d_c * Tp);
-                            } else {
-                                T = T * rcp_1ma;
-                                const float dchannel_dcolor = alpha * T;
-                                const float d_c = colour - accum_rec;
-                                accum_rec = fmaf(alpha, d_c, accum_rec);
-                                float sum = d_c * dL_dpixel;
-                                if (COLG) v_c = dchannel_dcolor * dL_dpixel;
-                                if (INVD) {
-                                    const float d_i = *reinterpret_cast<const float*>(at_bytes + joff + 4) - accum_invd;
-                                    accum_invd = fmaf(alpha, d_i, accum_invd);
-                                    sum = fmaf(d_i, dL_invd, sum);
-                                    v_invd = dchannel_dcolor * dL_invd;
-                                }
-                                if (GEO) {
-                                    const float4 cm = *reinterpret_cast<const float4*>(c_bytes + joff);
-                                    const float d0 = cm.x - accum_m0, d1 = cm.y - accum_m1, d2 = cm.z - accum_m2, d3 = cm.w - accum_m3;
-                                    accum_m0 = fmaf(alpha, d0, accum_m0); accum_m1 = fmaf(alpha, d1, accum_m1);
-                                    accum_m2 = fmaf(alpha, d2, accum_m2); accum_m3 = fmaf(alpha, d3, accum_m3);
-                                    sum = fmaf(d0, dm0, sum); sum = fmaf(d1, dm1, sum); sum = fmaf(d2, dm2, sum); sum = fmaf(d3, dm3, sum);
-                                    v_m0 = dchannel_dcolor * dm0; v_m1 = dchannel_dcolor * dm1;
-                                    v_m2 = dchannel_dcolor * dm2; v_m3 = dchannel_dcolor * dm3;
-                                }
-                                dL_dalpha = fmaf(nTf_bg, rcp_1ma, sum * T);
-                            }
-                            v_g = alpha_u * dL_dalpha;
-                        }
-                        sg[u * SSTRIDE + pix_off] = v_g;
-                        if (COLG || INVD || GEO) {
-                            const bool mine = col == u;
-                            if (COLG) { v_c = row16_sum(v_c); t_c = mine ? v_c : t_c; }
-                            if (INVD) { v_invd = row16_sum(v_invd); t_invd = mine ? v_invd : t_invd; }
+                        // The reference keeps (last_alpha, last_colour) and folds them into the "colour behind" accumulator at
+                        // the start of the next step (backward.cu:605,620,631); folding right after use is the same
+                        // recurrence -- acc' = acc + alpha (c - acc) -- with one fma per channel.
+                        const float rcp_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                        float dL_dalpha, v_w = 0.f;
+                        if (!MULTI) {   // one channel: carry Tp = T dL/dpixel instead of T
+                            Tp = Tp * rcp_1ma;
+                            const float d_c = ci[u].x - accum_rec;
+                            accum_rec = fmaf(alpha, d_c, accum_rec);
+                            if (COLG) v_w = alpha * Tp;   // = w dL/dpixel: this pixel's share of dL/dcolour
+                            dL_dalpha = fmaf(nTf_bg, rcp_1ma, d_c * Tp);
+                        } else {        // projected colour: c^ = sum_ch c_ch dL/dchannel_ch
+                            T = T * rcp_1ma;
+                            float chat = ci[u].x * dL_dpixel;
+                            if (INVD) chat = fmaf(ci[u].y, dL_invd, chat);
                             if (GEO) {
-                                v_m0 = row16_sum(v_m0); v_m1 = row16_sum(v_m1); v_m2 = row16_sum(v_m2); v_m3 = row16_sum(v_m3);
-                                t_m0 = mine ? v_m0 : t_m0; t_m1 = mine ? v_m1 : t_m1;
-                                t_m2 = mine ? v_m2 : t_m2; t_m3 = mine ? v_m3 : t_m3;
+                                const float4 c4 = cm[GEO ? u : 0];
+                                chat = fmaf(c4.x, dm0, chat); chat = fmaf(c4.y, dm1, chat);
+                                chat = fmaf(c4.z, dm2, chat); chat = fmaf(c4.w, dm3, chat);
                             }
+                            const float d_c = chat - accum_rec;
+                            accum_rec = fmaf(alpha, d_c, accum_rec);
+                            v_w = alpha * T;              // blend weight (dchannel_dcolor, backward.cu:607)
+                            dL_dalpha = fmaf(nTf_bg, rcp_1ma, d_c * T);
                         }
+                        sg[u * SSTRIDE + pix_off] = alpha_u * dL_dalpha;
+                        if (EXTRA) sw[u * SSTRIDE + pix_off] = v_w;
                     }
                     // ---- flush the eight slots
                     {
@@ -648,6 +673,7 @@ __global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG)
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     float Sg, Sx, Sy, Sxx, Sxy, Syy;
+                    float E[EXTRA ? NX : 1];
                     {
                         const uint32_t joff = list[k0 + sl];
                         const float2 cxy = *reinterpret_cast<const float2*>(geo_bytes + joff);
@@ -667,37 +693,60 @@ __global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG)
                         const float Rxx = fmaf(dx0, Rx - M1, M2);
                         Sg = M0; Sx = Rx; Sxx = Rxx;
                         Sy = dyr * M0; Sxy = dyr * Rx; Syy = (dyr * dyr) * M0;
+                        if (EXTRA) {   // the row's share of the channel gradients: sum_x w dL/dchannel
+                            const float4 w0v = *reinterpret_cast<const float4*>(sw + sl * SSTRIDE + slot_row(q));
+                            const float4 w1v = *reinterpret_cast<const float4*>(sw + sl * SSTRIDE + slot_row(q) + 4);
+                            if (!MULTI) {
+                                E[0] = ((w0v.x + w0v.y) + (w0v.z + w0v.w)) + ((w1v.x + w1v.y) + (w1v.z + w1v.w));
+                            } else {
+#pragma unroll
+                                for (int c = 0; c < NX; c++) {
+                                    const float4 d0 = *reinterpret_cast<const float4*>(drow + 64 * c);
+                                    const float4 d1 = *reinterpret_cast<const float4*>(drow + 64 * c + 4);
+                                    float e = w0v.x * d0.x;
+                                    e = fmaf(w0v.y, d0.y, e); e = fmaf(w0v.z, d0.z, e); e = fmaf(w0v.w, d0.w, e);
+                                    e = fmaf(w1v.x, d1.x, e); e = fmaf(w1v.y, d1.y, e); e = fmaf(w1v.z, d1.z, e);
+                                    E[c] = fmaf(w1v.w, d1.w, e);
+                                }
+                            }
+                        }
                     }
-                    if (COLG) t_c = rows_sum(t_c);
-                    if (INVD) t_invd = rows_sum(t_invd);
-                    if (GEO) { t_m0 = rows_sum(t_m0); t_m1 = rows_sum(t_m1); t_m2 = rows_sum(t_m2); t_m3 = rows_sum(t_m3); }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();   // every lane has read its slot row: the buffer becomes [slot][field][row]
+                    __builtin_amdgcn_wave_barrier();   // every lane has read its slot rows: the buffers become [slot][field][row]
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     {
                         float* rp = sg + sl * LSTRIDE + q;
                         rp[sum_field(0)] = Sg; rp[sum_field(1)] = Sx; rp[sum_field(2)] = Sy;
                         rp[sum_field(3)] = Sxx; rp[sum_field(4)] = Sxy; rp[sum_field(5)] = Syy;
-                        if (EXTRA && lane < SLOTS) {
-                            float* xp = &s_x[EXTRA ? g.wave : 0][lane][0];
-                            xp[0] = COLG ? t_c : 0.f; xp[1] = INVD ? t_invd : 0.f;
-                            if (GEO) { xp[2] = t_m0; xp[3] = t_m1; xp[4] = t_m2; xp[5] = t_m3; }
+                        if (EXTRA) {   // record fields: 6 colour, 7 inverse depth, 8..11 all_map
+                            rp[sum_field(ACC_COL)] = E[0];
+                            rp[sum_field(ACC_INVD)] = INVD ? E[1] : 0.f;
+                            if (GEO) {
+                                float* xp = sw + sl * LSTRIDE + q;
+                                constexpr int M0I = INVD ? 2 : 1;
+                                xp[sum_field(0)] = E[GEO ? M0I : 0]; xp[sum_field(1)] = E[GEO ? M0I + 1 : 0];
+                                xp[sum_field(2)] = E[GEO ? M0I + 2 : 0]; xp[sum_field(3)] = E[GEO ? M0I + 3 : 0];
+                            }
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     {
-                        float v = 0.f;
-                        if (ff < 6) {
+                        float v = 0.f, v2 = 0.f;
+                        if (ff < (EXTRA ? 8 : 6)) {
                             const float4 r0 = *reinterpret_cast<const float4*>(sg + fs * LSTRIDE + sum_field(ff));
                             const float4 r1 = *reinterpret_cast<const float4*>(sg + fs * LSTRIDE + sum_field(ff) + 4);
                             v = ((r0.x + r0.y) + (r0.z + r0.w)) + ((r1.x + r1.y) + (r1.z + r1.w));
-                        } else if (EXTRA) {
-                            v = s_x[EXTRA ? g.wave : 0][fs][ff - 6];
                         }
-                        if (CAP > 0 && (CAP >= BB || k0 + SLOTS <= CAP)) {   // (wave-uniform) park: 8 slots x NF fields, consecutive
-                            if (ff < NF) res[(k0 + fs) * NF + ff] = v;
+                        if (GEO && ff < 4) {
+                            const float4 r0 = *reinterpret_cast<const float4*>(sw + fs * LSTRIDE + sum_field(ff));
+                            const float4 r1 = *reinterpret_cast<const float4*>(sw + fs * LSTRIDE + sum_field(ff) + 4);
+                            v2 = ((r0.x + r0.y) + (r0.z + r0.w)) + ((r1.x + r1.y) + (r1.z + r1.w));
+                        }
+                        if (CAP >= BB || k0 + SLOTS <= CAP) {   // (wave-uniform) park: 8 slots x NF fields, consecutive
+                            if (ff < (NF < 8 ? NF : 8)) res[(k0 + fs) * NF + ff] = v;
+                            if (GEO && ff < 4) res[(k0 + fs) * NF + 8 + ff] = v2;
                         } else {
                             // the 6-8 atomics of one splat hit 8 consecutive floats of its 64-byte accumulator record and
                             // coalesce into ONE L2 request (measured 7x the rate of one field per instruction)
@@ -705,14 +754,11 @@ __global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG)
                             const uint32_t id = INVD ? *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_id) + (joff >> 2))
                                                      : __float_as_uint(*reinterpret_cast<const float*>(at_bytes + joff + 4));
                             if (v != 0.f) atomicAdd(grad_acc + (size_t)id * acc_stride + ff, v);
-                            if (GEO) {
-                                const float v2 = ff < 4 ? s_x[g.wave][fs][2 + ff] : 0.f;
-                                if (v2 != 0.f) atomicAdd(grad_acc + (size_t)id * acc_stride + 8 + ff, v2);
-                            }
+                            if (GEO && v2 != 0.f) atomicAdd(grad_acc + (size_t)id * acc_stride + 8 + ff, v2);
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();   // the slot buffer may be overwritten from here on
+                    __builtin_amdgcn_wave_barrier();   // the slot buffers may be overwritten from here on
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     }
                 }
@@ -720,7 +766,7 @@ __global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG)
         }
         // ---- the batch's per-splat sums leave the workgroup: lane (entry, field) -> consecutive floats of the splat's
         // 64-byte accumulator record = one L2 request per entry
-        if (CAP > 0) {
+        {
             __syncthreads();
             const int nb = min(BB, total - i * BB);
             uint64_t tm[4][NC];
@@ -731,12 +777,14 @@ __global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG)
 #pragma unroll
                 for (int c = 0; c < NC; c++) { tm[w][c] = s_tmask[w][c]; base[w][c] = acc; acc += __builtin_popcountll(tm[w][c]); }
             }
-            const int f = (int)(threadIdx.x & 7);
+            constexpr int FL = NF > 8 ? 16 : 8;     // lanes per entry
+            constexpr int EPP = 256 / FL;           // entries per pass of the workgroup
+            const int f = (int)(threadIdx.x & (FL - 1));
 #pragma unroll
             for (int c = 0; c < NC; c++) {
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const int bit = h * 32 + (int)(threadIdx.x >> 3), e = c * 64 + bit;
+                for (int h = 0; h < 64 / EPP; h++) {
+                    const int bit = h * EPP + (int)(threadIdx.x / FL), e = c * 64 + bit;
                     if (e < nb && f < NF) {
                         float v = 0.f;
                         bool any = false;
@@ -747,7 +795,7 @@ __global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG)
                             if (((m >> bit) & 1ull) && pos < CAP) { v += s_res[w][pos * NF + f]; any = true; }
                         }
                         if (any && v != 0.f) {
-                            const uint32_t id = __float_as_uint(s_at[e + 1].y);
+                            const uint32_t id = INVD ? s_id[e + 1] : __float_as_uint(s_at[e + 1].y);
                             atomicAdd(grad_acc + (size_t)id * acc_stride + f, v);
                         }
                     }
@@ -793,15 +841,9 @@ void launch_render_fwd_sorting(hipStream_t s, bool geo, int tiles, const uint32_
 void launch_render_bwd(hipStream_t s, bool geo, bool invd, bool colg, int tiles, const uint2* ranges,
                        const uint32_t* point_list, int W, int H, int grid_x, const float* bg_color,
                        const SplatRec* rec, const float* final_Ts, const uint32_t* n_contrib, const float* dL_dpixels,
-                       const float* dL_dout_invdepth, const float* dL_dout_all_map, float* grad_acc, bool unit,
-                       int acc_stride, uint32_t id_mask, const uint32_t* nonunit_gate) {
+                       const float* dL_dout_invdepth, const float* dL_dout_all_map, float* grad_acc, int acc_stride,
+                       uint32_t id_mask, const uint32_t* nonunit_gate) {
     ProfScope p("render_bwd", s);
-    if (unit && !geo && !invd && !colg) {
-        hipLaunchKernelGGL((k_render_bwd3<false, false, false, true>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H,
-                           grid_x, bg_color, rec, final_Ts, n_contrib, dL_dpixels, dL_dout_invdepth, dL_dout_all_map, grad_acc, acc_stride,
-                           LIST_ID_MASK, nullptr);
-        return;
-    }
 #define CGS_BWD(G, I, C)                                                                                         \
     hipLaunchKernelGGL((k_render_bwd3<G, I, C>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H, grid_x, \
                        bg_color, rec, final_Ts, n_contrib, dL_dpixels, dL_dout_invdepth, dL_dout_all_map, grad_acc, acc_stride, id_mask, nonunit_gate)

@@ -212,7 +212,19 @@ class _Ext:
         return present
 
 
-_C = _Ext()
+class _ExtProxy:
+    """``diff_cur_rasterization._C``: the compiled host shim (csrc/torch_shim.cpp, the counterpart of the reference's pybind
+    module, ext.cpp:15-19) by default, the ctypes bindings above with CGS_TORCH_SHIM=0.  Resolved on first use."""
+    _impl = None
+
+    def __getattr__(self, name):
+        impl = _ExtProxy._impl
+        if impl is None:
+            impl = _ExtProxy._impl = L.shim() if L.use_shim() else _Ext()
+        return getattr(impl, name)
+
+
+_C = _ExtProxy()
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, all_map,

@@ -45,8 +45,11 @@ def _fused_route_ok(pc, pipe, scaling_modifier, override_color):
 
 
 def _param_stamp(pc):
+    """What prepare_scaling_rot derived `pc.get_xyz` ... from: parameter storage + versions, the curve count and the is_bezier
+    tensor (a changed curve type re-samples differently); the eps it used travels beside it (`pc._derived_eps`) and is handed
+    to the fused route, which re-samples the curves itself."""
     return (pc._curve_points.data_ptr(), pc._curve_points._version, pc._width.data_ptr(), pc._width._version,
-            tuple(pc._curve_points.shape))
+            tuple(pc._curve_points.shape), pc.is_bezier.data_ptr(), pc.is_bezier._version)
 
 
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_sh=False, override_color=None,
@@ -77,6 +80,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_
                          "and the reference's default pipeline flags")
     if use_fused:
         from ..ops import view_render as VR
+        pend = []
         while True:
             # clamp and direction map (:138-145) come out of the same autograd node (one epilogue launch); the exposure of
             # use_trained_exp sits between compositor and clamp upstream, so that combination keeps the separate ops
@@ -84,16 +88,17 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_
             rendered_image, depth_image, out_all_map, radii, rend_dir = VR.view_render(
                 pc._curve_points, pc._width, pc._opacity, pc._mask if use_mask else None, screenspace_points, pc.is_bezier,
                 pc.n_gaussians, mask_thr, bg_color, viewpoint_camera, tanfovx, tanfovy, static_bucket_cap, status_sink,
-                clamp and fold, compute_rend_dir and fold)
+                clamp and fold, compute_rend_dir and fold, pend, getattr(pc, "_derived_eps", 1e-8))
             try:
                 pkg = _package(viewpoint_camera, pc, rendered_image, radii, depth_image, out_all_map, screenspace_points,
                                use_trained_exp, clamp and not fold, compute_rend_dir and not fold, False)
             except Exception:
-                VR.finish()   # (use_trained_exp on a one-channel image raises like the reference: no forward left outstanding)
+                # (use_trained_exp on a one-channel image raises like the reference: no forward left outstanding)
+                VR.finish(pend.pop() if pend else None)
                 raise
             if compute_rend_dir and fold:
                 pkg["rend_dir"] = rend_dir
-            ok, n_visible = VR.finish()
+            ok, n_visible = VR.finish(pend.pop() if pend else None)
             if ok:
                 break
             # a tile list outgrew its bucket (first view of a new scene, or a much denser one): the capacity has been raised

@@ -306,8 +306,10 @@ class GaussianCurveModel:
             self._curve_points, self._width, self.is_bezier, self.n_gaussians, eps)
         # which parameter state the derived tensors belong to: render() takes its fused per-view route (which samples the
         # curves itself) only while they are current, so both routes draw the same splats
+        self._derived_eps = float(eps)
         self._derived_from = (self._curve_points.data_ptr(), self._curve_points._version, self._width.data_ptr(),
-                              self._width._version, tuple(self._curve_points.shape))
+                              self._width._version, tuple(self._curve_points.shape), self.is_bezier.data_ptr(),
+                              self.is_bezier._version)
 
     # ------------------------------------------------------------------ accessors (:66-140)
     @property

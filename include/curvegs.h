@@ -144,8 +144,8 @@ size_t cgs_binning_bytes(int64_t R);
  *     compositors then use closed forms, sum w = 1 - T and dC/dalpha = (1 - bg) T_final / (1 - alpha)); dL_drotation_extra [P,4] or NULL is added to the gradient of the
  *     raw splat rotations before it is pulled back to the curves (the curve-smoothness regulariser enters there).
  *     Outputs: dL_dmeans2D [P,3] (NDC-scaled, feeds add_densification_stats), dL_dcurve_points [B,4,3], dL_dwidth [B,1],
- *     dL_dopacity_logit [B,1], dL_dmask_logit [P] (required iff mask_logit) -- overwritten, or added to when `accumulate`
- *     is non-zero (several views summed into one gradient buffer without extra kernels).  scratch:
+ *     dL_dopacity_logit [B,1], dL_dmask_logit [P] (required iff mask_logit) -- overwritten, or added to when `flags`
+ *     has CGS_VIEW_ACCUMULATE (several views summed into one gradient buffer without extra kernels).  scratch:
  *     cgs_view_backward_scratch_floats(B, m) floats.
  *   cgs_view_forward_checked: the same forward for eager callers (the drop-in render(): gaussian_renderer/__init__.py:18-157
  *     as train.py:95-97 calls it).  Like the reference's forward it reports how much it binned -- but the host only waits for
@@ -172,8 +172,11 @@ int64_t cgs_view_forward_checked(int B, int m, const float* curve_points, const 
                      float* scaling, void* stream);
 /* The same in two halves, so that the caller can queue MORE work behind the forward before it blocks (render() queues its
  * clamp and direction-map kernels, then waits): cgs_view_forward_begin enqueues everything including the status readback and
- * returns; cgs_view_forward_wait blocks on that readback and returns what cgs_view_forward_checked returns.  One forward may be
- * outstanding per host thread. */
+ * returns a HANDLE (>= 0; negative: status code); cgs_view_forward_wait(handle, &n_visible) blocks on that readback, releases
+ * the handle and returns what cgs_view_forward_checked returns (n_visible, optional: splats with radii > 0 -- sizes render()'s
+ * visibility_filter = (radii > 0).nonzero(), gaussian_renderer/__init__.py:150, without a device-wide sync).  Any number of
+ * forwards (threads, devices, streams, models) may be outstanding up to a pool of 64; a handle that will never be waited on
+ * (an exception between the two halves) is returned with cgs_view_forward_abandon. */
 int cgs_view_forward_begin(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
                      float eps, double* norms, const float* opacity_logit, const float* mask_logit, float mask_thr,
                      const float* colors_precomp, void* geometry_buffer, void* binning_buffer, size_t binning_bytes,
@@ -181,7 +184,8 @@ int cgs_view_forward_begin(int B, int m, const float* curve_points, const float*
                      const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
                      float* out_color, float* out_invdepth, float* out_all_map, int* radii, float* xyz, float* rotation,
                      float* scaling, void* stream);
-int64_t cgs_view_forward_wait(void);
+int64_t cgs_view_forward_wait(int handle, int64_t* n_visible);
+void cgs_view_forward_abandon(int handle);
 /* Epilogue of render() on the fused route, /root/reference/gaussian_renderer/__init__.py:138-145 in one launch: color_out [H,W] =
  * clamp ? clamp(color_raw, 0, 1) : color_raw (NULL: skipped); dir_out [3,H,W] = all_map[0:3] taken from view to world space,
  * out_i = sum_k all_map[k] * viewmatrix[4 i + k] (viewmatrix = world_view_transform, row-major 4x4; NULL: skipped).
@@ -190,30 +194,39 @@ int cgs_render_epilogue(int height, int width, const float* color_raw, const flo
                         float* color_out, float* dir_out, void* stream);
 int cgs_clamp_backward(int64_t n, const float* raw, const float* g_in, float* g_out, void* stream);
 uint32_t cgs_bucket_capacity_hint(int P, int width, int height);
-/* Number of splats with radii > 0 in the calling thread's last cgs_view_forward_checked (-1: none yet): lets the caller size
- * render()'s visibility_filter = (radii > 0).nonzero() (gaussian_renderer/__init__.py:150) without a device-wide sync. */
+/* Number of splats with radii > 0 in the calling thread's last cgs_view_forward_checked (-1: none yet); the two-halves form
+ * hands it out through cgs_view_forward_wait. */
 int64_t cgs_last_forward_visible(void);
 /* Several views of ONE parameter state (a view batch between two optimizer steps; not the reference's one-view iteration):
- * with cgs_set_view_shared_sampling(1) cgs_view_forward no longer runs the grid-wide norm pass of prepare_scaling_rot and
- * cgs_view_backward adds its per-splat gradients into `scratch` and skips the last pass of the sampling backward (linear in
- * them); the caller brackets the batch with cgs_view_shared_begin (zeroes norms and scratch, computes the norms once) and
- * cgs_view_shared_end (that last pass, once: dL/dcurve_points, dL/dwidth written or added to).  Every view of the batch must
- * use the SAME norms and scratch buffers; opacity / mask gradients keep coming from cgs_view_backward (accumulate = 1 to sum
- * them over the batch).  The setter is process-wide and returns the previous value. */
-int cgs_set_view_shared_sampling(int on);
+ * cgs_view_forward_shared is cgs_view_forward without the grid-wide norm pass of prepare_scaling_rot, and cgs_view_backward
+ * with CGS_VIEW_SHARED in its flags adds its per-splat gradients into `scratch` and skips the last pass of the sampling
+ * backward (linear in them); the caller brackets the batch with cgs_view_shared_begin (zeroes norms and scratch, computes the
+ * norms once) and cgs_view_shared_end (that last pass, once: dL/dcurve_points, dL/dwidth written or added to).  Every view of
+ * the batch must use the SAME norms and scratch buffers; opacity / mask gradients keep coming from cgs_view_backward
+ * (CGS_VIEW_ACCUMULATE to sum them over the batch).  The mode is chosen per call: no process-wide state. */
+int cgs_view_forward_shared(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
+                     float eps, double* norms, const float* opacity_logit, const float* mask_logit, float mask_thr,
+                     const float* colors_precomp, void* geometry_buffer, void* binning_buffer, size_t binning_bytes,
+                     void* image_buffer, uint32_t bucket_capacity, const float* background, int width_px, int height_px,
+                     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                     float* out_color, float* out_invdepth, float* out_all_map, int* radii, float* xyz, float* rotation,
+                     float* scaling, void* stream);
 int cgs_view_shared_begin(int B, int m, const float* curve_points, const uint8_t* is_bezier, const float* coef, double* norms,
                           float* scratch, void* stream);
 int cgs_view_shared_end(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
                         float eps, double* norms, float* scratch, float* dL_dcurve_points, float* dL_dwidth, int accumulate,
                         void* stream);
 size_t cgs_view_backward_scratch_floats(int B, int m);
+/* flags of cgs_view_backward (a plain 0 / 1 keeps its old meaning: overwrite / accumulate) */
+#define CGS_VIEW_ACCUMULATE 1 /* add to dL_dcurve_points, dL_dwidth, dL_dopacity_logit, dL_dmask_logit instead of writing them */
+#define CGS_VIEW_SHARED 2     /* shared curve sampling of a view batch (above): per-splat gradients go to `scratch` only */
 int cgs_view_backward(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
                       float eps, double* norms, const float* opacity_logit, const float* mask_logit, float mask_thr,
                       const float* colors_precomp, void* geometry_buffer, const void* binning_buffer, const void* image_buffer, const float* background,
                       int width_px, int height_px, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                       float tan_fovx, float tan_fovy, const int* radii, const float* dL_dout_color,
                       const float* dL_drotation_extra, float* dL_dmeans2D, float* dL_dcurve_points, float* dL_dwidth,
-                      float* dL_dopacity_logit, float* dL_dmask_logit, float* scratch, int accumulate, void* stream);
+                      float* dL_dopacity_logit, float* dL_dmask_logit, float* scratch, int flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Curve -> Gaussian sampling.  Replaces GaussianCurveModel.prepare_scaling_rot
@@ -362,21 +375,14 @@ int cgs_set_tile_culling(int on);
 /* A/B switches for measurements (process-wide; each returns the previous setting).
  *   cgs_set_fused_tile_sort: 1 (default) = the sync-free forward sorts each tile's bucket inside the compositor kernel when the
  *     bucket capacity allows; 0 = separate per-tile sort launch.
- *   cgs_set_unit_backward: backward compositor of the unit-colour view path (cgs_view_backward without colors_precomp):
- *     4 (default) = pair-major kernel (lane = (splat, quadrant) pair, csrc/render_unit_bwd.hip), 3 = the pixel-major
- *     k_render_bwd3<UNIT>.  Same results to rounding.  Any other value only queries. */
+ */
 int cgs_set_fused_tile_sort(int on);
-int cgs_set_unit_backward(int variant);
 /*   cgs_set_operator_unit_route: 1 (default) = a cgs_rasterize_backward that is asked for neither colour nor depth / all_map
  *     gradients (the training configuration of the reference's own call, gaussian_renderer/__init__.py:96-129) lets the GPU choose
  *     between the pair-major unit-colour compositor and the general one: the forward's scatter raises a word of the image buffer
  *     when some visible splat's colour or all_map[3] is not exactly 1, and both kernels test it on entry (no host sync; the
  *     forward tags its tile-list entries with quadrant masks whenever P < 2^28).  0 = always the general instance. */
 int cgs_set_operator_unit_route(int on);
-/*   cgs_set_forward_pipeline: 1 = the fused sort + composite forward runs as the persistent prefetcher / walker kernel
- *     (csrc/render_pipe.hip: one wave brings tile t+1 into LDS while four composite tile t); 0 (default) = one workgroup per
- *     tile (k_render_fwd3<.., SORT>).  Bit-identical results.  CGS_FWD_PIPE=1 in the environment sets the initial value. */
-int cgs_set_forward_pipeline(int on);
 /* Introspection of the calling thread's last cgs_rasterize_forward: num_rendered, the longest per-tile list and
  * which binning path produced it (0 = exact count/scan/scatter layout, 1 = single-pass fixed-capacity buckets). */
 /* ------------------------------------------------------------------------------------------------

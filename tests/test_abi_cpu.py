@@ -74,6 +74,32 @@ def test_rasterizer_argument_checks_match_reference():
           rotations=torch.zeros(4, 4), cov3D_precomp=torch.zeros(4, 6))
 
 
+def test_host_shim_loads_and_mirrors_the_reference_pybind_module(monkeypatch):
+    """curve_gaussian_amd._cgs_torch (csrc/torch_shim.cpp) is what `diff_cur_rasterization._C` resolves to: the three entry
+    points of the reference's pybind module (ext.cpp:15-19) with its argument counts, plus the extensions; CGS_TORCH_SHIM=0
+    selects the ctypes bindings over the same library."""
+    from curve_gaussian_amd import _lib
+    from curve_gaussian_amd import diff_cur_rasterization as D
+    shim = _lib.shim()
+    for name in ("rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible", "rasterize_gaussians_static",
+                 "forward_status", "view_forward", "view_backward", "view_wait", "view_abandon"):
+        assert callable(getattr(shim, name)), name
+    assert _lib.use_shim()
+    monkeypatch.setattr(D._ExtProxy, "_impl", None)
+    assert D._C.rasterize_gaussians is shim.rasterize_gaussians
+    # RasterizeGaussiansCUDA takes 22 arguments (rasterize_points.h:18-44): one short is a TypeError before any device work
+    with pytest.raises(TypeError):
+        shim.rasterize_gaussians(*([torch.zeros(3)] * 21))
+    with pytest.raises(RuntimeError, match=r"means3D must have dimensions \(num_points, 3\)"):   # rasterize_points.cu:60-62
+        shim.rasterize_gaussians(torch.zeros(3), torch.zeros(5), torch.ones(5, 1), torch.ones(5, 1), torch.ones(5, 3),
+                                 torch.ones(5, 4), 1.0, torch.empty(0), torch.ones(5, 4), torch.eye(4), torch.eye(4), 0.5, 0.5, 16,
+                                 16, torch.empty(0), 0, torch.zeros(3), False, False, True, False)
+    monkeypatch.setenv("CGS_TORCH_SHIM", "0")
+    monkeypatch.setattr(D._ExtProxy, "_impl", None)
+    assert D._C.mark_visible is not None and isinstance(D._ExtProxy._impl, D._Ext)
+    monkeypatch.setattr(D._ExtProxy, "_impl", None)
+
+
 def test_product_has_no_cpu_fallback():
     from curve_gaussian_amd import _lib
     from curve_gaussian_amd.diff_cur_rasterization import _C
@@ -88,8 +114,10 @@ def test_product_has_no_cpu_fallback():
         sample_curves(torch.zeros(2, 4, 3), torch.zeros(2, 1))
     with pytest.raises(_lib.CurveGSError, match="GPU tensor"):
         distCUDA2(torch.zeros(5, 3))
+    e = torch.empty(0)
     with pytest.raises(RuntimeError, match="means3D must have dimensions"):
-        _C.rasterize_gaussians(torch.zeros(3), torch.zeros(4), *([None] * 20))
+        _C.rasterize_gaussians(torch.zeros(3), torch.zeros(4), e, e, e, e, 1.0, e, e, torch.eye(4), torch.eye(4), 0.5, 0.5, 8, 8, e, 0,
+                               torch.zeros(3), False, False, True, False)
 
 
 def test_sampling_coefficients_match_reference_expressions():

@@ -495,15 +495,17 @@ class _ViewCalls:
         off = int(lib.cgs_image_status_offset(self.W, self.H))
         self.status = self.img[off:off + 4 * int(lib.cgs_status_words())].view(torch.int32)
 
-    def forward(self, want_splats=False, image_only=False):
+    def forward(self, want_splats=False, image_only=False, shared=False):
         """want_splats: also return the model's derived splat tensors (xyz, raw rotation, scaling) the kernels computed;
-        image_only: pass neither inverse depth nor all_map (the image-only instance of the unit-colour forward)."""
+        image_only: pass neither inverse depth nor all_map (the image-only instance of the unit-colour forward); shared:
+        cgs_view_forward_shared (the norm pass was run by cgs_view_shared_begin)."""
         L, lib, pt, cf, cam = self.L, self.lib, self.L.ptr, self.C.c_float, self.cam
         st = L.raw_stream(torch.device(DEV))
         if want_splats:
             self.xyz, self.rot, self.scl = self.f32(self.P, 3), self.f32(self.P, 4), self.f32(self.P, 3)
         sp = (pt(self.xyz), pt(self.rot), pt(self.scl)) if want_splats else (None, None, None)
-        L.check(lib.cgs_view_forward(self.B, self.m, pt(self.cp), pt(self.w), pt(self.isb), pt(self.coef), cf(1e-8),
+        fwd = lib.cgs_view_forward_shared if shared else lib.cgs_view_forward
+        L.check(fwd(self.B, self.m, pt(self.cp), pt(self.w), pt(self.isb), pt(self.coef), cf(1e-8),
                                      pt(self.norms), pt(self.op), None, cf(0.01), pt(self.colors), pt(self.geom), pt(self.binb),
                                      self.nbin, pt(self.img), self.cap, pt(self.bg), self.W, self.H,
                                      pt(cam.world_view_transform), pt(cam.full_proj_transform), pt(cam.camera_center),
@@ -722,14 +724,14 @@ def test_headline_instances_meet_the_raster_criterion_on_identical_inputs(cfg, b
                                                          (333, 211, 2500, 5, 0.2, True, 0.8), (16, 16, 5, 6, 0.0, False, 0.0),
                                                          (64, 48, 110, 7, 0.0, True, 1.5)])
 def test_pair_major_backward_matches_pixel_major(W, H, B, seed, bg, opaque, wide):
-    """The two backward compositors of the unit-colour view path -- pair-major `k_render_bwd_unit` (default) and pixel-major
-    `k_render_bwd3<UNIT>` (cgs_set_unit_backward(3)) -- on the same forward: image sizes that are not multiples of the tile
-    (partial border tiles and quadrants), a single tile, tile lists longer than one 256-entry batch (dense small images), grey
-    background, opacities at the 0.99 clamp (exact walk instead of the clamp-free one), fat splats that fill whole tiles.  The
-    kernels evaluate the same closed form with different exponent roundings (quadrant- vs half-quadrant-centred), so they agree
+    """Two independent implementations of the unit-colour view on the same curves: the view path's own instances (unit-colour
+    forward with the closed-form sums, pair-major `k_render_bwd_unit`) and the GENERAL instances the same entry points run
+    when they are handed an explicit all-ones `colors_precomp` (general forward, untagged lists, pixel-major `k_render_bwd3`
+    with the reference's recurrences).  Cases: image sizes that are not multiples of the tile (partial border tiles and
+    quadrants), a single tile, tile lists longer than one 256-entry batch (dense small images), grey background, opacities at
+    the 0.99 clamp (exact walk instead of the clamp-free one), fat splats that fill whole tiles.  The kernels evaluate the same
+    quantities with different exponent roundings (quadrant- vs half-quadrant-centred) and different arithmetic, so they agree
     to threshold flips: relative L2 and the 1e-4-of-max criterion."""
-    from curve_gaussian_amd import _lib as L
-    lib = L.load()
     curves = S.make_curves(B, seed)
     if opaque:
         curves = _opaque(curves)
@@ -737,29 +739,27 @@ def test_pair_major_backward_matches_pixel_major(W, H, B, seed, bg, opaque, wide
         curves = dict(curves)
         curves["width"] = curves["width"] + wide          # log-width: e^wide times wider splats
     cam = S.make_camera((0.5, -1.5, 0.8), (0.5, 0.5, 0.5), (0, 0, 1), H, W)
-    # (the last case keeps the capacity within the in-kernel sort's reach, so the SORTING forward stages the batches)
-    vc = _ViewCalls(curves["curve_points"], curves["width"], curves["opacity"], curves["is_bezier"], cam,
-                    1024 if seed == 7 else 2048, bg=bg)
     dimg = torch.randn(1, H, W, generator=torch.Generator().manual_seed(seed)).to(DEV)
-    res = {}
-    prev = lib.cgs_set_unit_backward(4)
-    try:
-        for v in (3, 4):
-            lib.cgs_set_unit_backward(v)
-            # poison the binning buffer: every list entry a backward may read has to be WRITTEN by this forward -- batches
-            # the forward never stages (every pixel terminated before them: the last case, opaque lists of > 256 entries) keep
-            # valid, untagged indices, not whatever the buffer held (the pixel-major kernel stages the whole range)
-            vc.binb.fill_(0xFF)
-            vc.forward()
-            g = [vc.f32(vc.B, 4, 3), vc.f32(vc.B, 1), vc.f32(vc.B, 1)]
-            m2d = vc.backward(dimg, *g, 0)
-            res[v] = [m2d.cpu().double()] + [t.cpu().double() for t in g]
-    finally:
-        lib.cgs_set_unit_backward(prev)
+    res, img = {}, {}
+    for v in (3, 4):   # 3: general instances (explicit unit colours), 4: the view path's unit instances
+        # (the last case keeps the capacity within the in-kernel sort's reach, so the SORTING forward stages the batches)
+        vc = _ViewCalls(curves["curve_points"], curves["width"], curves["opacity"], curves["is_bezier"], cam,
+                        1024 if seed == 7 else 2048, bg=bg, colors=torch.ones(B * 12) if v == 3 else None)
+        # poison the binning buffer: every list entry a backward may read has to be WRITTEN by this forward -- batches
+        # the forward never stages (every pixel terminated before them: the last case, opaque lists of > 256 entries) keep
+        # valid, untagged indices, not whatever the buffer held (the pixel-major kernel stages the whole range)
+        vc.binb.fill_(0xFF)
+        vc.forward()
+        img[v] = (vc.color.cpu().numpy(), vc.invd.cpu().numpy(), vc.omap.cpu().numpy())
+        g = [vc.f32(vc.B, 4, 3), vc.f32(vc.B, 1), vc.f32(vc.B, 1)]
+        m2d = vc.backward(dimg, *g, 0)
+        res[v] = [m2d.cpu().double()] + [t.cpu().double() for t in g]
     assert float(res[3][0].abs().max()) > 0
     if seed == 7:
         longest = int(vc.status[5::2][:256].max())
         assert 256 < longest <= 1024, f"case 7 is meant to have tile lists of several batches (longest {longest})"
+    for name, a, b in zip(("color", "invdepth", "all_map"), img[4], img[3]):
+        assert_close(name, a, b, abs_floor=1e-7, outlier_frac=1e-3, tile_cluster=None)
     for name, a, b in zip(("dL_dmeans2D", "curve_points", "width", "opacity"), res[4], res[3]):
         rel = float((a - b).norm() / b.norm().clamp_min(1e-30))
         assert rel < 2e-4, f"{name}: relative L2 {rel:.2e}"
@@ -1089,58 +1089,8 @@ def test_graphed_train_step_crosses_the_connection_phase():
                                    rtol=1e-3, atol=1e-5, err_msg=n)
 
 
-@pytest.mark.parametrize("W,H,B,seed,opaque,wide,cap", [(129, 97, 300, 2, False, 0.0, 1024), (64, 48, 110, 7, True, 1.5, 1024),
-                                                        (333, 211, 2500, 5, True, 0.8, 1024), (16, 16, 5, 6, False, 0.0, 64)])
-def test_persistent_forward_pipeline_is_bit_identical(W, H, B, seed, opaque, wide, cap):
-    """csrc/render_pipe.hip (cgs_set_forward_pipeline(1): persistent workgroups, a prefetcher wave that brings the next tile's
-    keys and -- by direct global -> LDS loads -- records in while four waves composite) against the one-workgroup-per-tile
-    forward on the same buckets: image, inverse depth, all_map, final transmittance, the tagged tile lists (order and quadrant
-    masks) and the backward's gradients, bit for bit.  Cases: partial border tiles, lists of several 256-entry fills with early
-    termination (the prefetcher's wave-local bitonic sort), a dense scene, a single tile."""
-    from curve_gaussian_amd import _lib as L
-    lib = L.load()
-    curves = S.make_curves(B, seed)
-    if opaque:
-        curves = _opaque(curves)
-    if wide:
-        curves = dict(curves)
-        curves["width"] = curves["width"] + wide
-    cam = S.make_camera((0.5, -1.5, 0.8), (0.5, 0.5, 0.5), (0, 0, 1), H, W)
-    dimg = torch.randn(1, H, W, generator=torch.Generator().manual_seed(seed)).to(DEV)
-    res = {}
-    prev = lib.cgs_set_forward_pipeline(0)
-    try:
-        for mode in (0, 1):
-            lib.cgs_set_forward_pipeline(mode)
-            vc = _ViewCalls(curves["curve_points"], curves["width"], curves["opacity"], curves["is_bezier"], cam, cap)
-            vc.binb.fill_(0xFF)
-            vc.forward()
-            tiles = ((W + 15) // 16) * ((H + 15) // 16)
-            lists = vc.binb[:4 * cap * tiles].view(torch.int32).reshape(tiles, cap).clone()
-            counts = torch.minimum(vc.status[4:4 + 512:2].sum(), torch.tensor(1 << 30))   # (num_rendered: same buckets either way)
-            g = [vc.f32(vc.B, 4, 3), vc.f32(vc.B, 1), vc.f32(vc.B, 1)]
-            m2d = vc.backward(dimg, *g, 0)
-            res[mode] = dict(color=vc.color.clone(), invd=vc.invd.clone(), omap=vc.omap.clone(), T=vc.final_T(), lists=lists,
-                             R=int(counts), m2d=m2d)
-    finally:
-        lib.cgs_set_forward_pipeline(prev)
-    a, b = res[0], res[1]
-    assert a["R"] == b["R"] and a["R"] > 0
-    for k in ("color", "invd", "omap", "T"):
-        assert torch.equal(a[k], b[k]), k
-    # every entry the per-tile kernel wrote is written identically (it leaves entries behind a fully terminated tile's last
-    # staged batch untagged; the pipeline tags every entry -- ids agree everywhere)
-    ida, idb = a["lists"] & 0x0FFFFFFF, b["lists"] & 0x0FFFFFFF
-    written = a["lists"] != -1
-    assert torch.equal(ida[written], idb[written])
-    tagged = written & ((a["lists"] >> 28) != 0)
-    assert torch.equal(a["lists"][tagged], b["lists"][tagged])
-    rel = float((a["m2d"] - b["m2d"]).norm() / a["m2d"].norm().clamp_min(1e-30))
-    assert rel < 1e-4, f"backward on the two forwards' lists: {rel:.2e}"   # (float atomics order; same lists)
-
-
 def test_shared_sampling_over_a_view_batch_gives_the_summed_gradient():
-    """cgs_set_view_shared_sampling(1) + cgs_view_shared_begin / _end: the grid-wide norm pass and the last pass of the sampling
+    """cgs_view_forward_shared / CGS_VIEW_SHARED + cgs_view_shared_begin / _end: the grid-wide norm pass and the last pass of the sampling
     backward once per view BATCH (same parameters for every view of it) instead of once per view.  The batch gradient must be
     the sum of the per-view gradients of the default mode -- that backward pass is linear in the per-splat gradients."""
     import ctypes as C
@@ -1156,21 +1106,17 @@ def test_shared_sampling_over_a_view_batch_gives_the_summed_gradient():
 
     def batch(shared):
         g = [vc.f32(vc.B, 4, 3), vc.f32(vc.B, 1), vc.f32(vc.B, 1)]
-        prev = lib.cgs_set_view_shared_sampling(1 if shared else 0)
-        try:
-            if shared:
-                L.check(lib.cgs_view_shared_begin(vc.B, vc.m, pt(vc.cp), pt(vc.isb), pt(vc.coef), pt(vc.norms), pt(vc.scratch), st),
-                        "cgs_view_shared_begin")
-            for cam, d in zip(cams, dimgs):
-                vc.cam = cam
-                vc.forward()
-                vc.backward(d, *g, 1)
-            if shared:
-                L.check(lib.cgs_view_shared_end(vc.B, vc.m, pt(vc.cp), pt(vc.w), pt(vc.isb), pt(vc.coef), C.c_float(1e-8),
-                                                pt(vc.norms), pt(vc.scratch), pt(g[0]), pt(g[1]), 0, st), "cgs_view_shared_end")
-            torch.cuda.synchronize()
-        finally:
-            lib.cgs_set_view_shared_sampling(prev)
+        if shared:
+            L.check(lib.cgs_view_shared_begin(vc.B, vc.m, pt(vc.cp), pt(vc.isb), pt(vc.coef), pt(vc.norms), pt(vc.scratch), st),
+                    "cgs_view_shared_begin")
+        for cam, d in zip(cams, dimgs):
+            vc.cam = cam
+            vc.forward(shared=shared)
+            vc.backward(d, *g, 3 if shared else 1)    # CGS_VIEW_ACCUMULATE [| CGS_VIEW_SHARED]
+        if shared:
+            L.check(lib.cgs_view_shared_end(vc.B, vc.m, pt(vc.cp), pt(vc.w), pt(vc.isb), pt(vc.coef), C.c_float(1e-8),
+                                            pt(vc.norms), pt(vc.scratch), pt(g[0]), pt(g[1]), 0, st), "cgs_view_shared_end")
+        torch.cuda.synchronize()
         return [t.cpu().double() for t in g]
 
     ref, got = batch(False), batch(True)

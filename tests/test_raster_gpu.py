@@ -81,7 +81,7 @@ def assert_radii(got, ref):
         assert (np.abs(got[bad].astype(np.int64) - ref[bad]) == 1).all() and (got[bad] > 0).all() and (ref[bad] > 0).all()
 
 
-def compare(sp, cam, bg, grads, grad_outlier_frac=None, **kw):
+def compare(sp, cam, bg, grads, grad_outlier_frac=None, grad_outlier_frac_big=None, **kw):
     fw = oracle_forward(sp, cam, bg, **{k: v for k, v in kw.items() if k not in ("debug", "colour_grad")})
     hip = run_hip(sp, cam, bg, grads, **kw)
     assert_radii(hip["radii"], fw.radii)
@@ -104,9 +104,9 @@ def compare(sp, cam, bg, grads, grad_outlier_frac=None, **kw):
                 ref = flat.reshape(Pn, Mn, 3).sum(-1)
                 v = v.reshape(Pn, Mn)
             if grad_outlier_frac is None:
-                assert_close(k, v, ref, abs_floor=1e-6)
+                assert_close(k, v, ref, abs_floor=1e-6, outlier_frac_big=grad_outlier_frac_big)
             else:
-                assert_close(k, v, ref, abs_floor=1e-6, outlier_frac=grad_outlier_frac)
+                assert_close(k, v, ref, abs_floor=1e-6, outlier_frac=grad_outlier_frac, outlier_frac_big=grad_outlier_frac_big)
     fw.free()
     return hip
 
@@ -710,7 +710,13 @@ def test_baseline_config_training_instance_matches_oracle(cfg, P):
     # of 1/255 (or whose pixel's T sits within rounding of 1e-4) and lands on the other side of the test than in the
     # oracle's expf arithmetic; each such flip moves that splat's gradient by a whole pixel's contribution.  Measured
     # 1.03e-4 of the dL/dopacity elements, identical for every kernel instance and for the round-1 kernels: 2e-4 allowed.
-    compare(sp, cam, torch.zeros(3), g, debug=False, colour_grad=False, grad_outlier_frac=2e-4 if cfg == "cfg5" else None)
+    # The RELATIVE criterion on the elements above 1 % of the maximum sees the same flips from closer up (every pixel of this
+    # view terminates, and a flipped termination moves every splat of that pixel by up to a factor 1 - alpha): XX
+    # of the elements of a gradient tensor beyond 1e-3 relative, 0.5e-4 .. 1.1e-4 beyond 1e-2 -- the same counts for the general
+    # pixel-major instance and the gated pair-major unit instance (scratch diagnostic of round 5; unit vs general on the same
+    # forward: 4e-5 relative L2).  cfg2 - cfg4 stay on the default budget.
+    compare(sp, cam, torch.zeros(3), g, debug=False, colour_grad=False, grad_outlier_frac=2e-4 if cfg == "cfg5" else None,
+            grad_outlier_frac_big=6e-4 if cfg == "cfg5" else None)
     # grey background: the bg term of dL/dalpha (backward.cu:649-652) at full size.  (Not white: with unit colours the image
     # would be sum w + T_final = 1 wherever no pixel terminated and every gradient would cancel to rounding noise.)
     if cfg == "cfg3":

@@ -98,17 +98,98 @@ def test_stale_derived_tensors_send_render_down_the_general_route(monkeypatch):
     assert len(calls) == 1 and not torch.equal(stale, fresh)
 
 
-def test_fused_route_refuses_gradients_it_cannot_propagate():
-    from curve_gaussian_amd._lib import CurveGSError
+@pytest.mark.parametrize("use_mask", [False, True])
+def test_fused_route_serves_depth_and_normal_losses(use_mask):
+    """A loss on depth / rend_dir / rend_alpha through the DEFAULT render() (the reference's rasterizer backward takes
+    grad_out_depth and grad_out_all_map, diff_cur_rasterization/__init__.py:117-151): the fused node's backward re-renders the
+    view through the general operator route and pulls every upstream gradient through it -- same gradients as fused=False,
+    and a loss on `render` alone afterwards still takes the fast backward."""
     from curve_gaussian_amd.gaussian_renderer import PipelineParams, render
-    c, mask, cam = _small(B=60)
+    c, mask, cam = _small(B=200)
+    cam = cam.to(DEV)
+    H, W = cam.image_height, cam.image_width
+    bg = torch.zeros(3, device=DEV)
+    g = torch.Generator().manual_seed(11)
+    w_img, w_d, w_n, w_a = (torch.randn(s_, generator=g).to(DEV) for s_ in ((1, H, W), (1, H, W), (3, H, W), (1, H, W)))
+    grads = {}
+    for route in (None, False):
+        gm = _model(c, mask)
+        pkg = render(cam, gm, PipelineParams(), bg, use_mask=use_mask, mask_thr=0.3, fused=route)
+        loss = ((pkg["render"] * w_img).sum() + (pkg["depth"] * w_d).sum() + (pkg["rend_dir"] * w_n).sum()
+                + (pkg["rend_alpha"] * w_a).sum())
+        loss.backward()
+        names = ("_curve_points", "_width", "_opacity") + (("_mask",) if use_mask else ())
+        grads[route] = {n: getattr(gm, n).grad.clone() for n in names}
+        grads[route]["means2D"] = pkg["viewspace_points"].grad.clone()
+    for n, a in grads[None].items():
+        b = grads[False][n]
+        assert float(b.abs().max()) > 0, n
+        rel = float((a - b).norm() / b.norm())
+        assert rel < 2e-5, f"{n}: fused-route backward (general recomputation) vs general route: relative L2 {rel:.2e}"
+    # depth alone (no gradient at `render`)
     gm = _model(c, mask)
-    pkg = render(cam.to(DEV), gm, PipelineParams(), torch.zeros(3, device=DEV))
-    with pytest.raises(CurveGSError, match="fused=False"):
-        (pkg["render"].sum() + pkg["rend_alpha"].sum()).backward()
-    pkg = render(cam.to(DEV), gm, PipelineParams(), torch.zeros(3, device=DEV), fused=False)
-    (pkg["render"].sum() + pkg["rend_alpha"].sum() + pkg["depth"].sum()).backward()     # the general route takes them
-    assert gm._curve_points.grad.abs().max() > 0
+    pkg = render(cam, gm, PipelineParams(), bg)
+    (pkg["depth"] * w_d).sum().backward()
+    gm2 = _model(c, mask)
+    pkg2 = render(cam, gm2, PipelineParams(), bg, fused=False)
+    (pkg2["depth"] * w_d).sum().backward()
+    rel = float((gm._curve_points.grad - gm2._curve_points.grad).norm() / gm2._curve_points.grad.norm())
+    assert rel < 2e-5, rel
+
+
+def test_fused_route_resamples_with_the_eps_of_prepare_scaling_rot(monkeypatch):
+    """prepare_scaling_rot(eps) stamps the eps it used; the fused route (which samples the curves itself) renders with it, so
+    both routes draw the same splats for any eps."""
+    from curve_gaussian_amd.gaussian_renderer import PipelineParams, render
+    c, mask, cam = _small(B=120)
+    cam = cam.to(DEV)
+    bg = torch.zeros(3, device=DEV)
+    gm = _model(c, mask)
+    gm.prepare_scaling_rot(eps=0.5)      # (an absurd eps: changes rotations / scalings visibly)
+    calls = _count_fused_calls(monkeypatch)
+    a = render(cam, gm, PipelineParams(), bg)
+    assert len(calls) >= 1
+    b = render(cam, gm, PipelineParams(), bg, fused=False)
+    assert torch.equal(a["radii"], b["radii"])
+    assert_close("render", a["render"].detach().cpu().numpy(), b["render"].detach().cpu().numpy())
+    gm.prepare_scaling_rot()
+    d = render(cam, gm, PipelineParams(), bg)
+    assert not torch.equal(a["render"], d["render"])
+
+
+def test_two_models_interleave_their_fused_forwards():
+    """Pending forwards are carried by handle (cgs_view_forward_begin -> cgs_view_forward_wait(handle)): two view_render calls
+    of different models / image sizes begun back to back and finished in the opposite order do not disturb each other."""
+    from curve_gaussian_amd.gaussian_renderer import PipelineParams, render
+    from curve_gaussian_amd.ops import view_render as VR
+    c1, mask1, cam1 = _small(B=150, seed=5)
+    c2, mask2, cam2 = _small(B=260, seed=6, H=64, W=80)
+    gm1, gm2 = _model(c1, mask1), _model(c2, mask2)
+    cam1, cam2 = cam1.to(DEV), cam2.to(DEV)
+    bg = torch.zeros(3, device=DEV)
+    ref1 = render(cam1, gm1, PipelineParams(), bg)["render"].clone()   # (also sizes the buckets of both shapes)
+    ref2 = render(cam2, gm2, PipelineParams(), bg)["render"].clone()
+
+    def begin(gm, cam):
+        pend = []
+        z = torch.zeros_like(gm.get_xyz, requires_grad=True)
+        out = VR.view_render(gm._curve_points, gm._width, gm._opacity, None, z, gm.is_bezier, gm.n_gaussians, 0.01, bg, cam,
+                             *tanfov(cam), 0, None, True, False, pend)
+        return out[0], pend[0]
+    img1, p1 = begin(gm1, cam1)
+    img2, p2 = begin(gm2, cam2)
+    ok2, n2 = VR.finish(p2)
+    ok1, n1 = VR.finish(p1)
+    assert ok1 and ok2
+    assert n1 == int((render(cam1, gm1, PipelineParams(), bg)["radii"] > 0).sum())
+    assert torch.equal(img1, ref1) and torch.equal(img2, ref2)
+    assert VR.finish(p1) == (True, -1)                  # a finished handle is inert
+    # a dropped Pending gives its slot back (no leak after many abandoned forwards)
+    for _ in range(200):
+        _img, p = begin(gm2, cam2)
+        del p
+    img2b, p2b = begin(gm2, cam2)
+    assert VR.finish(p2b)[0] and torch.equal(img2b, ref2)
 
 
 def test_fused_route_grows_its_buckets_and_remembers_the_capacity():

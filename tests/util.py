@@ -57,7 +57,7 @@ BIG_FRAC = 1e-2         # ... those above this fraction of the tensor's maximum
 
 
 def assert_close(name, a, b, rel=REL_TOL, outlier_frac=OUTLIER_FRAC, abs_floor=None, max_outlier=None, tile_cluster=8,
-                 rel_big=REL_BIG, big_frac=BIG_FRAC):
+                 rel_big=REL_BIG, big_frac=BIG_FRAC, outlier_frac_big=None):
     """|a - b| <= rel * max|b| on all but `outlier_frac` of the elements -- the budget for alpha >= 1/255 and T < 1e-4 decisions
     that flip under a different rounding of the exponent -- AND the budget is capped in magnitude and in space:
 
@@ -74,16 +74,19 @@ def assert_close(name, a, b, rel=REL_TOL, outlier_frac=OUTLIER_FRAC, abs_floor=N
     assert frac <= outlier_frac, f"{name}: {frac:.2e} of elements exceed rel tol {rel} (worst normalised err {worst:.3e})"
     # `rel * max|b|` is an ABSOLUTE tolerance: an element at 1 % of the maximum may be off by 1 % of itself and pass.  So, on top:
     # every element above big_frac of the maximum agrees to rel_big RELATIVE to itself, within the same outlier budget
-    # (counted against the whole tensor, like the flips above).  Elements below big_frac of the maximum are held by the
+    # (counted against the whole tensor, like the flips above; `outlier_frac_big` when the caller measured another budget for
+    # this criterion).  Elements below big_frac of the maximum are held by the
     # absolute criterion only: their relative error is dominated by cancellation in sums the two sides order differently.
+    if outlier_frac_big is None:
+        outlier_frac_big = outlier_frac
     if rel_big is not None and a.size:
         scale = np.abs(b).max()
         big = np.abs(b) > big_frac * scale
         bad_rel = big & (np.abs(a - b) > rel_big * np.abs(b))
         n_bad = int(bad_rel.sum())
-        assert n_bad <= outlier_frac * a.size, (
+        assert n_bad <= outlier_frac_big * a.size, (
             f"{name}: {n_bad} of {int(big.sum())} elements above {big_frac:g} of the maximum differ by more than {rel_big:g} "
-            f"relative (budget {outlier_frac * a.size:.1f}); worst {float((np.abs(a - b)[big] / np.abs(b)[big]).max()):.3e}")
+            f"relative (budget {outlier_frac_big * a.size:.1f}); worst {float((np.abs(a - b)[big] / np.abs(b)[big]).max()):.3e}")
     image_like = a.ndim == 3 and a.shape[1] >= 16 and a.shape[2] >= 16
     if max_outlier is None and image_like:
         max_outlier = MAX_OUTLIER["image"]
