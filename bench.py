@@ -86,6 +86,97 @@ def committed_profile(config):
 
 ISSUE_PEAK_G = 1024 * 2.4 / 2.0   # G wave-instructions/s: 1024 SIMDs, 2.4 GHz, 2 cycles per wave64 FMA-class instruction
 
+# ------------------------------------------------------------------------------------------------ operator-API instances
+# Kernel times of the rasterizer instances the OPERATOR API reaches (GaussianRasterizer, the reference's own call shape,
+# diff_cur_rasterization/__init__.py:46-151), measured with the library's own HIP events (cgs_prof_*).  Cases (upstream
+# gradients / what requires grad):
+#   reference_call    colours == 1 without grad, only dL/dcolour flowing in (gaussian_renderer/__init__.py:96-129) -> the gated
+#                     pair-major unit kernel
+#   training_general  the same call with the unit route switched off (cgs_set_operator_unit_route(0)) -> k_render_bwd3<0,0,0>
+#   colour_grad       arbitrary colours that require grad, dL/dcolour only                            -> k_render_bwd3<0,0,1>
+#   colour_allmap     ... + dL/dall_map                                                               -> k_render_bwd3<1,0,1>
+#   all_grad          ... + dL/dinvdepth + dL/dall_map                                                -> k_render_bwd3<1,1,1>
+CASES = ("reference_call", "training_general", "colour_grad", "colour_allmap", "all_grad")
+
+
+def config_splats(cfg, dev, view=0):
+    """Splat tensors of one view of a BASELINE config, made by the product's own sampling / attribute kernels."""
+    from curve_gaussian_amd import synthetic as S
+    from curve_gaussian_amd.ops.curve_sampling import sample_curves, splat_attributes
+    curves, cams = S.make_config(cfg, n_views=max(view + 1, 1))
+    cam = cams[view].to(dev)
+    c = {k: v.to(dev) for k, v in curves.items()}
+    xyz, rot, scl = sample_curves(c["curve_points"], c["width"], c["is_bezier"], 12)
+    rotn, opac, scales, amap = splat_attributes(rot, xyz, c["opacity"], scl, cam.camera_center, cam.world_view_transform, 12,
+                                                None, 0.01)
+    return dict(means3D=xyz.detach(), rotations=rotn.detach(), opacities=opac.detach(), scales=scales.detach(),
+                all_map=amap.detach()), cam
+
+
+def time_instances(cfg="cfg3", n_rep=6, cases=CASES, dev=None):
+    import math
+
+    from curve_gaussian_amd import _lib as L
+    from curve_gaussian_amd.diff_cur_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    dev = dev or torch.device("cuda:0")
+    lib = L.load()
+    sp, cam = config_splats(cfg, dev)
+    P = sp["means3D"].shape[0]
+    H, W = cam.image_height, cam.image_width
+    rs = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+        bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+        projmatrix=cam.full_proj_transform, sh_degree=0, campos=cam.camera_center, prefiltered=False, debug=False,
+        antialiasing=False, render_geo=True)
+    g = torch.Generator().manual_seed(5)
+    dcol = (torch.randn(1, H, W, generator=g) * 1e-3).to(dev)
+    dinv = (torch.randn(1, H, W, generator=g) * 1e-3).to(dev)
+    damap = (torch.randn(4, H, W, generator=g) * 1e-3).to(dev)
+    rand_col = torch.rand(P, 1, generator=g).to(dev)
+    out = {}
+    for case in cases:
+        unit = case in ("reference_call", "training_general")
+        prev = lib.cgs_set_operator_unit_route(0 if case == "training_general" else 1)
+        colors = torch.ones(P, 1, device=dev) if unit else rand_col.clone().requires_grad_(True)
+        ins = {k: v.clone().requires_grad_(True) for k, v in sp.items()}
+        m2d = torch.zeros(P, 3, device=dev, requires_grad=True)
+        rast = GaussianRasterizer(rs)
+
+        def once():
+            color, radii, invd, amap = rast(means3D=ins["means3D"], means2D=m2d, opacities=ins["opacities"],
+                                            colors_precomp=colors, scales=ins["scales"], rotations=ins["rotations"],
+                                            all_map=ins["all_map"])
+            loss = (color * dcol).sum()
+            if case == "all_grad":
+                loss = loss + (invd * dinv).sum()
+            if case in ("all_grad", "colour_allmap"):
+                loss = loss + (amap * damap).sum()
+            loss.backward()
+
+        # (the first case also warms the clocks up: an idle GPU runs the first few dozen launches 10 % slower)
+        for _ in range(30 if case == cases[0] else 3):
+            once()
+        torch.cuda.synchronize()
+        lib.cgs_prof_reset()
+        lib.cgs_prof_enable(1)
+        for _ in range(n_rep):
+            once()
+        torch.cuda.synchronize()
+        lib.cgs_prof_enable(0)
+        prof = L.prof_collect()
+        lib.cgs_prof_reset()
+        lib.cgs_set_operator_unit_route(prev)
+        out[case] = {k: round(ms / max(n, 1) * 1e3, 1) for k, (ms, n) in sorted(prof.items())}
+    stats = lib.cgs_last_forward_stats
+    import ctypes as C
+    R, longest, path = C.c_int64(), C.c_int64(), C.c_int()
+    stats(C.byref(R), C.byref(longest), C.byref(path))
+    out["_workload"] = {"config": cfg, "splats": P, "width": W, "height": H, "instances_R": int(R.value),
+                        "binning_path": int(path.value)}
+    return out
+
+
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -103,6 +194,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true")
     ap.add_argument("--no-train-step", action="store_true")
+    ap.add_argument("--no-general-route", action="store_true",
+                    help="skip the `general_route` block (kernel times of the operator-API instances, GaussianRasterizer)")
+    ap.add_argument("--all-configs", action="store_true",
+                    help="after the run, also run cfg1..cfg5 (one child process each, N = 1, short) and attach a compact "
+                         "`all_configs` block: value, ms per view, whole-path roofline fraction, train step, drop-in view")
     ap.add_argument("--cpu-views", type=int, default=6)
     ap.add_argument("--torch-cpu-splats", type=int, default=48,
                     help="cfg1 only: splats of the bounded sample the pure-PyTorch CPU rasterizer (oracle/torch_ref.py) is timed on")
@@ -749,6 +845,15 @@ def main():
                                          "peak_note": "1024 SIMDs x 2.4 GHz / 2 cycles (wave64 v_fma_f32); 4-cycle "
                                                       "instructions (v_cmp, v_cndmask, integer) halve it: a mix at "
                                                       "simd_cycles_per_valu_instr ~3 is issue-saturated"}
+            bi = prof["pmc"].get("render_bwd", {}) if prof is not None else {}
+            if "SQ_INSTS_VALU" in bi and "render_bwd" in kernel_ms and dom != "render_bwd":
+                rate_b = bi["SQ_INSTS_VALU"] / (kernel_ms["render_bwd"] * 1e-3) / 1e9
+                out["issue_roofline_render_bwd"] = {
+                    "bound": "valu-issue", "kernel": "render_bwd", "source": prof["source"],
+                    "valu_wave_instr_per_launch": int(bi["SQ_INSTS_VALU"]), "salu_instr_per_launch": int(bi.get("SQ_INSTS_SALU", 0)),
+                    "lds_instr_per_launch": int(bi.get("SQ_INSTS_LDS", 0)), "achieved": round(rate_b, 1),
+                    "peak": round(ISSUE_PEAK_G, 1), "unit": "G wave-instr/s", "frac": round(rate_b / ISSUE_PEAK_G, 4),
+                    "simd_cycles_per_valu_instr": round(1024 * 2.4 / rate_b, 3)}
         out["kernel_ms_per_view"] = {k: round(v, 5) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])}
         if shared is not None:
             out["shared_sampling"] = shared
@@ -798,6 +903,39 @@ def main():
                               "image per view, eager (fused view route: cgs_view_forward_checked / cgs_view_backward); "
                               "..._no_visibility: without the nonzero() host sync and the world-space direction map; "
                               "..._general_route: fused=False (GaussianRasterizer, the round-3 drop-in path)")
+        if not args.no_general_route:
+            # ---- what the reference's own GaussianRasterizer call reaches: kernel times per instance, the
+            # backward compositor's HBM-roofline fraction on K8's algorithmic bytes, and the whole operator route
+            gi = time_instances(args.config, 6, dev=dev)
+            wl = gi.pop("_workload")
+            Rg = float(wl["instances_R"])
+            k8 = KERNEL_ALG_BYTES["render_bwd"](P, Rg, H * W, tiles)
+            inst = {}
+            for case, ks in gi.items():
+                bwd_us = ks.get("render_bwd_unit_gated", 0.0) + ks.get("render_bwd", 0.0)
+                inst[case] = {"render_bwd_us": round(bwd_us, 1), "render_fwd_us": ks.get("render_fwd"),
+                              "sum_kernel_us": round(sum(ks.values()), 1),
+                              "render_bwd_hbm_frac": round(k8 / (bwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+            ref = gi["reference_call"]
+            ref_sum_us = sum(ref.values())
+            alg_ref_call = algorithmic_bytes(P, Rg, H, W)
+            out["general_route"] = {
+                "what": "GaussianRasterizer (operator API) on one view of this config: per-kernel times (us, HIP events, serial) "
+                        "of the instance each kind of upstream gradient reaches; reference_call = the reference's own call "
+                        "(unit colours without grad, only d/dcolour): device-side verdict -> pair-major unit backward",
+                "instances_R": int(Rg),
+                "instances": inst,
+                "kernels_us": gi,
+                "roofline": {"bound": "hbm", "kernel": "render_bwd (reference_call: k_render_bwd_unit, gated)",
+                             "achieved": round(k8 / (inst["reference_call"]["render_bwd_us"] * 1e-6) / 1e9, 2),
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": inst["reference_call"]["render_bwd_hbm_frac"],
+                             "traffic": None, "algorithmic_bytes_per_launch": int(k8),
+                             "kernel_ms": round(inst["reference_call"]["render_bwd_us"] * 1e-3, 5)},
+                "whole_route_reference_call": {"sum_kernel_ms": round(ref_sum_us * 1e-3, 5),
+                                               "algorithmic_bytes_per_view": int(alg_ref_call),
+                                               "hbm_roofline_frac": round(alg_ref_call / (ref_sum_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                                               "eager_ms_per_view": out.get("dropin_view_general_route_ms")},
+            }
         for prm in (gm._curve_points, gm._width, gm._opacity, gm._mask):
             prm.grad = None
         ts = TrainStep(gm, tcams, gts)
@@ -977,6 +1115,28 @@ def main():
                 "sample": f"{S_} of the view's {P} splats over the full {W}x{H} image, oracle/torch_ref.dense_render + autograd "
                           f"(dense P x H x W: cost per splat does not depend on its footprint), torch.set_num_threads({threads}), "
                           f"{tp2 - tp0:.1f} s"}
+    if args.all_configs and world == 1:
+        # one child per BASELINE config on this same GPU, after everything above is done with it: the headline fields of each
+        # line, compact (the children skip the CPU baseline and the operator-instance block; their timed region is shorter)
+        import subprocess
+        allc = {}
+        for cfg in ("cfg1", "cfg2", "cfg3", "cfg4", "cfg5"):
+            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", cfg, "--steps", "8", "--warmup", "2",
+                   "--min-seconds", "1.0", "--no-cpu-baseline", "--no-general-route"]
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+            r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                allc[cfg] = {"error": (r.stderr or r.stdout)[-300:]}
+                continue
+            j = json.loads(line[-1])
+            allc[cfg] = {"value": j["value"], "ms_per_view": j["ms_per_view"],
+                         "whole_path_hbm_frac": j.get("whole_path", {}).get("hbm_roofline_frac"),
+                         "serial_view_graph_ms": j.get("serial_view_graph_ms"), "train_step_ms": j.get("train_step_ms"),
+                         "train_step_eager_ms": j.get("train_step_eager_ms"), "dropin_view_ms": j.get("dropin_view_ms"),
+                         "dropin_view_general_route_ms": j.get("dropin_view_general_route_ms"),
+                         "splats": j["config"]["splats"], "instances_per_view_R": j["config"]["instances_per_view_R"]}
+        out["all_configs"] = allc
     if dist is not None:
         dist.destroy_process_group()
     try:   # RCCL writes its banner through C stdio: flush that buffer so the JSON line is the LAST line on stdout

@@ -66,6 +66,9 @@ static std::atomic<int> g_tile_cull{1};   // exact tile-level culling of (splat,
 //   big   splats with oversized tile rects seen by the previous blocking forward: non-zero switches their deferral to
 //         k_scatter_big on (one more launch, only worth it when there are any -- room-scale scenes with near-camera splats)
 struct BinHints { int64_t R = 0, max = 0, big = 0; };
+// bucket scatter: splats per wave from the instance count the shape binned last time (profiles/r04_experiments.md #19: 12 wins
+// at cfg3 / cfg5 -- 1.6 M / 8 M instances --, 8 at cfg2 / cfg4 -- 0.4 M / 0.17 M)
+static inline int scatter_spw(const BinHints& h) { return (h.R > 0 && h.R < 800000) ? 8 : 12; }
 struct HintEntry { int P = -1, W = 0, H = 0; uint64_t stamp = 0; BinHints h; };
 static std::mutex g_hint_mu;
 static HintEntry g_hint_tab[32];
@@ -165,6 +168,31 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 }  // namespace cgs
 
 using namespace cgs;
+
+// Longest tile list of a finished scatter, for the checked (blocking) view forward: one small launch between the scatter
+// and the compositor, so the host's wait ends when the BINNING is done and the compositor is still running.
+__global__ void __launch_bounds__(256) k_count_stats(const uint32_t* __restrict__ tile_count, int tiles, const int* __restrict__ radii,
+                                                     int P, const uint32_t* __restrict__ big, uint32_t* __restrict__ out4) {
+    uint32_t mx = 0, sum = 0, vis = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < tiles; i += gridDim.x * 256) {
+        const uint32_t c = tile_count[i];
+        mx = max(mx, c);
+        sum += c;
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256) vis += radii[i] > 0 ? 1u : 0u;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
+        sum += (uint32_t)__shfl_xor((int)sum, off, 64);
+        vis += (uint32_t)__shfl_xor((int)vis, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out4[0], sum);   // num_rendered
+        atomicMax(&out4[1], mx);    // longest tile list
+        atomicAdd(&out4[2], vis);   // splats with radii > 0 (sizes render()'s visibility_filter without a host sync)
+        if (blockIdx.x == 0 && threadIdx.x == 0) out4[3] = *big;   // splats with oversized tile rects (final after the scatter)
+    }
+}
 
 extern "C" {
 
@@ -348,19 +376,33 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
             BinState bin = bin_from_chunk(bchunk, (size_t)(cap * tiles));
             const bool defer_big = hints.big > 0;
             launch_scatter_bucket(s, P, radii, geom.rec, gx, gy, img.tile_count, bin.keys, (uint32_t)cap, cull, img.total + 3,
-                                  defer_big ? img.tile_cursor : nullptr, (uint32_t)tiles, nonunit);   // (cursors: unused here)
-            // (the fused sort+composite kernel is for the sync-free forward only: here num_rendered has to come back to
-            // the host, and with the separate sort kernel that readback overlaps the compositor instead of following it)
-            launch_tile_sort_bucket(s, tiles, img.tile_count, img.ranges, img.total, bin.keys, bin.point_list, (uint32_t)cap);
-            if (!read_totals()) return CGS_ERR_HIP;
-            if (!render(bin.point_list)) return CGS_ERR_HIP;
-            if (!wait_totals()) return CGS_ERR_HIP;
-            int64_t Rb = 0;
-            uint32_t longest = 0;
-            for (int k = 0; k < TOTAL_PARTS; k++) {
-                Rb += (int64_t)h_tot[4 + 2 * k];
-                longest = std::max(longest, h_tot[5 + 2 * k]);
+                                  defer_big ? img.tile_cursor : nullptr, (uint32_t)tiles, nonunit, scatter_spw(hints));   // (cursors: unused here)
+            // num_rendered (part of the reference's return value) and the longest tile list are known once the SCATTER is done:
+            // one small launch reduces the tile histogram, 16 bytes travel to the host, and the forward compositor -- which
+            // sorts every tile's bucket itself, like the sync-free forward's -- is queued behind them before the host waits.
+            // (Round 4 ran a separate sort launch here so that the readback could follow it: 30 us of kernel per view.)
+            uint32_t* const stat = img.work + 4;   // four words of the (cleared) work block
+            hipLaunchKernelGGL(k_count_stats, dim3(64), dim3(256), 0, s, img.tile_count, tiles, radii, P, img.total + 3, stat);
+            {
+                hipError_t e = hipMemcpyAsync(h_tot, stat, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+                if (e == hipSuccess) e = hipEventRecord(ev, s);
+                if (e != hipSuccess) {
+                    set_error("reading num_rendered failed: %s", hipGetErrorString(e));
+                    return CGS_ERR_HIP;
+                }
             }
+            if (fuse_sort() && render_fwd_can_sort((uint32_t)cap)) {
+                launch_render_fwd_sorting(s, render_geo != 0, tiles, img.tile_count, bin.keys, (uint32_t)cap, img.ranges, img.total,
+                                          bin.point_list, width, height, gx, geom.rec, img.final_T, img.n_contrib, background,
+                                          out_color, out_invdepth, out_all_map, false, tag);
+                if (!check_launch("render_fwd", debug, s)) return CGS_ERR_HIP;
+            } else {
+                launch_tile_sort_bucket(s, tiles, img.tile_count, img.ranges, img.total, bin.keys, bin.point_list, (uint32_t)cap);
+                if (!render(bin.point_list)) return CGS_ERR_HIP;
+            }
+            if (!wait_totals()) return CGS_ERR_HIP;
+            const uint32_t longest = h_tot[1];
+            const int64_t Rb = (int64_t)h_tot[0];   // (= the sum of the list lengths whenever no bucket overflowed)
             hints_update(P, width, height, (uint64_t)longest <= cap ? Rb : -1, longest, (int64_t)h_tot[3]);
             if ((uint64_t)longest <= cap) {
                 g_last_stats[0] = Rb; g_last_stats[1] = (int64_t)longest; g_last_stats[2] = 1;
@@ -479,10 +521,11 @@ int cgs_rasterize_forward_static(void* geometry_buffer, void* binning_buffer, si
                           cov3D_precomp, colors_precomp, render_geo ? all_map : nullptr, viewmatrix, projmatrix, cam_pos,
                           width, height, tan_fovx, tan_fovy, focal_x, focal_y, radii, geom.rec, geom.rgb, gx, gy, nullptr,
                           antialiasing, 1, geom.grad_acc, img.tile_count, clear_bytes / sizeof(uint32_t));
-    const bool defer_big = hints_load(P, width, height).big > 0;   // (from the caller's probing forwards of this shape)
+    const BinHints hints = hints_load(P, width, height);   // (from the caller's probing forwards of this shape)
+    const bool defer_big = hints.big > 0;
     const bool tag = list_tags_fit(P);
     launch_scatter_bucket(s, P, radii, geom.rec, gx, gy, img.tile_count, bin.keys, (uint32_t)cap, 1, img.total + 3,
-                          defer_big ? img.tile_cursor : nullptr, (uint32_t)tiles, img.work + NONUNIT_WORD);
+                          defer_big ? img.tile_cursor : nullptr, (uint32_t)tiles, img.work + NONUNIT_WORD, scatter_spw(hints));
     if (render_fwd_can_sort((uint32_t)cap) && fuse_sort()) {
         launch_render_fwd_sorting(s, render_geo != 0, tiles, img.tile_count, bin.keys, (uint32_t)cap, img.ranges, img.total,
                                   bin.point_list, width, height, gx, geom.rec, img.final_T, img.n_contrib, background,
@@ -671,31 +714,6 @@ static int64_t view_forward_wait(int handle, int64_t* n_visible) {
     return (int64_t)longest;
 }
 
-// Longest tile list of a finished scatter, for the checked (blocking) view forward: one small launch between the scatter
-// and the compositor, so the host's wait ends when the BINNING is done and the compositor is still running.
-__global__ void __launch_bounds__(256) k_count_stats(const uint32_t* __restrict__ tile_count, int tiles, const int* __restrict__ radii,
-                                                     int P, const uint32_t* __restrict__ big, uint32_t* __restrict__ out4) {
-    uint32_t mx = 0, sum = 0, vis = 0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < tiles; i += gridDim.x * 256) {
-        const uint32_t c = tile_count[i];
-        mx = max(mx, c);
-        sum += c;
-    }
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256) vis += radii[i] > 0 ? 1u : 0u;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
-        sum += (uint32_t)__shfl_xor((int)sum, off, 64);
-        vis += (uint32_t)__shfl_xor((int)vis, off, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&out4[0], sum);   // num_rendered
-        atomicMax(&out4[1], mx);    // longest tile list
-        atomicAdd(&out4[2], vis);   // splats with radii > 0 (sizes render()'s visibility_filter without a host sync)
-        if (blockIdx.x == 0 && threadIdx.x == 0) out4[3] = *big;   // splats with oversized tile rects (final after the scatter)
-    }
-}
-
 static int64_t view_forward_impl(int mode, int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
                      float eps, double* norms, const float* opacity_logit, const float* mask_logit, float mask_thr,
                      const float* colors_precomp, void* geometry_buffer, void* binning_buffer, size_t binning_bytes,
@@ -750,9 +768,10 @@ static int64_t view_forward_impl(int mode, int B, int m, const float* curve_poin
     // k_view_fwd writes unit colours (no colors_precomp) and all_map[3] = 1 itself: the compositor derives both sums from T
     const bool unit = colors_precomp == nullptr;
     const bool aux = out_all_map != nullptr;   // image-only forward (unit colours required) when the caller passes neither map
-    const bool defer_big = hints_load(P, width_px, height_px).big > 0;
+    const BinHints hints = hints_load(P, width_px, height_px);
+    const bool defer_big = hints.big > 0;
     launch_scatter_bucket(s, P, radii, geom.rec, gx, gy, img.tile_count, bin.keys, (uint32_t)cap, 1, img.total + 3,
-                          defer_big ? img.tile_cursor : nullptr, (uint32_t)tiles);
+                          defer_big ? img.tile_cursor : nullptr, (uint32_t)tiles, nullptr, scatter_spw(hints));
     // checked: the longest tile list (and the instance count, oversized-rect count) travel to the host right behind the
     // scatter; the compositor is queued before the host waits, so the wait overlaps it
     const bool checked = mode != 0;

@@ -285,15 +285,14 @@ constexpr uint32_t BIG_TILES = 96;
 // Splats per wave: 12 = the samples of ONE curve (the model's default n_gaussians: their rects share one window by
 // construction).  Round 4, cfg3 / cfg5 / cfg4 / cfg2: 4: 29.7 us; 6: 29.1; 8: 26.2 / 109.7 / 21.8 / 12.4; 12: 24.4 / 97.2 / 23.8 /
 // 13.0; 16: 39.8 / 167 / 23.3 / 16.9 (fewer, longer-running waves).
-#ifndef CGS_GW_SPW
-#define CGS_GW_SPW 12
-#endif
-constexpr int GW_SPW = CGS_GW_SPW;
+// Chosen per launch (template parameter, launch_scatter_bucket): 12 for dense views, 8 when the previous forward of the shape
+// binned few instances (latency-bound either way; a sparse view wants more, shorter waves).
 constexpr uint32_t GW_WIN = 16, GW_CELLS = GW_WIN * GW_WIN;
 #ifndef CGS_GW_LCAP
 #define CGS_GW_LCAP 192
 #endif
 constexpr uint32_t GW_LCAP = CGS_GW_LCAP;
+template <int GW_SPW>
 __global__ void __launch_bounds__(256) k_scatter_window(int P, const int* __restrict__ radii,
                                                         const SplatRec* __restrict__ rec, int grid_x, int grid_y,
                                                         uint32_t* __restrict__ tile_count, uint64_t* __restrict__ keys,
@@ -506,10 +505,14 @@ void launch_tile_sort_big(hipStream_t s, int tiles, const uint2* ranges, uint64_
 // ranges / num_rendered / longest list / overflow flag from the sort kernel.
 void launch_scatter_bucket(hipStream_t s, int P, const int* radii, const SplatRec* rec, int grid_x, int grid_y,
                            uint32_t* tile_count, uint64_t* keys, uint32_t cap, int cull, uint32_t* big_count,
-                           uint32_t* big_queue, uint32_t big_cap, uint32_t* nonunit) {
+                           uint32_t* big_queue, uint32_t big_cap, uint32_t* nonunit, int splats_per_wave) {
     ProfScope p("scatter", s);
-    hipLaunchKernelGGL(k_scatter_window, dim3((P + 4 * GW_SPW - 1) / (4 * GW_SPW)), dim3(256), 0, s, P, radii, rec, grid_x,
-                       grid_y, tile_count, keys, cap, cull, big_count, big_queue, big_cap, nonunit);
+    if (splats_per_wave == 8)
+        hipLaunchKernelGGL(k_scatter_window<8>, dim3((P + 4 * 8 - 1) / (4 * 8)), dim3(256), 0, s, P, radii, rec, grid_x,
+                           grid_y, tile_count, keys, cap, cull, big_count, big_queue, big_cap, nonunit);
+    else
+        hipLaunchKernelGGL(k_scatter_window<12>, dim3((P + 4 * 12 - 1) / (4 * 12)), dim3(256), 0, s, P, radii, rec, grid_x,
+                           grid_y, tile_count, keys, cap, cull, big_count, big_queue, big_cap, nonunit);
     if (big_queue)
         hipLaunchKernelGGL(k_scatter_big, dim3(512), dim3(256), 0, s, big_count, big_queue, big_cap, radii, rec, grid_x,
                            grid_y, tile_count, keys, cap, cull);

@@ -6,6 +6,16 @@
 namespace cgs {
 
 constexpr float ALPHA_MIN = 1.0f / 255.0f;
+// n_contrib word of the saved image state: bits 0..30 = the reference's n_contrib (1-based list position of the last blended
+// splat, forward.cu:353,394,403; the unit-colour forward stores the position in front of the TERMINATING entry instead --
+// equally valid, see below), bit 31 = the pixel TERMINATED (T < 1e-4 stopped it, forward.cu:371-376).  The backward's
+// position cut (backward.cu:576-578) only matters for a terminated pixel: any other pixel evaluated every entry of its list
+// and blended exactly those that pass the alpha test, which the backward repeats on the same exponent bits -- so its cut
+// is "the whole list", and a quadrant whose pixels all ran to the end needs no per-pixel position test at all.
+constexpr uint32_t NCONTRIB_TERMINATED = 0x80000000u;
+__device__ __forceinline__ uint32_t backward_cut(uint32_t word, uint32_t total) {
+    return (word & NCONTRIB_TERMINATED) ? (word & ~NCONTRIB_TERMINATED) : total;
+}
 constexpr float L2_NEVER = -1000.f;   // log2 "opacity" of the padding entry: alpha = exp2(-1000) = 0
 
 struct TileGeom {

@@ -34,7 +34,8 @@ void launch_scatter(hipStream_t s, int P, const int* radii, const SplatRec* rec,
 // big_cap entries): where they are deferred to for a one-workgroup-per-splat second kernel
 void launch_scatter_bucket(hipStream_t s, int P, const int* radii, const SplatRec* rec, int grid_x, int grid_y,
                            uint32_t* tile_count, uint64_t* keys, uint32_t cap, int cull, uint32_t* big_count,
-                           uint32_t* big_queue, uint32_t big_cap, uint32_t* nonunit = nullptr);
+                           uint32_t* big_queue, uint32_t big_cap, uint32_t* nonunit = nullptr,
+                           int splats_per_wave = 12);   // 12 (one curve per wave) or 8 (sparse views: more, shorter waves)
 void launch_tile_sort_bucket(hipStream_t s, int tiles, const uint32_t* tile_count, uint2* ranges, uint32_t* total,
                              uint64_t* keys, uint32_t* point_list, uint32_t cap);
 uint32_t bucket_cap_limit();

@@ -66,6 +66,10 @@ constexpr int GROUP = 16;
 #ifndef CGS_FWD3_WAVES
 #define CGS_FWD3_WAVES 6
 #endif
+// the general (arbitrary colours) instances carry two more accumulators and the last-contributor tracking
+#ifndef CGS_FWD3_WAVES_GENERAL
+#define CGS_FWD3_WAVES_GENERAL CGS_FWD3_WAVES
+#endif
 // fused rank + stage path of the sorting forward for tiles whose list fits one batch (0: always the general sort)
 #ifndef CGS_FWD_FAST
 #define CGS_FWD_FAST 1
@@ -94,7 +98,7 @@ constexpr uint32_t PAD_OFF = (BATCH + 1) * 16;   // byte offset of the padding e
 // LIST_TAG_SHIFT) for a pair-major backward of the same forward; UNIT implies it.  The operator API sets it whenever P < 2^28
 // so that the device-side "unit colours" decision (api.hip) can hand the backward to k_render_bwd_unit.
 template <bool GEO, bool SORT, bool UNIT = false, bool TAG = UNIT>
-__global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2* __restrict__ ranges,
+__global__ void __launch_bounds__(256, UNIT ? CGS_FWD3_WAVES : CGS_FWD3_WAVES_GENERAL) k_render_fwd3(const uint2* __restrict__ ranges,
                                                      const uint32_t* __restrict__ point_list, int W, int H, int grid_x,
                                                      const SplatRec* __restrict__ rec, float* __restrict__ final_T,
                                                      uint32_t* __restrict__ n_contrib, const float* __restrict__ bg_color,
@@ -349,12 +353,13 @@ __global__ void __launch_bounds__(256, CGS_FWD3_WAVES) k_render_fwd3(const uint2
         }
         if (last_off) last_contributor = (uint32_t)(i * BATCH) + (last_off >> 4) - (UNIT ? 1u : 0u);   // 1-based list position (UNIT: of the entry before the terminating one)
     }
-    if (UNIT && cA > -0x1p120f) last_contributor = (uint32_t)total;   // never terminated: no cut
+    const bool terminated = !(cA > -0x1p120f);
+    if (UNIT && !terminated) last_contributor = (uint32_t)total;   // never terminated: no cut
     if (g.inside) {
         const size_t HW = (size_t)H * W;
-        const float T = cA > -0x1p120f ? Tw : T_dead;
+        const float T = terminated ? T_dead : Tw;
         final_T[g.pix_id] = T;
-        n_contrib[g.pix_id] = last_contributor;
+        n_contrib[g.pix_id] = last_contributor | (terminated ? NCONTRIB_TERMINATED : 0u);   // (composite.h)
         if (UNIT) C = A3 = 1.f - T;
         out_color[g.pix_id] = C + T * bg_color[0];
         if (!IMAGE_ONLY) out_invdepth[g.pix_id] = Dacc;
@@ -505,8 +510,8 @@ __global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG)
 
     const float T_final = g.inside ? final_Ts[g.pix_id] : 0.f;
     float T = T_final;
-    const uint32_t last_contributor = g.inside ? n_contrib[g.pix_id] : 0u;
-    // largest list position any pixel of this quadrant blended: everything behind it is skipped wave-wide
+    const uint32_t last_contributor = g.inside ? backward_cut(n_contrib[g.pix_id], (uint32_t)total) : 0u;
+    // largest list position any pixel of this quadrant can have blended: everything behind it is skipped wave-wide
     uint32_t wave_last = last_contributor;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, off, 64));
@@ -820,6 +825,8 @@ void launch_render_fwd(hipStream_t s, bool geo, int tiles, const uint2* ranges, 
     else if (geo) CGS_FWD3(true, false, false, false, ranges, point_list, BucketSort{});
     else CGS_FWD3(false, false, false, false, ranges, point_list, BucketSort{});
 }
+// (Round 5: ordering only the lists beyond RANK_MAX in a pre-pass and letting this kernel sort the rest was measured at cfg5
+// -- render_fwd 183 + tile_sort 74 -> 248 us serial, but 1 484 -> 1 456 Msplats/s with three views in flight -- and dropped.)
 bool render_fwd_can_sort(uint32_t cap) { return cap <= RANK_MAX; }
 void launch_render_fwd_sorting(hipStream_t s, bool geo, int tiles, const uint32_t* tile_count, const uint64_t* keys,
                                uint32_t cap, uint2* ranges, uint32_t* total, uint32_t* point_list, int W, int H,

@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256, CGS_UBWD_WAVES) k_render_bwd_unit(
             const float T_final = final_Ts[g.pix_id];
             const float dL = dL_dpixels[g.pix_id];
             K = T_final * dL - T_final * (bg_color[0] * dL);     // (1 - bg) T_final dL/dpixel  (backward.cu:649-652)
-            last = n_contrib[g.pix_id];
+            last = backward_cut(n_contrib[g.pix_id], (uint32_t)total);
         }
         const int x = lane & 7, y = lane >> 3;
         const int b = y >> 2, yy = y & 3, hh = yy & 1, r = x + 8 * (yy >> 1);

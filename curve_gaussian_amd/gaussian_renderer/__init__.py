@@ -136,6 +136,49 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_
                     use_trained_exp, clamp, compute_rend_dir, compute_visibility)
 
 
+class _Epilogue(torch.autograd.Function):
+    """(:138-145) clamp of the image and view -> world transform of the direction map in ONE launch (cgs_render_epilogue)
+    instead of a clamp kernel and three broadcast multiply-adds; backward: torch.clamp's gradient mask in one launch
+    (cgs_clamp_backward), the direction map's (rare) gradient with a 3x3 contraction."""
+
+    @staticmethod
+    def forward(ctx, image, all_map, view, clamp, want_dir):
+        from .. import _lib as L
+        lib = L.load()
+        dev = image.device
+        raw = image.detach().contiguous()
+        am = all_map.detach().contiguous()
+        vw = view.detach().float().contiguous()
+        H, W = raw.shape[-2], raw.shape[-1]
+        out = torch.empty_like(raw) if clamp else raw
+        rend_dir = torch.empty((3, H, W), dtype=torch.float32, device=dev) if want_dir else torch.empty(0, device=dev)
+        with L.device_guard(dev):
+            L.check(lib.cgs_render_epilogue(H, W, L.ptr(raw), L.ptr(am), L.ptr(vw), 1, L.ptr(out) if clamp else None,
+                                            L.ptr(rend_dir), L.raw_stream(dev)), "cgs_render_epilogue")
+        ctx.raw = raw if clamp else None
+        ctx.view = vw
+        ctx.set_materialize_grads(False)
+        return out, rend_dir
+
+    @staticmethod
+    def backward(ctx, g_img, g_dir):
+        from .. import _lib as L
+        g_raw = g_map = None
+        if g_img is not None:
+            g_img = g_img.float().contiguous()
+            if ctx.raw is not None:
+                g_raw = torch.empty_like(g_img)
+                with L.device_guard(g_img.device):
+                    L.check(L.load().cgs_clamp_backward(g_img.numel(), L.ptr(ctx.raw), L.ptr(g_img), L.ptr(g_raw),
+                                                        L.raw_stream(g_img.device)), "cgs_clamp_backward")
+            else:
+                g_raw = g_img
+        if g_dir is not None and g_dir.numel():
+            g3 = torch.einsum("ik,ihw->khw", ctx.view[:3, :3], g_dir)      # out_i = sum_k d_k wv[i][k]
+            g_map = torch.cat([g3, torch.zeros_like(g3[:1])], 0)
+        return g_raw, g_map, None, None, None
+
+
 def _visible(radii, n_visible):
     """(:150) `(radii > 0).nonzero()`; the fused route knows the count from its status readback and skips the host sync."""
     from ..ops.view_render import visible_indices
@@ -152,20 +195,24 @@ def _package(viewpoint_camera, pc, rendered_image, radii, depth_image, out_all_m
                           + exposure[:3, 3, None, None])
     # clamp=False (extension): hand the raw composite to ops.losses.photometric_loss(clamp=True), which applies the
     # clamp and its gradient mask inside the loss kernels
-    if clamp:
-        rendered_image = rendered_image.clamp(0, 1)
     rendered_alpha = out_all_map[3:4, ]
-    rendered_dir = out_all_map[0:3]
-    # view space -> world space (:143-145).  The reference does this with a [H*W,3] x [3,3] matmul; the same
-    # contraction as three broadcast FMAs avoids a 150 us GEMM launch on a 1600^2 image.  compute_rend_dir=False
-    # (extension) leaves the view-space map in place for callers that do not use it (the photometric train step).
-    if compute_rend_dir:
-        wv = viewpoint_camera.world_view_transform[:3, :3]
-        d = rendered_dir
-        rendered_dir = torch.addcmul(torch.addcmul(d[0:1] * wv[:, 0].view(3, 1, 1), d[1:2], wv[:, 1].view(3, 1, 1)),
-                                     d[2:3], wv[:, 2].view(3, 1, 1))
+    # view space -> world space (:143-145).  The reference does this with a [H*W,3] x [3,3] matmul (a 150 us GEMM launch on
+    # a 1600^2 image) after a clamp kernel; both in one launch here.  compute_rend_dir=False (extension) skips the map for
+    # callers that do not use it (the photometric train step).
+    rendered_dir = None
+    if (clamp or compute_rend_dir) and rendered_image.is_cuda and rendered_image.shape[0] == 1 and rendered_image.dtype == torch.float32:
+        rendered_image, rd = _Epilogue.apply(rendered_image, out_all_map, viewpoint_camera.world_view_transform, bool(clamp),
+                                             bool(compute_rend_dir))
+        if compute_rend_dir:
+            rendered_dir = rd
     else:
-        rendered_dir = None
+        if clamp:
+            rendered_image = rendered_image.clamp(0, 1)
+        if compute_rend_dir:
+            wv = viewpoint_camera.world_view_transform[:3, :3]
+            d = out_all_map[0:3]
+            rendered_dir = torch.addcmul(torch.addcmul(d[0:1] * wv[:, 0].view(3, 1, 1), d[1:2], wv[:, 1].view(3, 1, 1)),
+                                         d[2:3], wv[:, 2].view(3, 1, 1))
     # compute_visibility=False (extension) skips the nonzero(), which is a host sync (train.py only needs it for the
     # densification statistics and the opacity regulariser)
     return {"render": rendered_image, "viewspace_points": screenspace_points,

@@ -71,14 +71,19 @@ def _final_state(sp):
     raw = img.cpu().numpy()
     final_T = raw[:4 * npix].view(np.float32).reshape(Q.H, Q.W)
     off = (4 * npix + 127) & ~127
-    n_contrib = raw[off:off + 4 * npix].view(np.uint32).reshape(Q.H, Q.W)
-    return color.cpu().numpy(), final_T, n_contrib
+    word = raw[off:off + 4 * npix].view(np.uint32).reshape(Q.H, Q.W)
+    # bits 0..30: the reference's n_contrib; bit 31: the pixel terminated (csrc/composite.h, NCONTRIB_TERMINATED)
+    _final_state.terminated = (word >> 31).astype(bool)
+    return color.cpu().numpy(), final_T, word & 0x7fffffff
 
 
 def test_quirk7_transmittance_stop_excludes_the_splat():
     sp = QC.quirk7_scene()
     color, final_T, n_contrib = _final_state(sp)
     QC.check_quirk7_forward(color, final_T, n_contrib)
+    # the saved word also says WHICH pixels the T < 1e-4 test stopped: the stacked pixel, not its neighbour that ran to the end
+    term = _final_state.terminated
+    assert term[16, 16] and not term[16, 17]
     d = np.zeros((1, Q.H, Q.W), np.float32)
     d[0, 16, 16] = 1.0
     _, _, g = _hip(sp, dimg=d)

@@ -277,7 +277,7 @@ def _decode_state(geomBuffer, binningBuffer, imgBuffer, P, H, W, R):
     base = imgBuffer.data_ptr()
     o = carve_offsets(base, [(H * W, 4), (H * W, 4), (tiles, 8), (tiles, 4), (tiles, 4), (516, 4)])
     ranges = ib[o[2]:o[2] + tiles * 8].view(np.uint32).reshape(-1, 2)
-    n_contrib = ib[o[1]:o[1] + H * W * 4].view(np.uint32)
+    n_contrib = ib[o[1]:o[1] + H * W * 4].view(np.uint32) & 0x7fffffff   # (bit 31: "terminated", csrc/composite.h)
     final_T = ib[o[0]:o[0] + H * W * 4].view(np.float32)
     bb = binningBuffer.cpu().numpy()
     # point_list is carved first (csrc/common.h); ranges index into it (compact in the exact layout, one
