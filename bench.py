@@ -890,19 +890,42 @@ def main():
                 # (retain_graph: the general route differentiates through the prepare_scaling_rot graph, which train.py
                 # rebuilds after every optimizer step and this loop keeps)
                 torch.autograd.backward(pkg["render"], dL_dcolor.reshape(pkg["render"].shape), retain_graph=True)
-        for name, kw in (("dropin_view_ms", {}), ("dropin_view_no_visibility_ms", {"compute_visibility": False, "compute_rend_dir": False}),
-                         ("dropin_view_general_route_ms", {"fused": False})):
-            dropin_pass(tcams[:3], **kw)
-            torch.cuda.synchronize()
-            td0 = time.perf_counter()
-            for _ in range(4):
+        def dropin_time(**kw):
+            """ms per view: median over 7 passes of all cameras (every camera rendered twice before: bucket capacities and
+            binning hints of each view are settled, so no pass contains an overflow redo; the median drops host hiccups)."""
+            for _ in range(2):
                 dropin_pass(tcams, **kw)
             torch.cuda.synchronize()
-            out[name] = round((time.perf_counter() - td0) / (4 * len(tcams)) * 1e3, 4)
+            ts_ = []
+            for _ in range(7):
+                td0 = time.perf_counter()
+                dropin_pass(tcams, **kw)
+                torch.cuda.synchronize()
+                ts_.append((time.perf_counter() - td0) / len(tcams) * 1e3)
+            return round(sorted(ts_)[len(ts_) // 2], 4)
+        for name, kw in (("dropin_view_ms", {}), ("dropin_view_no_visibility_ms", {"compute_visibility": False, "compute_rend_dir": False}),
+                         ("dropin_view_general_route_ms", {"fused": False})):
+            out[name] = dropin_time(**kw)
+        # the same two routes through the ctypes bindings instead of the compiled host shim (CGS_TORCH_SHIM=0), same process, same box
+        from curve_gaussian_amd import diff_cur_rasterization as _DCR
+        prev_env = os.environ.get("CGS_TORCH_SHIM")
+        os.environ["CGS_TORCH_SHIM"] = "0"
+        _DCR._ExtProxy._impl = None
+        try:
+            for name, kw in (("dropin_view_ctypes_ms", {}), ("dropin_view_general_route_ctypes_ms", {"fused": False})):
+                out[name] = dropin_time(**kw)
+        finally:
+            if prev_env is None:
+                os.environ.pop("CGS_TORCH_SHIM", None)
+            else:
+                os.environ["CGS_TORCH_SHIM"] = prev_env
+            _DCR._ExtProxy._impl = None
         out["dropin_note"] = ("dropin_view_ms: render(cam, gaussians, pipe, bg) with the reference's defaults + backward of the "
                               "image per view, eager (fused view route: cgs_view_forward_checked / cgs_view_backward); "
                               "..._no_visibility: without the nonzero() host sync and the world-space direction map; "
-                              "..._general_route: fused=False (GaussianRasterizer, the round-3 drop-in path)")
+                              "..._general_route: fused=False (GaussianRasterizer, the round-3 drop-in path); "
+                              "..._ctypes: the same routes through the ctypes bindings (CGS_TORCH_SHIM=0) instead of the compiled "
+                              "host shim curve_gaussian_amd/_cgs_torch.so, measured in the same process")
         if not args.no_general_route:
             # ---- what the reference's own GaussianRasterizer call reaches (VERDICT r4 #1): kernel times per instance, the
             # backward compositor's HBM-roofline fraction on K8's algorithmic bytes, and the whole operator route
@@ -939,15 +962,18 @@ def main():
         for prm in (gm._curve_points, gm._width, gm._opacity, gm._mask):
             prm.grad = None
         ts = TrainStep(gm, tcams, gts)
-        for _ in range(3):
+        for _ in range(10):
             ts.step()
         torch.cuda.synchronize()
-        tt0 = time.perf_counter()
-        n_ts = 16
-        for _ in range(n_ts):
-            ts.step()
-        torch.cuda.synchronize()
-        eager_ms = (time.perf_counter() - tt0) / n_ts * 1e3
+        n_ts = 8
+        chunks = []
+        for _ in range(7):   # median of seven 8-iteration chunks (each view's bucket capacity settled during the warm-up)
+            tt0 = time.perf_counter()
+            for _ in range(n_ts):
+                ts.step()
+            torch.cuda.synchronize()
+            chunks.append((time.perf_counter() - tt0) / n_ts * 1e3)
+        eager_ms = sorted(chunks)[len(chunks) // 2]
         # the same iteration replayed as one hipGraph launch (sync-free forward, device-state Adam)
         from curve_gaussian_amd.train_step import GraphedTrainStep
         gm2 = GaussianCurveModel(0, m, device=dev).create_from_curves(curves["curve_points"], curves["width"],

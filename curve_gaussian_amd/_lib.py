@@ -31,6 +31,10 @@ SIGNATURES = {
                                     C.c_uint32, _vp, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cgs_view_forward_shared": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _vp, _vp, C.c_size_t, _vp,
                                      C.c_uint32, _vp, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cgs_view_forward_render": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _vp, C.c_size_t, _vp, C.c_uint32,
+                                     _vp, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cgs_view_backward_render": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp,
+                                      _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "cgs_view_forward_wait": (_i64, [_i, C.POINTER(_i64)]),
     "cgs_view_forward_abandon": (None, [_i]),
     "cgs_render_epilogue": (_i, [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),

@@ -173,6 +173,9 @@ using namespace cgs;
 // and the compositor, so the host's wait ends when the BINNING is done and the compositor is still running.
 __global__ void __launch_bounds__(256) k_count_stats(const uint32_t* __restrict__ tile_count, int tiles, const int* __restrict__ radii,
                                                      int P, const uint32_t* __restrict__ big, uint32_t* __restrict__ out4) {
+    // (same-address atomics serialise at ~15 ns each: one per wave -- 768 of them -- made this reduction take 12.7 us of the
+    // host's critical path, profiles/r05_kernel_stats.csv; one per BLOCK after an LDS step: 64 blocks x 3)
+    __shared__ uint32_t s_part[3][4];
     uint32_t mx = 0, sum = 0, vis = 0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < tiles; i += gridDim.x * 256) {
         const uint32_t c = tile_count[i];
@@ -187,13 +190,51 @@ __global__ void __launch_bounds__(256) k_count_stats(const uint32_t* __restrict_
         vis += (uint32_t)__shfl_xor((int)vis, off, 64);
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&out4[0], sum);   // num_rendered
-        atomicMax(&out4[1], mx);    // longest tile list
-        atomicAdd(&out4[2], vis);   // splats with radii > 0 (sizes render()'s visibility_filter without a host sync)
-        if (blockIdx.x == 0 && threadIdx.x == 0) out4[3] = *big;   // splats with oversized tile rects (final after the scatter)
+        s_part[0][threadIdx.x >> 6] = sum;
+        s_part[1][threadIdx.x >> 6] = mx;
+        s_part[2][threadIdx.x >> 6] = vis;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&out4[0], s_part[0][0] + s_part[0][1] + s_part[0][2] + s_part[0][3]);                  // num_rendered
+        atomicMax(&out4[1], max(max(s_part[1][0], s_part[1][1]), max(s_part[1][2], s_part[1][3])));      // longest tile list
+        // splats with radii > 0 (sizes render()'s visibility_filter without a host sync)
+        atomicAdd(&out4[2], s_part[2][0] + s_part[2][1] + s_part[2][2] + s_part[2][3]);
+        if (blockIdx.x == 0) out4[3] = *big;   // splats with oversized tile rects (final after the scatter)
     }
 }
 
+// ---------------------------------------------------------------------------------------------- render() epilogue
+// gaussian_renderer/__init__.py:138-145 for the fused view route in ONE launch: the clamp of the image and the view -> world
+// transform of the direction map (the reference runs a clamp kernel and a [H*W,3] x [3,3] matmul on a 1600^2 image), and the
+// clamp's gradient mask for the way back.
+__global__ void __launch_bounds__(256) k_render_epilogue(size_t npix, const float* __restrict__ color_raw, const float* __restrict__ all_map,
+                                                         const float* __restrict__ wv, int clamp, float* __restrict__ color_out,
+                                                         float* __restrict__ dir_out) {
+    float w00 = 0.f, w01 = 0.f, w02 = 0.f, w10 = 0.f, w11 = 0.f, w12 = 0.f, w20 = 0.f, w21 = 0.f, w22 = 0.f;
+    if (dir_out) {   // (viewmatrix may be NULL for a clamp-only call)
+        w00 = wv[0]; w01 = wv[1]; w02 = wv[2]; w10 = wv[4]; w11 = wv[5]; w12 = wv[6]; w20 = wv[8]; w21 = wv[9]; w22 = wv[10];
+    }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
+        if (color_out) {
+            const float c = color_raw[i];
+            color_out[i] = clamp ? fminf(fmaxf(c, 0.f), 1.f) : c;
+        }
+        if (dir_out) {   // out_i = sum_k d_k wv[i][k]   (rendered_dir.permute(1, 2, 0) @ world_view_transform[:3, :3].T)
+            const float d0 = all_map[i], d1 = all_map[npix + i], d2 = all_map[2 * npix + i];
+            dir_out[i] = d0 * w00 + d1 * w01 + d2 * w02;
+            dir_out[npix + i] = d0 * w10 + d1 * w11 + d2 * w12;
+            dir_out[2 * npix + i] = d0 * w20 + d1 * w21 + d2 * w22;
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_clamp_backward(size_t n, const float* __restrict__ raw, const float* __restrict__ g_in,
+                                                        float* __restrict__ g_out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float x = raw[i];
+        g_out[i] = (x >= 0.f && x <= 1.f) ? g_in[i] : 0.f;   // torch.clamp's backward: the gradient passes where min <= x <= max
+    }
+}
 extern "C" {
 
 const char* cgs_last_error(void) { return g_err; }
@@ -720,9 +761,13 @@ static int64_t view_forward_impl(int mode, int B, int m, const float* curve_poin
                      void* image_buffer, uint32_t bucket_capacity, const float* background, int width_px, int height_px,
                      const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
                      float* out_color, float* out_invdepth, float* out_all_map, int* radii, float* xyz, float* rotation,
-                     float* scaling, void* stream_) {
+                     float* scaling, void* stream_, float* out_color_clamped = nullptr, float* out_rend_dir = nullptr) {
     hipStream_t s = (hipStream_t)stream_;
     const int P = B * m;
+    if (out_rend_dir && !out_all_map) {
+        set_error("cgs_view_forward: the direction map needs the all_map output");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
     if (B <= 0 || m <= 0 || m > 32 || (long long)B * m >= (1ll << 28) || width_px <= 0 || height_px <= 0 || !curve_points ||
         !width || !coef || !norms ||
         !opacity_logit || !geometry_buffer || !binning_buffer || !image_buffer || bucket_capacity == 0 || !background ||
@@ -795,11 +840,14 @@ static int64_t view_forward_impl(int mode, int B, int m, const float* curve_poin
     if (render_fwd_can_sort((uint32_t)cap) && fuse_sort()) {
         launch_render_fwd_sorting(s, aux, tiles, img.tile_count, bin.keys, (uint32_t)cap, img.ranges, img.total,
                                   bin.point_list, width_px, height_px, gx, geom.rec, img.final_T, img.n_contrib, background,
-                                  out_color, out_invdepth, out_all_map, unit);
+                                  out_color, out_invdepth, out_all_map, unit, unit, out_color_clamped, out_rend_dir, viewmatrix);
     } else {
         launch_tile_sort_bucket(s, tiles, img.tile_count, img.ranges, img.total, bin.keys, bin.point_list, (uint32_t)cap);
         launch_render_fwd(s, aux, tiles, img.ranges, bin.point_list, width_px, height_px, gx, geom.rec, img.final_T,
                           img.n_contrib, background, out_color, out_invdepth, out_all_map, unit);
+        if (out_color_clamped || out_rend_dir)   // (long-list buckets: the non-sorting forward has no epilogue of its own)
+            hipLaunchKernelGGL(k_render_epilogue, dim3((unsigned)std::min<size_t>((npix + 255) / 256, 4096)), dim3(256), 0, s, npix,
+                               out_color, out_all_map, viewmatrix, 1, out_color_clamped, out_rend_dir);
     }
     if (!check_launch("view_forward", false, s)) {
         if (checked) view_slot_release(slot);
@@ -847,6 +895,20 @@ int cgs_view_forward_begin(int B, int m, const float* curve_points, const float*
                              background, width_px, height_px, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, out_color,
                              out_invdepth, out_all_map, radii, xyz, rotation, scaling, stream_);
 }
+// ... with render()'s epilogue written by the compositor itself (out_color_clamped [H*W], out_rend_dir [3,H*W]; either may be NULL)
+int cgs_view_forward_render(int checked, int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier,
+                            const float* coef, float eps, double* norms, const float* opacity_logit, const float* mask_logit,
+                            float mask_thr, void* geometry_buffer, void* binning_buffer, size_t binning_bytes, void* image_buffer,
+                            uint32_t bucket_capacity, const float* background, int width_px, int height_px, const float* viewmatrix,
+                            const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, float* out_color,
+                            float* out_invdepth, float* out_all_map, int* radii, float* out_color_clamped, float* out_rend_dir,
+                            void* stream_) {
+    return (int)view_forward_impl(checked ? 2 : 0, B, m, curve_points, width, is_bezier, coef, eps, norms, opacity_logit, mask_logit,
+                                  mask_thr, nullptr, geometry_buffer, binning_buffer, binning_bytes, image_buffer, bucket_capacity,
+                                  background, width_px, height_px, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, out_color,
+                                  out_invdepth, out_all_map, radii, nullptr, nullptr, nullptr, stream_, out_color_clamped,
+                                  out_rend_dir);
+}
 int64_t cgs_view_forward_wait(int handle, int64_t* n_visible) { return view_forward_wait(handle, n_visible); }
 void cgs_view_forward_abandon(int handle) {
     if (handle >= 0 && handle < VIEW_SLOTS) view_slot_release(handle);
@@ -873,14 +935,20 @@ uint32_t cgs_bucket_capacity_hint(int P, int width, int height) {
 
 size_t cgs_view_backward_scratch_floats(int B, int m) { return (size_t)(B > 0 ? B : 0) * (size_t)(m > 0 ? m : 0) * 15; }
 
-int cgs_view_backward(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
+}  // extern "C"
+static int view_backward_impl(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
                       float eps, double* norms, const float* opacity_logit, const float* mask_logit, float mask_thr,
                       const float* colors_precomp, void* geometry_buffer, const void* binning_buffer, const void* image_buffer, const float* background,
                       int width_px, int height_px, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                       float tan_fovx, float tan_fovy, const int* radii, const float* dL_dout_color,
                       const float* dL_drotation_extra, float* dL_dmeans2D, float* dL_dcurve_points, float* dL_dwidth,
-                      float* dL_dopacity_logit, float* dL_dmask_logit, float* scratch, int flags, void* stream_) {
+                      float* dL_dopacity_logit, float* dL_dmask_logit, float* scratch, int flags, void* stream_,
+                      const float* clamp_raw) {
     hipStream_t s = (hipStream_t)stream_;
+    if (clamp_raw && colors_precomp) {
+        set_error("cgs_view_backward_render: the folded clamp mask is part of the unit-colour path (no colors_precomp)");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
     const int P = B * m;
     if (B <= 0 || m <= 0 || m > 32 || width_px <= 0 || height_px <= 0 || !curve_points || !width || !coef || !norms ||
         !opacity_logit || !geometry_buffer || !binning_buffer || !image_buffer || !background || !viewmatrix || !projmatrix ||
@@ -908,7 +976,7 @@ int cgs_view_backward(int B, int m, const float* curve_points, const float* widt
     // colours unless it was given colors_precomp (same argument here): closed-form dL/dalpha, no recurrences (render.hip, UNIT)
     if (colors_precomp == nullptr)
         launch_render_bwd_unit(s, tiles, img.ranges, bin.point_list, width_px, height_px, gx, background, geom.rec, img.final_T,
-                               img.n_contrib, dL_dout_color, geom.grad_acc);
+                               img.n_contrib, dL_dout_color, geom.grad_acc, ACC_STRIDE_VIEW, nullptr, clamp_raw);
     else   // arbitrary colours: the general training instance (the forward did not tag the lists)
         launch_render_bwd(s, false, false, false, tiles, img.ranges, bin.point_list, width_px, height_px, gx, background, geom.rec,
                           img.final_T, img.n_contrib, dL_dout_color, nullptr, nullptr, geom.grad_acc, ACC_STRIDE_VIEW);
@@ -921,6 +989,33 @@ int cgs_view_backward(int B, int m, const float* curve_points, const float* widt
                                      dL_dcurve_points, dL_dwidth, gv, (flags & CGS_VIEW_ACCUMULATE) ? 1 : 0);
     if (!check_launch("view_backward", false, s)) return CGS_ERR_HIP;
     return CGS_OK;
+}
+extern "C" {
+int cgs_view_backward(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
+                      float eps, double* norms, const float* opacity_logit, const float* mask_logit, float mask_thr,
+                      const float* colors_precomp, void* geometry_buffer, const void* binning_buffer, const void* image_buffer, const float* background,
+                      int width_px, int height_px, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                      float tan_fovx, float tan_fovy, const int* radii, const float* dL_dout_color,
+                      const float* dL_drotation_extra, float* dL_dmeans2D, float* dL_dcurve_points, float* dL_dwidth,
+                      float* dL_dopacity_logit, float* dL_dmask_logit, float* scratch, int flags, void* stream_) {
+    return view_backward_impl(B, m, curve_points, width, is_bezier, coef, eps, norms, opacity_logit, mask_logit, mask_thr, colors_precomp,
+                              geometry_buffer, binning_buffer, image_buffer, background, width_px, height_px, viewmatrix, projmatrix,
+                              cam_pos, tan_fovx, tan_fovy, radii, dL_dout_color, dL_drotation_extra, dL_dmeans2D, dL_dcurve_points,
+                              dL_dwidth, dL_dopacity_logit, dL_dmask_logit, scratch, flags, stream_, nullptr);
+}
+// ... for an image that went through render()'s clamp: dL_dout_color is the gradient of the CLAMPED image and color_raw the
+// forward's unclamped one; torch.clamp's gradient mask is applied where the compositor loads the pixel's upstream gradient
+int cgs_view_backward_render(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
+                      float eps, double* norms, const float* opacity_logit, const float* mask_logit, float mask_thr,
+                      void* geometry_buffer, const void* binning_buffer, const void* image_buffer, const float* background,
+                      int width_px, int height_px, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                      float tan_fovx, float tan_fovy, const int* radii, const float* dL_dout_color, const float* color_raw,
+                      float* dL_dmeans2D, float* dL_dcurve_points, float* dL_dwidth,
+                      float* dL_dopacity_logit, float* dL_dmask_logit, float* scratch, int flags, void* stream_) {
+    return view_backward_impl(B, m, curve_points, width, is_bezier, coef, eps, norms, opacity_logit, mask_logit, mask_thr, nullptr,
+                              geometry_buffer, binning_buffer, image_buffer, background, width_px, height_px, viewmatrix, projmatrix,
+                              cam_pos, tan_fovx, tan_fovy, radii, dL_dout_color, nullptr, dL_dmeans2D, dL_dcurve_points,
+                              dL_dwidth, dL_dopacity_logit, dL_dmask_logit, scratch, flags, stream_, color_raw);
 }
 
 int cgs_view_shared_begin(int B, int m, const float* curve_points, const uint8_t* is_bezier, const float* coef, double* norms,
@@ -1068,37 +1163,6 @@ int cgs_edge_aware_loss(int channels, int height, int width, const float* image,
 
 size_t cgs_photometric_workspace_bytes(int height, int width) {
     return photometric_workspace_bytes(height > 0 ? height : 1, width > 0 ? width : 1);
-}
-// ---------------------------------------------------------------------------------------------- render() epilogue
-// gaussian_renderer/__init__.py:138-145 for the fused view route in ONE launch: the clamp of the image and the view -> world
-// transform of the direction map (the reference runs a clamp kernel and a [H*W,3] x [3,3] matmul on a 1600^2 image), and the
-// clamp's gradient mask for the way back.
-__global__ void __launch_bounds__(256) k_render_epilogue(size_t npix, const float* __restrict__ color_raw, const float* __restrict__ all_map,
-                                                         const float* __restrict__ wv, int clamp, float* __restrict__ color_out,
-                                                         float* __restrict__ dir_out) {
-    float w00 = 0.f, w01 = 0.f, w02 = 0.f, w10 = 0.f, w11 = 0.f, w12 = 0.f, w20 = 0.f, w21 = 0.f, w22 = 0.f;
-    if (dir_out) {   // (viewmatrix may be NULL for a clamp-only call)
-        w00 = wv[0]; w01 = wv[1]; w02 = wv[2]; w10 = wv[4]; w11 = wv[5]; w12 = wv[6]; w20 = wv[8]; w21 = wv[9]; w22 = wv[10];
-    }
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
-        if (color_out) {
-            const float c = color_raw[i];
-            color_out[i] = clamp ? fminf(fmaxf(c, 0.f), 1.f) : c;
-        }
-        if (dir_out) {   // out_i = sum_k d_k wv[i][k]   (rendered_dir.permute(1, 2, 0) @ world_view_transform[:3, :3].T)
-            const float d0 = all_map[i], d1 = all_map[npix + i], d2 = all_map[2 * npix + i];
-            dir_out[i] = d0 * w00 + d1 * w01 + d2 * w02;
-            dir_out[npix + i] = d0 * w10 + d1 * w11 + d2 * w12;
-            dir_out[2 * npix + i] = d0 * w20 + d1 * w21 + d2 * w22;
-        }
-    }
-}
-__global__ void __launch_bounds__(256) k_clamp_backward(size_t n, const float* __restrict__ raw, const float* __restrict__ g_in,
-                                                        float* __restrict__ g_out) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float x = raw[i];
-        g_out[i] = (x >= 0.f && x <= 1.f) ? g_in[i] : 0.f;   // torch.clamp's backward: the gradient passes where min <= x <= max
-    }
 }
 int cgs_render_epilogue(int height, int width, const float* color_raw, const float* all_map, const float* viewmatrix, int clamp,
                         float* color_out, float* dir_out, void* stream_) {

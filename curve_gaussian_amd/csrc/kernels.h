@@ -55,7 +55,10 @@ void launch_render_fwd_sorting(hipStream_t s, bool geo, int tiles, const uint32_
                                uint32_t cap, uint2* ranges, uint32_t* total, uint32_t* point_list, int W, int H,
                                int grid_x, const SplatRec* rec, float* final_T, uint32_t* n_contrib,
                                const float* bg_color, float* out_color, float* out_invdepth, float* out_all_map,
-                               bool unit = false, bool tag = false);
+                               bool unit = false, bool tag = false,
+                               // render()'s epilogue written by the same kernel (NULL: not wanted): the image clamped to
+                               // [0, 1], the direction map in world space (wv = world_view_transform, device memory)
+                               float* color_clamped = nullptr, float* dir_out = nullptr, const float* wv = nullptr);
 void launch_render_bwd(hipStream_t s, bool geo, bool invd, bool colg, int tiles, const uint2* ranges,
                        const uint32_t* point_list, int W, int H, int grid_x, const float* bg_color,
                        const SplatRec* rec, const float* final_Ts, const uint32_t* n_contrib, const float* dL_dpixels,
@@ -71,7 +74,9 @@ void launch_render_bwd(hipStream_t s, bool geo, bool invd, bool colg, int tiles,
 void launch_render_bwd_unit(hipStream_t s, int tiles, const uint2* ranges, const uint32_t* point_list, int W, int H,
                             int grid_x, const float* bg_color, const SplatRec* rec, const float* final_Ts,
                             const uint32_t* n_contrib, const float* dL_dpixels, float* grad_acc,
-                            int acc_stride = ACC_STRIDE_VIEW, const uint32_t* nonunit_gate = nullptr);
+                            int acc_stride = ACC_STRIDE_VIEW, const uint32_t* nonunit_gate = nullptr,
+                            // torch.clamp's gradient mask folded in: dL/dpixel counts only where 0 <= clamp_raw <= 1 (NULL: all)
+                            const float* clamp_raw = nullptr);
 
 // sampling.hip
 int sample_norm_words();

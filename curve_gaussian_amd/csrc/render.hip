@@ -54,6 +54,16 @@ struct BucketSort {
     uint32_t cap;                // bucket capacity (<= RANK_MAX for this kernel)
 };
 
+// render()'s epilogue (gaussian_renderer/__init__.py:138-145) written by the forward itself when the caller asks for it: the
+// clamped image beside the raw one (torch.clamp's gradient mask needs the raw value) and the direction map taken from view to
+// world space, out_i = sum_k all_map[k] wv[4 i + k] -- the pixel's sums are in registers at that point, so the separate pass
+// over the 1600^2 image (82 MB of traffic, one launch) disappears.
+struct ViewEpilogue {
+    float* color_clamped;   // [H*W] or NULL
+    float* dir_out;         // [3,H*W] or NULL
+    const float* wv;        // world_view_transform, row-major 4x4 (device memory); read when dir_out != NULL
+};
+
 // ------------------------------------------------------------------------------------------------ forward, v3
 // Same per-pixel arithmetic after the exponent, but the exponent itself -- log2(alpha) of every (pixel, splat) pair, a
 // quadratic polynomial in the pixel coordinates -- comes from the matrix cores (p2_mfma.h): two bf16 MFMAs evaluate it for
@@ -103,7 +113,7 @@ __global__ void __launch_bounds__(256, UNIT ? CGS_FWD3_WAVES : CGS_FWD3_WAVES_GE
                                                      const SplatRec* __restrict__ rec, float* __restrict__ final_T,
                                                      uint32_t* __restrict__ n_contrib, const float* __restrict__ bg_color,
                                                      float* __restrict__ out_color, float* __restrict__ out_invdepth,
-                                                     float* __restrict__ out_all_map, BucketSort bs) {
+                                                     float* __restrict__ out_all_map, BucketSort bs, ViewEpilogue epi) {
     // UNIT without GEO is the image-only instance: the caller wants neither inverse depth nor all_map (a training iteration
     // reads `render` only, train.py:98-107) -- the walk then carries the transmittance and nothing else.
     constexpr bool IMAGE_ONLY = UNIT && !GEO;
@@ -361,7 +371,15 @@ __global__ void __launch_bounds__(256, UNIT ? CGS_FWD3_WAVES : CGS_FWD3_WAVES_GE
         final_T[g.pix_id] = T;
         n_contrib[g.pix_id] = last_contributor | (terminated ? NCONTRIB_TERMINATED : 0u);   // (composite.h)
         if (UNIT) C = A3 = 1.f - T;
-        out_color[g.pix_id] = C + T * bg_color[0];
+        const float Cout = C + T * bg_color[0];
+        out_color[g.pix_id] = Cout;
+        if (SORT && epi.color_clamped) epi.color_clamped[g.pix_id] = fminf(fmaxf(Cout, 0.f), 1.f);
+        if (SORT && GEO && epi.dir_out) {
+            const float* wv = epi.wv;
+            epi.dir_out[g.pix_id] = A0 * wv[0] + A1 * wv[1] + A2 * wv[2];
+            epi.dir_out[HW + g.pix_id] = A0 * wv[4] + A1 * wv[5] + A2 * wv[6];
+            epi.dir_out[2 * HW + g.pix_id] = A0 * wv[8] + A1 * wv[9] + A2 * wv[10];
+        }
         if (!IMAGE_ONLY) out_invdepth[g.pix_id] = Dacc;
         if (IMAGE_ONLY) {
             // (no other outputs)
@@ -813,11 +831,12 @@ __global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG)
 // ------------------------------------------------------------------------------------------------ launchers
 #define CGS_FWD3(G, S, U, T, R, PL, BS)                                                                               \
     hipLaunchKernelGGL((k_render_fwd3<G, S, U, T>), dim3(tiles), dim3(256), 0, s, R, PL, W, H, grid_x, rec, final_T,  \
-                       n_contrib, bg_color, out_color, out_invdepth, out_all_map, BS)
+                       n_contrib, bg_color, out_color, out_invdepth, out_all_map, BS, epi)
 void launch_render_fwd(hipStream_t s, bool geo, int tiles, const uint2* ranges, const uint32_t* point_list, int W,
                        int H, int grid_x, const SplatRec* rec, float* final_T, uint32_t* n_contrib,
                        const float* bg_color, float* out_color, float* out_invdepth, float* out_all_map, bool unit, bool tag) {
     ProfScope p("render_fwd", s);
+    const ViewEpilogue epi{nullptr, nullptr, nullptr};
     if (geo && unit) CGS_FWD3(true, false, true, true, ranges, point_list, BucketSort{});
     else if (unit) CGS_FWD3(false, false, true, true, ranges, point_list, BucketSort{});
     else if (geo && tag) CGS_FWD3(true, false, false, true, ranges, point_list, BucketSort{});
@@ -832,9 +851,10 @@ void launch_render_fwd_sorting(hipStream_t s, bool geo, int tiles, const uint32_
                                uint32_t cap, uint2* ranges, uint32_t* total, uint32_t* point_list, int W, int H,
                                int grid_x, const SplatRec* rec, float* final_T, uint32_t* n_contrib,
                                const float* bg_color, float* out_color, float* out_invdepth, float* out_all_map, bool unit,
-                               bool tag) {
+                               bool tag, float* color_clamped, float* dir_out, const float* wv) {
     ProfScope p("render_fwd", s);
     const BucketSort bs{tile_count, keys, point_list, ranges, total, cap};
+    const ViewEpilogue epi{color_clamped, geo ? dir_out : nullptr, wv};
     const uint2* no_ranges = nullptr;
     const uint32_t* no_list = nullptr;
     if (geo && unit) CGS_FWD3(true, true, true, true, no_ranges, no_list, bs);

@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256, CGS_UBWD_WAVES) k_render_bwd_unit(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int grid_x,
     const float* __restrict__ bg_color, const SplatRec* __restrict__ rec, const float* __restrict__ final_Ts,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels, float* __restrict__ grad_acc,
-    const uint32_t* __restrict__ nonunit_gate) {
+    const uint32_t* __restrict__ nonunit_gate, const float* __restrict__ clamp_raw) {
     if (GATED && *nonunit_gate != 0u) return;   // some visible splat has a colour or all_map[3] other than 1
     __shared__ float4 s_geo[UB + 1];     // {cx, cy, A2, B2}; entry UB: padding (never blended)
     __shared__ float4 s_at[UB + 1];      // {C2, log2 opacity, splat id bits, -}
@@ -201,7 +201,11 @@ __global__ void __launch_bounds__(256, CGS_UBWD_WAVES) k_render_bwd_unit(
         uint32_t last = 0u;
         if (g.inside) {
             const float T_final = final_Ts[g.pix_id];
-            const float dL = dL_dpixels[g.pix_id];
+            float dL = dL_dpixels[g.pix_id];
+            if (clamp_raw) {   // the caller's image went through clamp(0, 1): its gradient passes where 0 <= raw <= 1
+                const float x = clamp_raw[g.pix_id];
+                dL = (x >= 0.f && x <= 1.f) ? dL : 0.f;
+            }
             K = T_final * dL - T_final * (bg_color[0] * dL);     // (1 - bg) T_final dL/dpixel  (backward.cu:649-652)
             last = backward_cut(n_contrib[g.pix_id], (uint32_t)total);
         }
@@ -395,14 +399,14 @@ __global__ void __launch_bounds__(256, CGS_UBWD_WAVES) k_render_bwd_unit(
 void launch_render_bwd_unit(hipStream_t s, int tiles, const uint2* ranges, const uint32_t* point_list, int W, int H,
                             int grid_x, const float* bg_color, const SplatRec* rec, const float* final_Ts,
                             const uint32_t* n_contrib, const float* dL_dpixels, float* grad_acc, int acc_stride,
-                            const uint32_t* nonunit_gate) {
+                            const uint32_t* nonunit_gate, const float* clamp_raw) {
     ProfScope p(nonunit_gate ? "render_bwd_unit_gated" : "render_bwd", s);
     if (acc_stride == ACC_STRIDE_VIEW && !nonunit_gate)
         hipLaunchKernelGGL((k_render_bwd_unit<ACC_STRIDE_VIEW, false>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H,
-                           grid_x, bg_color, rec, final_Ts, n_contrib, dL_dpixels, grad_acc, nullptr);
+                           grid_x, bg_color, rec, final_Ts, n_contrib, dL_dpixels, grad_acc, nullptr, clamp_raw);
     else if (acc_stride == ACC_STRIDE && nonunit_gate)
         hipLaunchKernelGGL((k_render_bwd_unit<ACC_STRIDE, true>), dim3(tiles), dim3(256), 0, s, ranges, point_list, W, H, grid_x,
-                           bg_color, rec, final_Ts, n_contrib, dL_dpixels, grad_acc, nonunit_gate);
+                           bg_color, rec, final_Ts, n_contrib, dL_dpixels, grad_acc, nonunit_gate, clamp_raw);
     else
         set_error("launch_render_bwd_unit: unsupported (stride %d, gate %p) combination", acc_stride, (const void*)nonunit_gate);
 }

@@ -229,26 +229,20 @@ py::tuple view_forward(const Tensor& curve_points, const Tensor& width, const Te
     Tensor radii = at::empty({P}, cp.options().dtype(at::kInt));
     void* st = stream_of(cp);
     const uint8_t* isb = has(is_bezier_u8) ? (const uint8_t*)is_bezier_u8->data_ptr() : nullptr;
-    auto fwd = sync_free ? cgs_view_forward : cgs_view_forward_begin;
-    const int handle = check(fwd(B, (int)m, fp(cp), fp(w), isb, fp(coef), (float)eps, norms.data_ptr<double>(), fp(ol), fp(mk),
-                                 (float)mask_thr, nullptr, geom.data_ptr(), binb.data_ptr(), nbin, img.data_ptr(), (uint32_t)cap, fp(bgc),
-                                 (int)W, (int)H, fp(view), fp(proj), fp(cpos), (float)tanx, (float)tany, color.data_ptr<float>(),
-                                 invd.data_ptr<float>(), amap.data_ptr<float>(), radii.data_ptr<int>(), nullptr, nullptr, nullptr, st),
-                             sync_free ? "cgs_view_forward" : "cgs_view_forward_begin");
-    // render()'s epilogue (gaussian_renderer/__init__.py:138-145) in the same stream, one launch
+    // render()'s epilogue (gaussian_renderer/__init__.py:138-145) is written by the forward compositor itself
     Tensor color_out = color, rend_dir = at::empty({0}, fopt);
     py::object color_raw = py::none();
-    if (clamp || want_dir) {
-        if (clamp) color_out = at::empty({1, H, W}, fopt);
-        if (want_dir) rend_dir = at::empty({3, H, W}, fopt);
-        const int rc = cgs_render_epilogue((int)H, (int)W, color.data_ptr<float>(), amap.data_ptr<float>(), fp(view), 1,
-                                           clamp ? color_out.data_ptr<float>() : nullptr, want_dir ? rend_dir.data_ptr<float>() : nullptr, st);
-        if (rc < 0) {
-            if (!sync_free) cgs_view_forward_abandon(handle);
-            check(rc, "cgs_render_epilogue");
-        }
-        if (clamp) color_raw = py::cast(color);
-    }
+    if (clamp) color_out = at::empty({1, H, W}, fopt);
+    if (want_dir) rend_dir = at::empty({3, H, W}, fopt);
+    const int handle = check(cgs_view_forward_render(sync_free ? 0 : 1, B, (int)m, fp(cp), fp(w), isb, fp(coef), (float)eps,
+                                                     norms.data_ptr<double>(), fp(ol), fp(mk), (float)mask_thr, geom.data_ptr(),
+                                                     binb.data_ptr(), nbin, img.data_ptr(), (uint32_t)cap, fp(bgc), (int)W, (int)H,
+                                                     fp(view), fp(proj), fp(cpos), (float)tanx, (float)tany, color.data_ptr<float>(),
+                                                     invd.data_ptr<float>(), amap.data_ptr<float>(), radii.data_ptr<int>(),
+                                                     clamp ? color_out.data_ptr<float>() : nullptr,
+                                                     want_dir ? rend_dir.data_ptr<float>() : nullptr, st),
+                             "cgs_view_forward_render");
+    if (clamp) color_raw = py::cast(color);
     return py::make_tuple(color_out, invd, amap, radii, rend_dir, color_raw,
                           py::make_tuple(cp, w, ol, mk.defined() ? py::cast(mk) : py::none(), geom, binb, img, radii, norms, bgc, view, proj, cpos),
                           sync_free ? -1 : handle);
@@ -287,19 +281,16 @@ py::tuple view_backward(const Tensor& cp, const Tensor& w, const Tensor& ol, con
     if (g_color_in.has_value()) {
         void* st = stream_of(cp);
         Tensor g_color = f32c(*g_color_in, "grad of render");
-        if (has(color_raw)) {   // torch.clamp's gradient rule on the unclamped image
-            Tensor g_raw = at::empty_like(g_color);
-            check(cgs_clamp_backward(g_color.numel(), fp(*color_raw), fp(g_color), g_raw.data_ptr<float>(), st), "cgs_clamp_backward");
-            g_color = g_raw;
-        }
         Tensor scratch = at::empty({(int64_t)cgs_view_backward_scratch_floats(B, (int)m)}, fopt);
         const uint8_t* isb = has(is_bezier_u8) ? (const uint8_t*)is_bezier_u8->data_ptr() : nullptr;
-        check(cgs_view_backward(B, (int)m, fp(cp), fp(w), isb, fp(coef), (float)eps, norms.data_ptr<double>(), fp(ol),
-                                has_mk ? fp(*mk) : nullptr, (float)mask_thr, nullptr, geom.data_ptr(), binb.data_ptr(), img.data_ptr(),
-                                fp(bgc), (int)W, (int)H, fp(view), fp(proj), fp(cpos), (float)tanx, (float)tany, radii.data_ptr<int>(),
-                                fp(g_color), nullptr, g_m2d.data_ptr<float>(), g_cp.data_ptr<float>(), g_w.data_ptr<float>(),
-                                g_ol.data_ptr<float>(), has_mk ? g_mk.data_ptr<float>() : nullptr, scratch.data_ptr<float>(), 0, st),
-              "cgs_view_backward");
+        // (color_raw: torch.clamp's gradient rule on the unclamped image, folded into the compositor's per-pixel load)
+        check(cgs_view_backward_render(B, (int)m, fp(cp), fp(w), isb, fp(coef), (float)eps, norms.data_ptr<double>(), fp(ol),
+                                       has_mk ? fp(*mk) : nullptr, (float)mask_thr, geom.data_ptr(), binb.data_ptr(), img.data_ptr(),
+                                       fp(bgc), (int)W, (int)H, fp(view), fp(proj), fp(cpos), (float)tanx, (float)tany,
+                                       radii.data_ptr<int>(), fp(g_color), has(color_raw) ? fp(*color_raw) : nullptr,
+                                       g_m2d.data_ptr<float>(), g_cp.data_ptr<float>(), g_w.data_ptr<float>(), g_ol.data_ptr<float>(),
+                                       has_mk ? g_mk.data_ptr<float>() : nullptr, scratch.data_ptr<float>(), 0, st),
+              "cgs_view_backward_render");
     }
     return py::make_tuple(g_cp, g_w, g_ol, has_mk ? py::cast(g_mk) : py::none(), g_m2d);
 }

@@ -184,6 +184,18 @@ int cgs_view_forward_begin(int B, int m, const float* curve_points, const float*
                      const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
                      float* out_color, float* out_invdepth, float* out_all_map, int* radii, float* xyz, float* rotation,
                      float* scaling, void* stream);
+/* The view forward WITH render()'s epilogue (gaussian_renderer/__init__.py:138-145) written by the compositor itself instead of
+ * a separate pass over the image (cgs_render_epilogue below): out_color_clamped [H,W] = clamp(out_color, 0, 1) beside the raw
+ * out_color (torch.clamp's gradient rule needs the raw value: cgs_view_backward_render), out_rend_dir [3,H,W] = all_map[0:3]
+ * taken from view to world space; either may be NULL.  Unit colours only (no colors_precomp); checked != 0: like
+ * cgs_view_forward_begin (returns a handle for cgs_view_forward_wait), checked == 0: like cgs_view_forward (sync-free). */
+int cgs_view_forward_render(int checked, int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier,
+                            const float* coef, float eps, double* norms, const float* opacity_logit, const float* mask_logit,
+                            float mask_thr, void* geometry_buffer, void* binning_buffer, size_t binning_bytes, void* image_buffer,
+                            uint32_t bucket_capacity, const float* background, int width_px, int height_px, const float* viewmatrix,
+                            const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, float* out_color,
+                            float* out_invdepth, float* out_all_map, int* radii, float* out_color_clamped, float* out_rend_dir,
+                            void* stream);
 int64_t cgs_view_forward_wait(int handle, int64_t* n_visible);
 void cgs_view_forward_abandon(int handle);
 /* Epilogue of render() on the fused route, /root/reference/gaussian_renderer/__init__.py:138-145 in one launch: color_out [H,W] =
@@ -226,6 +238,16 @@ int cgs_view_backward(int B, int m, const float* curve_points, const float* widt
                       int width_px, int height_px, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                       float tan_fovx, float tan_fovy, const int* radii, const float* dL_dout_color,
                       const float* dL_drotation_extra, float* dL_dmeans2D, float* dL_dcurve_points, float* dL_dwidth,
+                      float* dL_dopacity_logit, float* dL_dmask_logit, float* scratch, int flags, void* stream);
+/* cgs_view_backward for an image that went through render()'s clamp: dL_dout_color is the gradient of the CLAMPED image,
+ * color_raw the forward's unclamped one; the gradient counts only where 0 <= color_raw <= 1 (torch.clamp's rule), applied
+ * where the compositor loads the pixel's upstream gradient -- no separate cgs_clamp_backward pass.  Unit colours only. */
+int cgs_view_backward_render(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
+                      float eps, double* norms, const float* opacity_logit, const float* mask_logit, float mask_thr,
+                      void* geometry_buffer, const void* binning_buffer, const void* image_buffer, const float* background,
+                      int width_px, int height_px, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                      float tan_fovx, float tan_fovy, const int* radii, const float* dL_dout_color, const float* color_raw,
+                      float* dL_dmeans2D, float* dL_dcurve_points, float* dL_dwidth,
                       float* dL_dopacity_logit, float* dL_dmask_logit, float* scratch, int flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

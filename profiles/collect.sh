@@ -21,6 +21,8 @@ timeout 240 rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_WR SQ_I
 timeout 240 rocprofv3 --pmc SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_INSTS_FLAT SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL --kernel-trace --output-format csv -d $O/pmc3 -- $B --steps 4 --warmup 1 > $O/pmc3.log 2>&1
 timeout 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $B --steps 4 --warmup 1 > $O/fetch.log 2>&1
 timeout 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $B --steps 4 --warmup 1 > $O/write.log 2>&1
+# the operator-API instances (GaussianRasterizer: gated unit backward, general training / colour / all_map / all-gradient backward)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_general -- python $R/profiles/probes/general_instances.py cfg3 12 > $O/trace_general.log 2>&1
 # the graph-replay schedule of the default bench command, kernel trace only (durations overlap across streams)
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_graph -- python $R/bench.py --no-cpu-baseline --no-kernel-times --no-train-step --steps 4 --warmup 1 --min-seconds 0 > $O/trace_graph.log 2>&1
 find $O -name "*.csv" | wc -l

@@ -13,7 +13,10 @@ config = sys.argv[3] if len(sys.argv) > 3 else "cfg3"
 root = f"gpurun_out/{tag}"
 
 # the bench's one-off parity call runs other template instances than the timed per-view path: keep them apart
-SHORT = [("k_render_bwd3<false, false, true", "render_bwd_colour_grad"), ("k_render_fwd3<true, false", "render_fwd_presorted"),
+SHORT = [("k_render_bwd3<false, false, true", "render_bwd_colour_grad"), ("k_render_bwd3<true, false, true", "render_bwd_colour_allmap"),
+         ("k_render_bwd3<true, true, true", "render_bwd_all_grad"), ("k_render_bwd3<false, false, false", "render_bwd_training_general"),
+         ("k_render_bwd_unit<16", "render_bwd_unit_gated"),
+         ("k_render_fwd3<true, false", "render_fwd_presorted"), ("k_render_fwd3<true, true, false", "render_fwd_general"),
          ("k_render_bwd", "render_bwd"), ("k_render_fwd", "render_fwd"), ("k_tile_rank_sort", "tile_sort"),
          ("k_tile_sort", "tile_sort_big"), ("k_scatter", "scatter"), ("k_preprocess_fwd", "preprocess_fwd"),
          ("k_preprocess_bwd", "preprocess_bwd"), ("k_scan_tiles", "scan_tiles"), ("k_sample_f12", "sample_f12"),
@@ -50,6 +53,14 @@ stats("trace_graph", f"profiles/{rnd}_kernel_stats_graph.csv",
       "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-kernel-times --no-train-step --steps 16 "
       "--warmup 2   (default schedule: 3 views in flight, one hipGraph replay per view; kernels of different views overlap, "
       "so per-kernel durations are inflated relative to the serial schedule)\n")
+
+if glob.glob(f"{root}/trace_general/*/*_kernel_stats.csv"):
+    stats("trace_general", f"profiles/{rnd}_kernel_stats_general.csv",
+          "# rocprofv3 --kernel-trace --stats -- python profiles/probes/general_instances.py cfg3 12   (the operator API, "
+          "GaussianRasterizer: every backward instance -- k_render_bwd_unit<16, true> gated unit kernel of the reference's own call, "
+          "k_render_bwd3<false, false, false> training instance with the unit route off, <false, false, true> colour gradient, "
+          "<true, false, true> + all_map, <true, true, true> + inverse depth --, the general sorting forward "
+          "k_render_fwd3<true, true, false, true>; cfg3 view 0; MI355X gfx950)\n")
 
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
 # one counter file per pass: gpurun MERGES a new collection into an existing gpurun_out/<tag>/, so a pass directory can hold
