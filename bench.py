@@ -891,17 +891,18 @@ def main():
                 # rebuilds after every optimizer step and this loop keeps)
                 torch.autograd.backward(pkg["render"], dL_dcolor.reshape(pkg["render"].shape), retain_graph=True)
         def dropin_time(**kw):
-            """ms per view: median over 7 passes of all cameras (every camera rendered twice before: bucket capacities and
+            """ms per view: median over 7 timings of 3 passes of all cameras (every camera rendered twice before: bucket capacities and
             binning hints of each view are settled, so no pass contains an overflow redo; the median drops host hiccups)."""
             for _ in range(2):
                 dropin_pass(tcams, **kw)
             torch.cuda.synchronize()
             ts_ = []
-            for _ in range(7):
+            for _ in range(7):   # (one synchronisation per 24 views: the pipeline's fill / drain is not the steady state)
                 td0 = time.perf_counter()
-                dropin_pass(tcams, **kw)
+                for _ in range(3):
+                    dropin_pass(tcams, **kw)
                 torch.cuda.synchronize()
-                ts_.append((time.perf_counter() - td0) / len(tcams) * 1e3)
+                ts_.append((time.perf_counter() - td0) / (3 * len(tcams)) * 1e3)
             return round(sorted(ts_)[len(ts_) // 2], 4)
         for name, kw in (("dropin_view_ms", {}), ("dropin_view_no_visibility_ms", {"compute_visibility": False, "compute_rend_dir": False}),
                          ("dropin_view_general_route_ms", {"fused": False})):

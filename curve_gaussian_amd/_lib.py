@@ -41,6 +41,7 @@ SIGNATURES = {
     "cgs_clamp_backward": (_i, [_i64, _vp, _vp, _vp, _vp]),
     "cgs_bucket_capacity_hint": (C.c_uint32, [_i, _i, _i]),
     "cgs_last_forward_visible": (_i64, []),
+    "cgs_visible_indices": (_i, [_i, _vp, _vp, _i, _i, _vp, _vp]),
     "cgs_view_shared_begin": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cgs_view_shared_end": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _vp]),
     "cgs_view_backward_scratch_floats": (C.c_size_t, [_i, _i]),

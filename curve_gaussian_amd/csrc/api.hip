@@ -171,8 +171,11 @@ using namespace cgs;
 
 // Longest tile list of a finished scatter, for the checked (blocking) view forward: one small launch between the scatter
 // and the compositor, so the host's wait ends when the BINNING is done and the compositor is still running.
+constexpr int STAT_BLOCKS = 64;            // blocks of k_count_stats = chunks of k_visible_compact
+constexpr int VIS_COUNT_WORD = 16;         // work[16 .. 16 + STAT_BLOCKS): splats with radii > 0 per chunk of ceil(P / STAT_BLOCKS)
 __global__ void __launch_bounds__(256) k_count_stats(const uint32_t* __restrict__ tile_count, int tiles, const int* __restrict__ radii,
-                                                     int P, const uint32_t* __restrict__ big, uint32_t* __restrict__ out4) {
+                                                     int P, const uint32_t* __restrict__ big, uint32_t* __restrict__ out4,
+                                                     uint32_t* __restrict__ vis_counts) {
     // (same-address atomics serialise at ~15 ns each: one per wave -- 768 of them -- made this reduction take 12.7 us of the
     // host's critical path, profiles/r05_kernel_stats.csv; one per BLOCK after an LDS step: 64 blocks x 3)
     __shared__ uint32_t s_part[3][4];
@@ -182,7 +185,11 @@ __global__ void __launch_bounds__(256) k_count_stats(const uint32_t* __restrict_
         mx = max(mx, c);
         sum += c;
     }
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256) vis += radii[i] > 0 ? 1u : 0u;
+    // visible splats of this block's CONTIGUOUS chunk: the per-chunk counts are what k_visible_compact needs to write
+    // (radii > 0).nonzero() in order without a scan of its own
+    const int chunk = (P + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int lo = blockIdx.x * chunk, hi = min(P, lo + chunk);
+    for (int i = lo + threadIdx.x; i < hi; i += 256) vis += radii[i] > 0 ? 1u : 0u;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
@@ -196,11 +203,40 @@ __global__ void __launch_bounds__(256) k_count_stats(const uint32_t* __restrict_
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        const uint32_t bvis = s_part[2][0] + s_part[2][1] + s_part[2][2] + s_part[2][3];
+        vis_counts[blockIdx.x] = bvis;
         atomicAdd(&out4[0], s_part[0][0] + s_part[0][1] + s_part[0][2] + s_part[0][3]);                  // num_rendered
         atomicMax(&out4[1], max(max(s_part[1][0], s_part[1][1]), max(s_part[1][2], s_part[1][3])));      // longest tile list
-        // splats with radii > 0 (sizes render()'s visibility_filter without a host sync)
-        atomicAdd(&out4[2], s_part[2][0] + s_part[2][1] + s_part[2][2] + s_part[2][3]);
+        atomicAdd(&out4[2], bvis);   // splats with radii > 0 (sizes render()'s visibility_filter without a host sync)
         if (blockIdx.x == 0) out4[3] = *big;   // splats with oversized tile rects (final after the scatter)
+    }
+}
+// (radii > 0).nonzero() (gaussian_renderer/__init__.py:150) in one launch: block b writes the indices of its chunk's
+// visible splats, in order, behind those of the chunks before it (their counts come from k_count_stats).
+__global__ void __launch_bounds__(256) k_visible_compact(const int* __restrict__ radii, int P, const uint32_t* __restrict__ vis_counts,
+                                                         long long* __restrict__ out) {
+    __shared__ uint32_t s_wave[4];
+    uint32_t base = 0;
+    for (int b = 0; b < (int)blockIdx.x; b++) base += vis_counts[b];   // (<= 63 uniform loads)
+    const int chunk = (P + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int lo = blockIdx.x * chunk, hi = min(P, lo + chunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i0 = lo; i0 < hi; i0 += 256) {
+        const int i = i0 + (int)threadIdx.x;
+        const bool v = i < hi && radii[i] > 0;
+        const uint64_t bal = __ballot(v);
+        if (lane == 0) s_wave[wave] = (uint32_t)__builtin_popcountll(bal);
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const uint32_t c = s_wave[w];
+            before += w < wave ? c : 0u;
+            all += c;
+        }
+        if (v) out[base + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (long long)i;
+        base += all;
+        __syncthreads();
     }
 }
 
@@ -315,6 +351,7 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
                               int debug, void* stream_) {
     (void)prefiltered;
     hipStream_t s = (hipStream_t)stream_;
+    g_last_visible = -1;   // (set again by the bucket path, whose status readback carries the count)
     if (P < 0 || width <= 0 || height <= 0 || !out_color || !out_invdepth || !out_all_map || !background ||
         !viewmatrix || !projmatrix) {
         set_error("cgs_rasterize_forward: invalid argument (P=%d W=%d H=%d or NULL output/camera pointer)", P, width, height);
@@ -423,7 +460,8 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
             // sorts every tile's bucket itself, like the sync-free forward's -- is queued behind them before the host waits.
             // (Round 4 ran a separate sort launch here so that the readback could follow it: 30 us of kernel per view.)
             uint32_t* const stat = img.work + 4;   // four words of the (cleared) work block
-            hipLaunchKernelGGL(k_count_stats, dim3(64), dim3(256), 0, s, img.tile_count, tiles, radii, P, img.total + 3, stat);
+            hipLaunchKernelGGL(k_count_stats, dim3(STAT_BLOCKS), dim3(256), 0, s, img.tile_count, tiles, radii, P, img.total + 3, stat,
+                               img.work + VIS_COUNT_WORD);
             {
                 hipError_t e = hipMemcpyAsync(h_tot, stat, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
                 if (e == hipSuccess) e = hipEventRecord(ev, s);
@@ -444,6 +482,7 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
             if (!wait_totals()) return CGS_ERR_HIP;
             const uint32_t longest = h_tot[1];
             const int64_t Rb = (int64_t)h_tot[0];   // (= the sum of the list lengths whenever no bucket overflowed)
+            g_last_visible = (int64_t)h_tot[2];
             hints_update(P, width, height, (uint64_t)longest <= cap ? Rb : -1, longest, (int64_t)h_tot[3]);
             if ((uint64_t)longest <= cap) {
                 g_last_stats[0] = Rb; g_last_stats[1] = (int64_t)longest; g_last_stats[2] = 1;
@@ -827,7 +866,8 @@ static int64_t view_forward_impl(int mode, int B, int m, const float* curve_poin
         ViewStat& vs = g_view_slots[slot];
         // four words of the (cleared) work block
         uint32_t* const stat = img.work + 4;
-        hipLaunchKernelGGL(k_count_stats, dim3(64), dim3(256), 0, s, img.tile_count, tiles, radii, P, img.total + 3, stat);
+        hipLaunchKernelGGL(k_count_stats, dim3(STAT_BLOCKS), dim3(256), 0, s, img.tile_count, tiles, radii, P, img.total + 3, stat,
+                               img.work + VIS_COUNT_WORD);
         hipError_t e = hipMemcpyAsync(vs.h, stat, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipEventRecord(vs.ev, s);
         if (e != hipSuccess) {
@@ -926,6 +966,19 @@ int cgs_view_forward_shared(int B, int m, const float* curve_points, const float
                                   tan_fovy, out_color, out_invdepth, out_all_map, radii, xyz, rotation, scaling, stream_);
 }
 int64_t cgs_last_forward_visible(void) { return g_last_visible; }
+int cgs_visible_indices(int P, const int* radii, const void* image_buffer, int width, int height, int64_t* out_indices, void* stream_) {
+    if (P <= 0 || !radii || !image_buffer || width <= 0 || height <= 0 || !out_indices) {
+        set_error("cgs_visible_indices: invalid argument");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    const size_t tiles = (size_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+    char* ichunk = (char*)const_cast<void*>(image_buffer);
+    ImageState img = image_from_chunk(ichunk, (size_t)width * height, tiles);
+    hipLaunchKernelGGL(k_visible_compact, dim3(STAT_BLOCKS), dim3(256), 0, (hipStream_t)stream_, radii, P, img.work + VIS_COUNT_WORD,
+                       (long long*)out_indices);
+    if (!check_launch("visible_indices", false, (hipStream_t)stream_)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
 uint32_t cgs_bucket_capacity_hint(int P, int width, int height) {
     const int64_t mx = hints_load(P, width, height).max;
     if (mx <= 0) return 0u;

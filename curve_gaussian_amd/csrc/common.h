@@ -43,7 +43,7 @@ struct GeomState {            // carved from the geometry buffer
     float* rgb;               // [P]   SH-evaluated colour (SH path only)
     uint8_t* clamped;         // [P]
 };
-constexpr int WORK_WORDS = 64 * 32;   // 64 queue counters, one per 128-byte line (render_pipe.hip)
+constexpr int WORK_WORDS = 64 * 32;   // statistics of the checked forward [4..8), non-unit verdict [8], visible counts per chunk [16..80)
 constexpr int TOTAL_PARTS = 256;
 constexpr int TOTAL_WORDS = 4 + 2 * TOTAL_PARTS;
 struct ImageState {           // carved from the image buffer
@@ -52,7 +52,7 @@ struct ImageState {           // carved from the image buffer
     uint2* ranges;            // [tiles]  [start,end) in the sorted list
     uint32_t* tile_count;     // [tiles]
     uint32_t* tile_cursor;    // [tiles]
-    uint32_t* work;           // [WORK_WORDS]  cleared with the histogram: the tile-queue counters of the persistent forward compositor
+    uint32_t* work;           // [WORK_WORDS]  cleared with the histogram (api.hip: statistics, verdict and count words)
     uint32_t* total;          // [TOTAL_WORDS]  [0] = R, [1] = longest list (exact path); [4 + 2k], [5 + 2k] = partial
                               //                sum / max of the tile lists with tile % TOTAL_PARTS == k (bucket path)
 };

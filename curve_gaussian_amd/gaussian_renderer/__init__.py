@@ -98,13 +98,14 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_
                 raise
             if compute_rend_dir and fold:
                 pkg["rend_dir"] = rend_dir
-            ok, n_visible = VR.finish(pend.pop() if pend else None)
+            this = pend.pop() if pend else None
+            ok, n_visible = VR.finish(this)
             if ok:
                 break
             # a tile list outgrew its bucket (first view of a new scene, or a much denser one): the capacity has been raised
             screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True, device=dev)
         if compute_visibility:
-            pkg["visibility_filter"] = VR.visible_indices(radii, n_visible)
+            pkg["visibility_filter"] = VR.visible_indices(radii, n_visible, this)
         return pkg
     raster_settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
@@ -132,8 +133,12 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_
     rendered_image, radii, depth_image, out_all_map = rasterizer(
         means3D=means3D, means2D=means2D, shs=None, colors_precomp=colors_precomp, opacities=opacity, scales=scales,
         rotations=rotations, all_map=input_all_map, cov3D_precomp=cov3D_precomp)
+    # the blocking forward's status readback carries the radii > 0 count whenever it took the bucket path (-1 otherwise):
+    # visibility_filter then needs no device-wide sync
+    from .. import _lib as L
+    n_visible = int(L.load().cgs_last_forward_visible()) if (compute_visibility and not static_bucket_cap) else None
     return _package(viewpoint_camera, pc, rendered_image, radii, depth_image, out_all_map, screenspace_points,
-                    use_trained_exp, clamp, compute_rend_dir, compute_visibility)
+                    use_trained_exp, clamp, compute_rend_dir, compute_visibility, n_visible)
 
 
 class _Epilogue(torch.autograd.Function):

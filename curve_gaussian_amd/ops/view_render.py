@@ -25,10 +25,11 @@ class Pending:
     """One eager forward between cgs_view_forward_begin and cgs_view_forward_wait: the library's handle and what finish()
     needs to judge the readback.  Carried by the caller (render() gets it back from view_render), so forwards of different
     threads, devices, streams or models never see each other's."""
-    __slots__ = ("handle", "key", "cap")
+    __slots__ = ("handle", "key", "cap", "img")
 
-    def __init__(self, handle, key, cap):
+    def __init__(self, handle, key, cap, img=None):
         self.handle, self.key, self.cap = handle, key, cap
+        self.img = img     # the forward's image buffer: holds the per-chunk visible counts cgs_visible_indices reads
 
     def __del__(self):   # dropped without finish() (an exception in between): give the slot back
         if self.handle is not None and self.handle >= 0:
@@ -108,7 +109,7 @@ class _ViewRender(torch.autograd.Function):
                     _f(mask_thr), None, L.ptr(geom), L.ptr(binb), nbin, L.ptr(img), cap, L.ptr(bgc), W, H, L.ptr(view),
                     L.ptr(proj), L.ptr(campos), _f(tanx), _f(tany), L.ptr(color), L.ptr(invd), L.ptr(amap), L.ptr(radii),
                     None, None, None, st), "cgs_view_forward_begin")
-                pend = Pending(handle, (dev.index, P, W, H), cap)
+                pend = Pending(handle, (dev.index, P, W, H), cap, img)
                 if pending_out is not None:
                     pending_out.append(pend)
                 else:   # nobody will call finish(): wait here, like cgs_view_forward_checked
@@ -157,7 +158,7 @@ class _ViewRender(torch.autograd.Function):
                 off, nw = int(lib.cgs_image_status_offset(W, H)), int(lib.cgs_status_words())
                 status_sink.append(img[off:off + 4 * nw].view(torch.int32))
         else:
-            pend = Pending(handle, (dev.index, P, W, H), cap)
+            pend = Pending(handle, (dev.index, P, W, H), cap, img)
             if pending_out is not None:
                 pending_out.append(pend)
             else:
@@ -291,8 +292,18 @@ def finish(pend):
     return False, -1
 
 
-def visible_indices(radii, n_visible):
-    """(radii > 0).nonzero() (gaussian_renderer/__init__.py:150) -- without the device-wide sync when the count is known."""
+def visible_indices(radii, n_visible, pend=None):
+    """(radii > 0).nonzero() (gaussian_renderer/__init__.py:150).  With the count known (the checked forward's status readback
+    carries it) nothing waits for the device; with the forward's `Pending` as well it is ONE launch of the library
+    (cgs_visible_indices: the forward left per-chunk counts in its image buffer) instead of a compare + nonzero_static."""
     if n_visible is not None and n_visible >= 0:
+        if pend is not None and pend.img is not None and radii.is_cuda and radii.dtype == torch.int32 and radii.numel() > 0:
+            out = torch.empty((int(n_visible), 1), dtype=torch.int64, device=radii.device)
+            if n_visible > 0:
+                _dev, _P, W, H = pend.key
+                with L.device_guard(radii.device):
+                    L.check(L.load().cgs_visible_indices(radii.numel(), L.ptr(radii), L.ptr(pend.img), W, H, L.ptr(out),
+                                                         L.raw_stream(radii.device)), "cgs_visible_indices")
+            return out
         return torch.nonzero_static(radii > 0, size=int(n_visible))
     return (radii > 0).nonzero()

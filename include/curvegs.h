@@ -209,6 +209,11 @@ uint32_t cgs_bucket_capacity_hint(int P, int width, int height);
 /* Number of splats with radii > 0 in the calling thread's last cgs_view_forward_checked (-1: none yet); the two-halves form
  * hands it out through cgs_view_forward_wait. */
 int64_t cgs_last_forward_visible(void);
+/* (radii > 0).nonzero() (gaussian_renderer/__init__.py:150) in ONE launch and without a host sync, for the radii of a CHECKED
+ * forward (cgs_view_forward_checked / _begin / _render with checked != 0, or cgs_rasterize_forward on its bucket path): that
+ * forward left the visible count of every 1/64th of the splats in its image buffer, and n_visible = their sum came back with
+ * its status readback.  out_indices [n_visible] int64, ascending (what torch's nonzero() returns, as a column). */
+int cgs_visible_indices(int P, const int* radii, const void* image_buffer, int width, int height, int64_t* out_indices, void* stream);
 /* Several views of ONE parameter state (a view batch between two optimizer steps; not the reference's one-view iteration):
  * cgs_view_forward_shared is cgs_view_forward without the grid-wide norm pass of prepare_scaling_rot, and cgs_view_backward
  * with CGS_VIEW_SHARED in its flags adds its per-splat gradients into `scratch` and skips the last pass of the sampling

@@ -157,6 +157,24 @@ def test_fused_route_resamples_with_the_eps_of_prepare_scaling_rot(monkeypatch):
     assert not torch.equal(a["render"], d["render"])
 
 
+@pytest.mark.parametrize("B", [1, 37, 2000])
+def test_visibility_filter_is_nonzero_of_radii_in_one_launch(B):
+    """render()["visibility_filter"] == (radii > 0).nonzero() (gaussian_renderer/__init__.py:150): the fused route writes it with
+    cgs_visible_indices from the per-chunk counts its checked forward left in the image buffer (no compare / nonzero kernels,
+    no host sync); splat counts that do not divide into the 64 chunks, a camera that culls part of the cloud."""
+    from curve_gaussian_amd.gaussian_renderer import PipelineParams, render
+    c, mask, cam = _small(B=B, seed=9)
+    cam = S.make_camera((0.5, 0.5, 0.5), (0.9, 0.2, 0.5), (0, 0, 1), 96, 128).to(DEV)     # inside the cloud: near culls
+    gm = _model(c, mask)
+    bg = torch.zeros(3, device=DEV)
+    for fused in (None, False):
+        pkg = render(cam, gm, PipelineParams(), bg, fused=fused)
+        want = (pkg["radii"] > 0).nonzero()
+        got = pkg["visibility_filter"]
+        assert got.dtype == want.dtype and got.shape == want.shape and torch.equal(got, want), fused
+        assert 0 < want.shape[0] < pkg["radii"].shape[0] or B == 1
+
+
 def test_two_models_interleave_their_fused_forwards():
     """Pending forwards are carried by handle (cgs_view_forward_begin -> cgs_view_forward_wait(handle)): two view_render calls
     of different models / image sizes begun back to back and finished in the opposite order do not disturb each other."""
