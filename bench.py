@@ -884,9 +884,16 @@ def main():
         # pipeline flags this is ONE autograd node over cgs_view_forward_checked / cgs_view_backward -- the headline kernels.
         from curve_gaussian_amd.gaussian_renderer import PipelineParams, render as dropin_render
         pipe = PipelineParams()
+        import ctypes as _C
+        exact_path_views = [0]
+        _path = _C.c_int(0)
+
         def dropin_pass(cams, **kw):
             for c in cams:
                 pkg = dropin_render(c, gm, pipe, bg, **kw)
+                if kw.get("fused") is False:   # did this blocking forward fall back to the exact layout (a bucket overflow)?
+                    lib.cgs_last_forward_stats(None, None, _C.byref(_path))
+                    exact_path_views[0] += 1 if _path.value == 0 else 0
                 # (retain_graph: the general route differentiates through the prepare_scaling_rot graph, which train.py
                 # rebuilds after every optimizer step and this loop keeps)
                 torch.autograd.backward(pkg["render"], dL_dcolor.reshape(pkg["render"].shape), retain_graph=True)
@@ -906,7 +913,9 @@ def main():
             return round(sorted(ts_)[len(ts_) // 2], 4)
         for name, kw in (("dropin_view_ms", {}), ("dropin_view_no_visibility_ms", {"compute_visibility": False, "compute_rend_dir": False}),
                          ("dropin_view_general_route_ms", {"fused": False})):
+            exact_path_views[0] = 0
             out[name] = dropin_time(**kw)
+        out["dropin_general_route_exact_path_views"] = exact_path_views[0]   # of 8 x (2 + 21) forwards: bucket overflows redone
         # the same two routes through the ctypes bindings instead of the compiled host shim (CGS_TORCH_SHIM=0), same process, same box
         from curve_gaussian_amd import diff_cur_rasterization as _DCR
         prev_env = os.environ.get("CGS_TORCH_SHIM")

@@ -541,6 +541,29 @@ def test_binning_hints_are_kept_per_workload_shape():
     assert paths[:2] == [0, 0] and all(p == 1 for p in paths[3:]), paths
 
 
+def test_binning_hints_survive_a_run_of_sparser_views():
+    """A training loop cycles through views whose longest tile lists differ by tens of per cent: ten sparser views in a row
+    must not shrink the bucket capacity so far that the next dense view overflows and is redone through the exact path (the
+    hint is a SLOWLY decaying maximum: 1/1024 per call)."""
+    dev = torch.device(DEV)
+    H, W = 96, 144
+    sp = S.random_splats(4000, 95, scale_range=(0.004, 0.05))
+    dense = S.make_camera((0.5, -3.5, 0.7), (0.5, 0.5, 0.5), (0, 0, 1), H, W)     # far: the cloud falls into few tiles, long lists
+    sparse = S.make_camera((0.5, -1.2, 0.7), (0.5, 0.5, 0.5), (0, 0, 1), H, W)    # close: the same splats spread over the image
+    _raster_raw(sp, dense, H, W, dev, reset_hints=True)
+    assert _forward_stats()[2] == 0
+    ref = _raster_raw(sp, dense, H, W, dev)
+    assert _forward_stats()[2] == 1
+    long_dense = _forward_stats()[1]
+    for _ in range(10):
+        _raster_raw(sp, sparse, H, W, dev)
+        assert _forward_stats()[2] == 1
+    assert _forward_stats()[1] < 0.8 * long_dense, "the sparse view is meant to have clearly shorter lists"
+    out = _raster_raw(sp, dense, H, W, dev)
+    assert _forward_stats()[2] == 1, "the dense view overflowed its buckets after a run of sparser views"
+    assert out[0] == ref[0] and torch.equal(out[1], ref[1])
+
+
 def test_binning_hints_carry_over_a_topology_edit():
     """Densify / prune / split change P by a few curves: the new cloud's first forward is seeded from the most recent history
     of the same resolution (num_rendered scaled by the splat ratio) and runs the single-pass bucket path at once -- with the
