@@ -956,7 +956,11 @@ int cgs_view_forward_render(int checked, int B, int m, const float* curve_points
 }
 int64_t cgs_view_forward_wait(int handle, int64_t* n_visible) { return view_forward_wait(handle, n_visible); }
 void cgs_view_forward_abandon(int handle) {
-    if (handle >= 0 && handle < VIEW_SLOTS) view_slot_release(handle);
+    if (handle < 0 || handle >= VIEW_SLOTS || !g_view_slots[handle].busy) return;
+    // the slot's readback may still be in flight: let it land before the pinned words can be handed to another forward (a
+    // later forward on ANOTHER stream would otherwise race with it)
+    (void)hipEventSynchronize(g_view_slots[handle].ev);
+    view_slot_release(handle);
 }
 int cgs_view_forward_shared(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
                      float eps, double* norms, const float* opacity_logit, const float* mask_logit, float mask_thr,
