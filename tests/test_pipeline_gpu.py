@@ -810,7 +810,10 @@ def test_unit_colour_instances_agree_with_the_general_ones_on_random_scenes():
         cam = S.make_camera(*cams_at[rng.randrange(len(cams_at))], H, W)
         bg = rng.choice([0.0, 0.0, 0.4])
         out = {}
-        for name, colors in (("unit", None), ("general", torch.ones(B * 12))):
+        # (the general instances run twice: their own run-to-run difference -- float atomics order, amplified by the cancellation
+        # inside the curve-sampling backward -- is the noise floor of the comparison; on a fully opaque 8 000-curve cloud at
+        # 64 x 333 it reaches 3e-4 relative L2 for dL/dwidth, elsewhere 1e-9 .. 1e-5)
+        for name, colors in (("unit", None), ("general", torch.ones(B * 12)), ("general_again", torch.ones(B * 12))):
             vc = _ViewCalls(curves["curve_points"], curves["width"], curves["opacity"], curves["is_bezier"], cam, 4096, colors=colors, bg=bg)
             try:
                 vc.forward()
@@ -832,8 +835,11 @@ def test_unit_colour_instances_agree_with_the_general_ones_on_random_scenes():
         for k in ("color", "omap", "invd"):
             assert amax(u[k], gen[k]) < 2e-5, f"{where}: {k} {amax(u[k], gen[k]):.2e}"
         assert l2(u["m2d"], gen["m2d"]) < 1e-3, f"{where}: dL_dmeans2D {l2(u['m2d'], gen['m2d']):.2e}"
-        for name, a, b in zip(("curve_points", "width", "opacity"), u["g"], gen["g"]):
-            assert l2(a, b) < 1e-3 and bool(torch.isfinite(a).all()), f"{where}: dL/d{name} {l2(a, b):.2e}"
+        for name, a, b, b2 in zip(("curve_points", "width", "opacity"), u["g"], gen["g"], out["general_again"]["g"]):
+            noise = l2(b2, b)
+            assert noise < 1e-3, f"{where}: dL/d{name}: the general instances differ from themselves by {noise:.2e}"
+            assert l2(a, b) < 1e-3 + 4.0 * noise and bool(torch.isfinite(a).all()), \
+                f"{where}: dL/d{name} {l2(a, b):.2e} (run-to-run noise of the general instances {noise:.2e})"
         done += 1
         if done == 16:
             break
