@@ -70,10 +70,18 @@ __global__ void __launch_bounds__(256) k_view_fwd(
 // kernel (18 us alone) stretched to 102 us inside the overlapped schedule (round 2: 0.406 -> 0.385 ms per view at 72
 // VGPRs).  Round 3, with both compositors at 80 VGPRs: 7 / 6 / 5 waves = 23.8 / 20.4 / 18.4 us serial and 792 / 793 / 774
 // Msplats/s with three views in flight -- 6 takes the serial gain without the overlapped loss.
+// Round 5: the waves-per-SIMD bound is a template parameter chosen per launch.  At a million splats (cfg5) the kernel is a
+// sixth of the serial view and its 23 spills at the 80-VGPR cap cost more than the co-residence buys: 6 / 5 / 4 waves =
+// 1 476 - 1 483 / 1 505 / 1 532 Msplats/s with three views in flight there, 815 - 817 / 797 / 800 at cfg3 (same box).
 #ifndef CGS_VIEW_BWD_WAVES
 #define CGS_VIEW_BWD_WAVES 6
 #endif
-__global__ void __launch_bounds__(SAMPLE_BLOCK, CGS_VIEW_BWD_WAVES) k_view_bwd(
+#ifndef CGS_VIEW_BWD_WAVES_LARGE
+#define CGS_VIEW_BWD_WAVES_LARGE 4
+#endif
+constexpr int VIEW_BWD_LARGE_P = 512 * 1024;   // splat count from which the roomier instance is launched
+template <int WAVES>
+__global__ void __launch_bounds__(SAMPLE_BLOCK, WAVES) k_view_bwd(
     int B, int m, int curves_per_block, const float* __restrict__ cp, const float* __restrict__ width,
     const uint8_t* __restrict__ is_bezier, const SampleCoef* __restrict__ coef, float eps, double* __restrict__ norms,
     const float* __restrict__ opacity_logit, const float* __restrict__ mask_logit, float mask_thr,
@@ -195,10 +203,16 @@ void launch_view_backward(hipStream_t s, int B, int m, const float* cp, const fl
     ProfScope p("view_bwd", s);
     const int cpb = SAMPLE_BLOCK / m;
     const ViewParams vp{viewmatrix, projmatrix, tan_fovx, tan_fovy, focal_x, focal_y, W, H, 0, 0};
-    hipLaunchKernelGGL(k_view_bwd, dim3((B + cpb - 1) / cpb), dim3(SAMPLE_BLOCK), 0, s, B, m, cpb, cp, width, is_bezier,
-                       reinterpret_cast<const SampleCoef*>(coef), eps, norms, opacity_logit, mask_logit, mask_thr, campos, vp,
-                       radii, rec, grad_acc, g_rot_raw_extra, dL_dmean2D, g_opacity_logit, g_mask_logit, g_xyz, g_scaling,
-                       gv_cache, accumulate);
+    if ((long long)B * m >= VIEW_BWD_LARGE_P)
+        hipLaunchKernelGGL(k_view_bwd<CGS_VIEW_BWD_WAVES_LARGE>, dim3((B + cpb - 1) / cpb), dim3(SAMPLE_BLOCK), 0, s, B, m, cpb, cp,
+                           width, is_bezier, reinterpret_cast<const SampleCoef*>(coef), eps, norms, opacity_logit, mask_logit,
+                           mask_thr, campos, vp, radii, rec, grad_acc, g_rot_raw_extra, dL_dmean2D, g_opacity_logit, g_mask_logit,
+                           g_xyz, g_scaling, gv_cache, accumulate);
+    else
+        hipLaunchKernelGGL(k_view_bwd<CGS_VIEW_BWD_WAVES>, dim3((B + cpb - 1) / cpb), dim3(SAMPLE_BLOCK), 0, s, B, m, cpb, cp, width,
+                           is_bezier, reinterpret_cast<const SampleCoef*>(coef), eps, norms, opacity_logit, mask_logit, mask_thr,
+                           campos, vp, radii, rec, grad_acc, g_rot_raw_extra, dL_dmean2D, g_opacity_logit, g_mask_logit, g_xyz,
+                           g_scaling, gv_cache, accumulate);
 }
 
 }  // namespace cgs
