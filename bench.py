@@ -884,15 +884,15 @@ def main():
         # pipeline flags this is ONE autograd node over cgs_view_forward_checked / cgs_view_backward -- the headline kernels.
         from curve_gaussian_amd.gaussian_renderer import PipelineParams, render as dropin_render
         pipe = PipelineParams()
-        import ctypes as _C
+        import ctypes as _ct
         exact_path_views = [0]
-        _path = _C.c_int(0)
+        _path = _ct.c_int(0)
 
         def dropin_pass(cams, **kw):
             for c in cams:
                 pkg = dropin_render(c, gm, pipe, bg, **kw)
                 if kw.get("fused") is False:   # did this blocking forward fall back to the exact layout (a bucket overflow)?
-                    lib.cgs_last_forward_stats(None, None, _C.byref(_path))
+                    lib.cgs_last_forward_stats(None, None, _ct.byref(_path))
                     exact_path_views[0] += 1 if _path.value == 0 else 0
                 # (retain_graph: the general route differentiates through the prepare_scaling_rot graph, which train.py
                 # rebuilds after every optimizer step and this loop keeps)
