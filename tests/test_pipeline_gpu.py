@@ -1043,6 +1043,38 @@ def test_bench_default_schedule_over_single_rank_rccl():
     assert out["step_gradient_rel_l2_vs_serial_eager"] < 1e-3
 
 
+def test_bench_default_command_runs_every_section():
+    """`python bench.py --gpus 1 --steps K --warmup W` -- the driver's command, nothing switched off -- end to end on the
+    smallest config: the timed region, per-kernel times, shared sampling, the drop-in routes (shim and ctypes), the operator-API
+    instances (`general_route`), every train-step variant and the CPU baseline all run and land in ONE JSON line with the
+    contract's fields.  (Round 5: a shadowed name crashed the CPU-baseline section of exactly this command while every test
+    that switches sections off stayed green.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--min-seconds", "0.2",
+           "--config", "cfg1", "--cpu-views", "1", "--torch-cpu-splats", "4"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and r.stdout.rstrip().endswith(lines[0]), r.stdout[-2000:]
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["steps"] == 3 and out["warmup"] == 1 and out["value"] > 0
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(out["roofline"])
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(out["cpu_baseline"]) and out["cpu_baseline"]["value"] > 0
+    assert "workload" in out["config"] and "model" not in out["config"]
+    for k in ("dropin_view_ms", "dropin_view_general_route_ms", "dropin_view_ctypes_ms", "train_step_ms", "train_step_eager_ms"):
+        assert out[k] > 0, k
+    gr = out["general_route"]
+    assert set(gr["instances"]) == {"reference_call", "training_general", "colour_grad", "colour_allmap", "all_grad"}
+    assert gr["roofline"]["bound"] == "hbm" and 0 < gr["roofline"]["frac"] < 1
+
+
 def test_connection_loss_matches_the_reference_block():
     """cgs_endpoint_connection_loss (O(B) memory, one sweep) against train.py:133-146 written out with torch.cdist:
     value, gradient w.r.t. the control points (only first and last points receive one), the no-pair case, and end points
