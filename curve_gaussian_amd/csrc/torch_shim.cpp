@@ -266,11 +266,41 @@ py::tuple view_backward(const Tensor& cp, const Tensor& w, const Tensor& ol, con
                         const c10::optional<Tensor>& is_bezier_u8, const Tensor& coef, const Tensor& geom, const Tensor& binb,
                         const Tensor& img, const Tensor& radii, const Tensor& norms, const Tensor& bgc, const Tensor& view,
                         const Tensor& proj, const Tensor& cpos, int64_t m, double mask_thr, double tanx, double tany, int64_t H,
-                        int64_t W, double eps, const c10::optional<Tensor>& g_color_in, const c10::optional<Tensor>& color_raw) {
+                        int64_t W, double eps, const c10::optional<Tensor>& g_color_in, const c10::optional<Tensor>& color_raw,
+                        const c10::optional<std::vector<Tensor>>& sinks) {
     c10::hip::HIPGuardMasqueradingAsCUDA guard(cp.device());
     const int B = (int)cp.size(0), P = B * (int)m;
     const auto fopt = cp.options().dtype(at::kFloat);
     const bool has_mk = has(mk);
+    if (sinks.has_value()) {
+        // Gradient sinks (TrainStep: the optimizer's flat gradient buffer): the four curve-level gradients are ADDED to the
+        // caller's tensors by the kernels themselves (CGS_VIEW_ACCUMULATE) and the node returns None for those inputs, so
+        // autograd has no AccumulateGrad kernels to run for them.
+        const auto& sk = *sinks;
+        if (sk.size() != (has_mk ? 4u : 3u)) raise_cgs("view_backward: grad_sinks must hold one tensor per differentiable curve input");
+        const int64_t want[4] = {(int64_t)B * 12, B, B, has_mk ? mk->numel() : 0};
+        for (size_t i = 0; i < sk.size(); ++i) {
+            require_gpu(sk[i], "grad sink");
+            if (sk[i].scalar_type() != at::kFloat || !sk[i].is_contiguous() || sk[i].numel() != want[i])
+                raise_cgs("view_backward: grad sink " + std::to_string(i) + " must be a contiguous float32 tensor shaped like its parameter");
+        }
+        Tensor g_m2d = g_color_in.has_value() ? at::empty({P, 3}, fopt) : at::zeros({P, 3}, fopt);
+        if (g_color_in.has_value()) {
+            void* st = stream_of(cp);
+            Tensor g_color = f32c(*g_color_in, "grad of render");
+            Tensor scratch = at::empty({(int64_t)cgs_view_backward_scratch_floats(B, (int)m)}, fopt);
+            const uint8_t* isb = has(is_bezier_u8) ? (const uint8_t*)is_bezier_u8->data_ptr() : nullptr;
+            check(cgs_view_backward_render(B, (int)m, fp(cp), fp(w), isb, fp(coef), (float)eps, norms.data_ptr<double>(), fp(ol),
+                                           has_mk ? fp(*mk) : nullptr, (float)mask_thr, geom.data_ptr(), binb.data_ptr(), img.data_ptr(),
+                                           fp(bgc), (int)W, (int)H, fp(view), fp(proj), fp(cpos), (float)tanx, (float)tany,
+                                           radii.data_ptr<int>(), fp(g_color), has(color_raw) ? fp(*color_raw) : nullptr,
+                                           g_m2d.data_ptr<float>(), sk[0].data_ptr<float>(), sk[1].data_ptr<float>(),
+                                           sk[2].data_ptr<float>(), has_mk ? sk[3].data_ptr<float>() : nullptr,
+                                           scratch.data_ptr<float>(), CGS_VIEW_ACCUMULATE, st),
+                  "cgs_view_backward_render");
+        }
+        return py::make_tuple(py::none(), py::none(), py::none(), py::none(), g_m2d);
+    }
     // one allocation for the four curve-level gradients + the screen-space gradient, one for the scratch
     const int64_t n_curve = (int64_t)B * 14, n_mk = has_mk ? mk->numel() : 0;
     Tensor buf = g_color_in.has_value() ? at::empty({n_curve + n_mk + (int64_t)P * 3}, fopt) : at::zeros({n_curve + n_mk + (int64_t)P * 3}, fopt);
@@ -313,5 +343,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
     mod.def("view_forward", &view_forward);
     mod.def("view_wait", &view_wait);
     mod.def("view_abandon", &view_abandon);
-    mod.def("view_backward", &view_backward);
+    mod.def("view_backward", &view_backward, py::arg("cp"), py::arg("w"), py::arg("ol"), py::arg("mk"), py::arg("is_bezier_u8"),
+            py::arg("coef"), py::arg("geom"), py::arg("binb"), py::arg("img"), py::arg("radii"), py::arg("norms"), py::arg("bgc"),
+            py::arg("view"), py::arg("proj"), py::arg("cpos"), py::arg("m"), py::arg("mask_thr"), py::arg("tanx"), py::arg("tany"),
+            py::arg("H"), py::arg("W"), py::arg("eps"), py::arg("g_color"), py::arg("color_raw"), py::arg("sinks") = py::none());
 }

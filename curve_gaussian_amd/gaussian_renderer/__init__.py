@@ -52,9 +52,22 @@ def _param_stamp(pc):
             tuple(pc._curve_points.shape), pc.is_bezier.data_ptr(), pc.is_bezier._version)
 
 
+def _grad_sinks(pc, use_mask):
+    """The parameters' `.grad` tensors as sinks of the fused backward, or None when any of them cannot serve (absent, not
+    float32, not contiguous, or gradients switched off): the ordinary autograd accumulation then applies."""
+    ps = [pc._curve_points, pc._width, pc._opacity] + ([pc._mask] if use_mask else [])
+    if not torch.is_grad_enabled():
+        return None
+    for p in ps:
+        g = p.grad
+        if not p.requires_grad or g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape:
+            return None
+    return [p.grad for p in ps]
+
+
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_sh=False, override_color=None,
            use_trained_exp=False, use_mask=False, mask_thr=0.01, compute_visibility=True, clamp=True,
-           compute_rend_dir=True, static_bucket_cap=0, status_sink=None, fused=None):
+           compute_rend_dir=True, static_bucket_cap=0, status_sink=None, fused=None, grad_sinks=False):
     """Render the scene.  Background tensor (bg_color) must be on the GPU.  Returns the reference's dict
     {render, viewspace_points, visibility_filter, radii, depth, rend_dir, rend_alpha} (:147-155).
 
@@ -65,7 +78,11 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_
     Flags of the reference's signature: ``pipe.compute_cov3D_python`` feeds ``pc.get_covariance`` as cov3D_precomp (:67-68);
     ``use_trained_exp`` applies the exposure with the reference's own expression (:131-135); ``separate_sh=True`` raises the
     TypeError the reference raises (its rasterizer has no ``dc`` argument: SURVEY quirk 20); ``override_color`` and
-    ``pipe.convert_SHs_python`` are overwritten by the unit colours upstream (:96-97) and change nothing here either."""
+    ``pipe.convert_SHs_python`` are overwritten by the unit colours upstream (:96-97) and change nothing here either.
+    ``grad_sinks=True`` (fused route, training loops that own their ``.grad`` buffers): the backward kernels add the gradients
+    of curve points / width / opacity / mask straight into the parameters' existing ``.grad`` tensors -- the same values
+    autograd's AccumulateGrad would have added, three to four kernel launches fewer per iteration; gradient hooks on those
+    parameters do not see this contribution."""
     if separate_sh:   # (:108-119) GaussianRasterizer.forward() got an unexpected keyword argument 'dc'
         raise TypeError("GaussianRasterizer.forward() got an unexpected keyword argument 'dc' (render(separate_sh=True): the "
                         "reference's rasterizer has no separate-SH entry point, gaussian_renderer/__init__.py:108-119)")
@@ -81,6 +98,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_
     if use_fused:
         from ..ops import view_render as VR
         pend = []
+        sinks = _grad_sinks(pc, use_mask) if grad_sinks else None
         while True:
             # clamp and direction map (:138-145) come out of the same autograd node (one epilogue launch); the exposure of
             # use_trained_exp sits between compositor and clamp upstream, so that combination keeps the separate ops
@@ -88,7 +106,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_
             rendered_image, depth_image, out_all_map, radii, rend_dir = VR.view_render(
                 pc._curve_points, pc._width, pc._opacity, pc._mask if use_mask else None, screenspace_points, pc.is_bezier,
                 pc.n_gaussians, mask_thr, bg_color, viewpoint_camera, tanfovx, tanfovy, static_bucket_cap, status_sink,
-                clamp and fold, compute_rend_dir and fold, pend, getattr(pc, "_derived_eps", 1e-8))
+                clamp and fold, compute_rend_dir and fold, pend, getattr(pc, "_derived_eps", 1e-8), sinks)
             try:
                 pkg = _package(viewpoint_camera, pc, rendered_image, radii, depth_image, out_all_map, screenspace_points,
                                use_trained_exp, clamp and not fold, compute_rend_dir and not fold, False)

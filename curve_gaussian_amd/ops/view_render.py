@@ -57,8 +57,9 @@ class _ViewRender(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, curve_points, width, opacity_logit, mask_logit, means2D, is_bezier, m, mask_thr, bg, cam, tanx, tany,
-                static_cap=0, status_sink=None, clamp=False, want_dir=False, pending_out=None, eps=1e-8):
+                static_cap=0, status_sink=None, clamp=False, want_dir=False, pending_out=None, eps=1e-8, grad_sinks=None):
         L.require_gpu_tensor(curve_points, "curve_points")
+        ctx.sinks = grad_sinks
         L.require_gpu_tensor(bg, "bg_color")                       # "Background tensor (bg_color) must be on GPU!" (:23)
         L.require_gpu_tensor(cam.world_view_transform, "viewpoint_camera.world_view_transform")
         lib = L.load()
@@ -180,7 +181,7 @@ class _ViewRender(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_color, g_invd, g_amap, _g_radii, g_dir):
         if g_invd is not None or g_amap is not None or g_dir is not None:
-            return _general_backward(ctx, g_color, g_invd, g_amap, g_dir) + (None,) * 13
+            return _general_backward(ctx, g_color, g_invd, g_amap, g_dir) + (None,) * 14
         cp, w, ol, mk, geom, binb, img, radii, norms, bgc, view, proj, campos = ctx.saved_tensors
         B, m, H, W, mask_thr, tanx, tany, eps = ctx.dims
         lib = L.load()
@@ -188,8 +189,10 @@ class _ViewRender(torch.autograd.Function):
         P = B * m
         mkp = mk if ctx.has_mask else None
         if L.use_shim():   # clamp gradient + cgs_view_backward in one call (csrc/torch_shim.cpp::view_backward)
+            # (ctx.sinks: the kernels add the curve-level gradients to the caller's buffers; None comes back for those inputs)
             return tuple(L.shim().view_backward(cp, w, ol, mkp, ctx.isb, ctx.coef, geom, binb, img, radii, norms, bgc, view, proj,
-                                                campos, m, mask_thr, tanx, tany, H, W, eps, g_color, ctx.raw)) + (None,) * 13
+                                                campos, m, mask_thr, tanx, tany, H, W, eps, g_color, ctx.raw,
+                                                ctx.sinks)) + (None,) * 14
         with L.device_guard(dev):
             f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
             g_cp, g_w, g_ol, g_m2d = f32(B, 4, 3), f32(B, 1), f32(B, 1), f32(P, 3)
@@ -198,7 +201,7 @@ class _ViewRender(torch.autograd.Function):
                 g_cp.zero_(); g_w.zero_(); g_ol.zero_(); g_m2d.zero_()
                 if g_mk is not None:
                     g_mk.zero_()
-                return (g_cp, g_w, g_ol, g_mk, g_m2d) + (None,) * 13
+                return (g_cp, g_w, g_ol, g_mk, g_m2d) + (None,) * 14
             g_color = g_color.float().contiguous()
             if ctx.raw is not None:   # torch.clamp's gradient rule on the unclamped image
                 g_raw = torch.empty_like(g_color)
@@ -212,7 +215,7 @@ class _ViewRender(torch.autograd.Function):
                 L.ptr(campos), _f(tanx), _f(tany), L.ptr(radii), L.ptr(g_color), None, L.ptr(g_m2d), L.ptr(g_cp), L.ptr(g_w),
                 L.ptr(g_ol), L.ptr(g_mk), L.ptr(scratch), 0, L.raw_stream(dev))
             L.check(rc, "cgs_view_backward")
-        return (g_cp, g_w, g_ol, g_mk, g_m2d) + (None,) * 13
+        return (g_cp, g_w, g_ol, g_mk, g_m2d) + (None,) * 14
 
 
 def _general_backward(ctx, g_color, g_invd, g_amap, g_dir):
@@ -261,13 +264,20 @@ def _general_backward(ctx, g_color, g_invd, g_amap, g_dir):
 
 
 def view_render(curve_points, width, opacity_logit, mask_logit, means2D, is_bezier, m, mask_thr, bg, cam, tanx, tany,
-                static_cap=0, status_sink=None, clamp=False, want_dir=False, pending_out=None, eps=1e-8):
+                static_cap=0, status_sink=None, clamp=False, want_dir=False, pending_out=None, eps=1e-8, grad_sinks=None):
     """-> (image [1,H,W] (clamped to [0,1] when `clamp`), inverse depth [1,H,W], all_map [4,H,W], radii [P], world-space
     direction map [3,H,W] or an empty tensor).  Eager callers (static_cap == 0) pass a list as `pending_out`: it receives the
     forward's `Pending`, to be handed to finish() once the caller has queued whatever else it has; without it the call waits
-    for the status readback itself."""
+    for the status readback itself.
+
+    `grad_sinks` (compiled shim only; ignored otherwise): float32 tensors shaped like (curve_points, width, opacity_logit[,
+    mask_logit]) -- normally the parameters' `.grad` -- that the backward kernels ADD their gradients to; the node then hands
+    autograd no gradient for those inputs (no AccumulateGrad kernels).  A loss that reaches depth / all_map / the direction
+    map takes the general backward, which returns its gradients the ordinary way."""
+    if grad_sinks is not None and not L.use_shim():
+        grad_sinks = None
     return _ViewRender.apply(curve_points, width, opacity_logit, mask_logit, means2D, is_bezier, m, mask_thr, bg, cam, tanx,
-                             tany, static_cap, status_sink, clamp, want_dir, pending_out, eps)
+                             tany, static_cap, status_sink, clamp, want_dir, pending_out, eps, grad_sinks)
 
 
 def finish(pend):

@@ -111,7 +111,8 @@ class TrainStep:
         cam, gt = self.cams[vi], self.gts[vi]
         use_mask = it >= self.densify_until_iter
         pkg = render(cam, g, self.pipe, self.bg, use_mask=use_mask, mask_thr=self.mask_threshold,
-                     compute_visibility=not self.fused, clamp=not self.fused, compute_rend_dir=not self.fused)
+                     compute_visibility=not self.fused, clamp=not self.fused, compute_rend_dir=not self.fused,
+                     grad_sinks=self.fused)   # (fused: the backward kernels add into the flat gradient buffer themselves)
         image = pkg["render"]
         if self.fused:   # raw composite in, render()'s clamp applied inside the loss kernels
             loss = photometric_loss(image, gt[:1], self.lambda_mse, self.lambda_dssim, clamp=True)

@@ -137,6 +137,42 @@ def test_fused_route_serves_depth_and_normal_losses(use_mask):
     assert rel < 2e-5, rel
 
 
+@pytest.mark.parametrize("use_mask", [False, True])
+def test_grad_sinks_put_the_same_gradients_into_existing_grad_buffers(use_mask):
+    """render(grad_sinks=True): the backward kernels add into the parameters' `.grad` (what TrainStep(fused=True) uses on its
+    flat gradient buffer); same numbers as autograd's own accumulation, on top of what the buffers already held, and a loss
+    that reaches the geometry maps (general backward) still lands in `.grad` the ordinary way."""
+    from curve_gaussian_amd.gaussian_renderer import PipelineParams, render
+    c, mask, cam = _small()
+    cam = cam.to(DEV)
+    H, W = cam.image_height, cam.image_width
+    bg = torch.zeros(3, device=DEV)
+    gen = torch.Generator().manual_seed(3)
+    dimg = torch.randn(1, H, W, generator=gen).to(DEV)
+    ddepth = torch.randn(1, H, W, generator=gen).to(DEV)
+    names = ["_curve_points", "_width", "_opacity"] + (["_mask"] if use_mask else [])
+    got = {}
+    for sinks in (False, True):
+        gm = _model(c, mask)
+        prior = {}
+        for i, n in enumerate(names):   # something already in the buffers: the sinks must add, not overwrite
+            p = getattr(gm, n)
+            p.grad = torch.full_like(p, 0.25 * (i + 1))
+            prior[n] = p.grad
+        pkg = render(cam, gm, PipelineParams(), bg, use_mask=use_mask, mask_thr=0.3, grad_sinks=sinks)
+        ((pkg["render"] * dimg).sum() + 0.1 * gm._width.sum()).backward()      # (+ a term autograd accumulates itself)
+        pkg = render(cam, gm, PipelineParams(), bg, use_mask=use_mask, mask_thr=0.3, grad_sinks=sinks)
+        ((pkg["render"] * dimg).sum() + (pkg["depth"] * ddepth).sum()).backward()   # depth loss: the general backward
+        for n in names:
+            assert getattr(gm, n).grad is prior[n]          # still the caller's buffer
+        got[sinks] = {n: getattr(gm, n).grad.detach().cpu() for n in names}
+        got[sinks]["m2d"] = pkg["viewspace_points"].grad.detach().cpu()
+    for n in got[False]:
+        assert_close(n, got[True][n], got[False][n], rel=2e-4)
+    if not use_mask:   # a parameter outside the call keeps its own .grad untouched
+        assert gm._mask.grad is None or float(gm._mask.grad.abs().max()) == 0.0
+
+
 def test_fused_route_resamples_with_the_eps_of_prepare_scaling_rot(monkeypatch):
     """prepare_scaling_rot(eps) stamps the eps it used; the fused route (which samples the curves itself) renders with it, so
     both routes draw the same splats for any eps."""
