@@ -971,19 +971,30 @@ def main():
             }
         for prm in (gm._curve_points, gm._width, gm._opacity, gm._mask):
             prm.grad = None
-        ts = TrainStep(gm, tcams, gts)
-        for _ in range(10):
-            ts.step()
-        torch.cuda.synchronize()
-        n_ts = 8
-        chunks = []
-        for _ in range(7):   # median of seven 8-iteration chunks (each view's bucket capacity settled during the warm-up)
+        # Every form of the iteration is timed over the SAME window of a run from the synthetic initial state -- iterations
+        # 4 .. 35 after three warm-up iterations: the optimizer moves the scene (opacities fall against the sparse random
+        # targets), so the work per iteration drifts (cfg3: -25 % over the first 130 iterations) and figures from different
+        # windows are not comparable.
+        n_ts = 32
+
+        def time_eager(ts):
+            for _ in range(3):
+                ts.step()
+            torch.cuda.synchronize()
             tt0 = time.perf_counter()
             for _ in range(n_ts):
                 ts.step()
             torch.cuda.synchronize()
-            chunks.append((time.perf_counter() - tt0) / n_ts * 1e3)
-        eager_ms = sorted(chunks)[len(chunks) // 2]
+            return (time.perf_counter() - tt0) / n_ts * 1e3
+
+        eager_ms = time_eager(TrainStep(gm, tcams, gts))
+        # the same eager iteration without autograd (TrainStep(direct=True): library calls one after the other, exact binning,
+        # nothing captured)
+        gm1 = GaussianCurveModel(0, m, device=dev).create_from_curves(curves["curve_points"], curves["width"],
+                                                                      curves["opacity"], curves["mask"],
+                                                                      curves["is_bezier"])
+        out["train_step_eager_direct_ms"] = round(time_eager(TrainStep(gm1, tcams, gts, direct=True)), 4)
+        del gm1
         # the same iteration replayed as one hipGraph launch (sync-free forward, device-state Adam)
         from curve_gaussian_amd.train_step import GraphedTrainStep
         gm2 = GaussianCurveModel(0, m, device=dev).create_from_curves(curves["curve_points"], curves["width"],
@@ -1051,8 +1062,8 @@ def main():
         out["train_step_ms"] = round(graph_ms, 4)
         out["train_step_eager_ms"] = round(eager_ms, 4)
         out["train_step_graph_recaptures"] = gs.recaptures
-        out["train_step_note"] = ("train_step_ms: GraphedTrainStep (whole iteration = one hipGraph replay); "
-                                  "train_step_eager_ms: TrainStep (Python autograd, ~30 launches).  Iteration = lr update + view pick + render (fused attrs + raster) + edge_aware_loss + fused_ssim "
+        out["train_step_note"] = ("every figure = mean over iterations 4..35 of a run from the synthetic initial state (the work per iteration drifts as the optimizer moves the scene); train_step_ms: GraphedTrainStep (whole iteration = one hipGraph replay); "
+                                  "train_step_eager_ms: TrainStep (Python autograd, ~30 launches); train_step_eager_direct_ms: TrainStep(direct=True), the same eager iteration as plain library calls without autograd (exact binning, nothing captured).  Iteration = lr update + view pick + render (fused attrs + raster) + edge_aware_loss + fused_ssim "
                                   "+ backward + Adam (6 groups) + prepare_scaling_rot; regularisers of train.py:110-146 "
                                   "excluded (SURVEY 8d).  train_step_image_only_forward_ms: the same iteration when the forward "
                                   "writes `render` only (GraphedTrainStep(aux_outputs=False)); NOT the headline: the reference's "

@@ -267,7 +267,7 @@ py::tuple view_backward(const Tensor& cp, const Tensor& w, const Tensor& ol, con
                         const Tensor& img, const Tensor& radii, const Tensor& norms, const Tensor& bgc, const Tensor& view,
                         const Tensor& proj, const Tensor& cpos, int64_t m, double mask_thr, double tanx, double tany, int64_t H,
                         int64_t W, double eps, const c10::optional<Tensor>& g_color_in, const c10::optional<Tensor>& color_raw,
-                        const c10::optional<std::vector<Tensor>>& sinks) {
+                        const c10::optional<std::vector<Tensor>>& sinks, const c10::optional<Tensor>& rot_extra) {
     c10::hip::HIPGuardMasqueradingAsCUDA guard(cp.device());
     const int B = (int)cp.size(0), P = B * (int)m;
     const auto fopt = cp.options().dtype(at::kFloat);
@@ -290,6 +290,20 @@ py::tuple view_backward(const Tensor& cp, const Tensor& w, const Tensor& ol, con
             Tensor g_color = f32c(*g_color_in, "grad of render");
             Tensor scratch = at::empty({(int64_t)cgs_view_backward_scratch_floats(B, (int)m)}, fopt);
             const uint8_t* isb = has(is_bezier_u8) ? (const uint8_t*)is_bezier_u8->data_ptr() : nullptr;
+            if (has(rot_extra)) {
+                // (+ a gradient with respect to the raw splat rotations, e.g. the curve-smoothness regulariser's: enters the
+                // fused chain before it is pulled back to the curves; the plain entry point, no clamp mask)
+                if (has(color_raw)) raise_cgs("view_backward: rot_extra and color_raw exclude each other");
+                Tensor rx = f32c(*rot_extra, "rot_extra");
+                if (rx.numel() != (int64_t)P * 4) raise_cgs("view_backward: rot_extra must be [P,4]");
+                check(cgs_view_backward(B, (int)m, fp(cp), fp(w), isb, fp(coef), (float)eps, norms.data_ptr<double>(), fp(ol),
+                                        has_mk ? fp(*mk) : nullptr, (float)mask_thr, nullptr, geom.data_ptr(), binb.data_ptr(),
+                                        img.data_ptr(), fp(bgc), (int)W, (int)H, fp(view), fp(proj), fp(cpos), (float)tanx, (float)tany,
+                                        radii.data_ptr<int>(), fp(g_color), fp(rx), g_m2d.data_ptr<float>(), sk[0].data_ptr<float>(),
+                                        sk[1].data_ptr<float>(), sk[2].data_ptr<float>(), has_mk ? sk[3].data_ptr<float>() : nullptr,
+                                        scratch.data_ptr<float>(), CGS_VIEW_ACCUMULATE, st),
+                      "cgs_view_backward");
+            } else
             check(cgs_view_backward_render(B, (int)m, fp(cp), fp(w), isb, fp(coef), (float)eps, norms.data_ptr<double>(), fp(ol),
                                            has_mk ? fp(*mk) : nullptr, (float)mask_thr, geom.data_ptr(), binb.data_ptr(), img.data_ptr(),
                                            fp(bgc), (int)W, (int)H, fp(view), fp(proj), fp(cpos), (float)tanx, (float)tany,
@@ -301,6 +315,7 @@ py::tuple view_backward(const Tensor& cp, const Tensor& w, const Tensor& ol, con
         }
         return py::make_tuple(py::none(), py::none(), py::none(), py::none(), g_m2d);
     }
+    if (has(rot_extra)) raise_cgs("view_backward: rot_extra is served together with grad sinks only");
     // one allocation for the four curve-level gradients + the screen-space gradient, one for the scratch
     const int64_t n_curve = (int64_t)B * 14, n_mk = has_mk ? mk->numel() : 0;
     Tensor buf = g_color_in.has_value() ? at::empty({n_curve + n_mk + (int64_t)P * 3}, fopt) : at::zeros({n_curve + n_mk + (int64_t)P * 3}, fopt);
@@ -346,5 +361,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
     mod.def("view_backward", &view_backward, py::arg("cp"), py::arg("w"), py::arg("ol"), py::arg("mk"), py::arg("is_bezier_u8"),
             py::arg("coef"), py::arg("geom"), py::arg("binb"), py::arg("img"), py::arg("radii"), py::arg("norms"), py::arg("bgc"),
             py::arg("view"), py::arg("proj"), py::arg("cpos"), py::arg("m"), py::arg("mask_thr"), py::arg("tanx"), py::arg("tany"),
-            py::arg("H"), py::arg("W"), py::arg("eps"), py::arg("g_color"), py::arg("color_raw"), py::arg("sinks") = py::none());
+            py::arg("H"), py::arg("W"), py::arg("eps"), py::arg("g_color"), py::arg("color_raw"), py::arg("sinks") = py::none(),
+            py::arg("rot_extra") = py::none());
 }

@@ -21,8 +21,14 @@ class TrainStep:
     def __init__(self, gaussians, cameras, gt_images, lambda_mse=10.0, lambda_dssim=0.1, lambda_mask=0.0005,
                  densify_until_iter=7000, mask_threshold=0.01, seed=0, rank=0, world=1, fused=True,
                  regularisers=False, opacity_loss_weight=0.01, lambda_curve_smo=0.1, lambda_width=0.01,
-                 lambda_points_conn=0.1, conn_from_iter=7000):
+                 lambda_points_conn=0.1, conn_from_iter=7000, direct=False):
         self.g = gaussians
+        # direct=True (fused only, compiled host shim): the iteration without autograd -- the checked view forward, the
+        # photometric loss kernels, the view backward (adding into the flat gradient buffer), Adam and prepare_scaling_rot
+        # called one after the other.  Same kernels and numbers as the autograd form; a third of its host time.  Unlike
+        # GraphedTrainStep nothing is captured: cameras may differ in size and field of view, binning stays exact.
+        self._eager_direct = bool(direct)
+        self._direct_ws = {}
         self.cams = cameras
         self.gts = gt_images                      # list of [1,H,W] edge maps on the device
         self.lambda_mse, self.lambda_dssim, self.lambda_mask = lambda_mse, lambda_dssim, lambda_mask
@@ -110,6 +116,8 @@ class TrainStep:
         vi = self._next_view() if view_index is None else view_index
         cam, gt = self.cams[vi], self.gts[vi]
         use_mask = it >= self.densify_until_iter
+        if self._eager_direct and self.fused:
+            return self._step_direct(cam, gt, use_mask)
         pkg = render(cam, g, self.pipe, self.bg, use_mask=use_mask, mask_thr=self.mask_threshold,
                      compute_visibility=not self.fused, clamp=not self.fused, compute_rend_dir=not self.fused,
                      grad_sinks=self.fused)   # (fused: the backward kernels add into the flat gradient buffer themselves)
@@ -134,6 +142,106 @@ class TrainStep:
             self.flat.zero_()                      # grads are views of the flat buffer: keep them, zero in place
         g.prepare_scaling_rot()                    # train.py:242-243
         return loss.detach(), pkg
+
+
+    def _step_direct(self, cam, gt, use_mask):
+        """TrainStep.step() from the render on, without autograd (TrainStep(direct=True)): train.py:95-107, :110-146, :235,
+        :242-243 as eight library calls.  The forward is the checked one (exact binning: a bucket overflow re-renders with the
+        raised capacity before anything reached the gradient buffer)."""
+        import ctypes as C
+        import math
+        from . import _lib as L
+        from .ops import view_render as VR
+        from .ops.curve_sampling import _bezier_mask, sample_coefficients
+        from .ops.losses import edge_pixel_count
+        g = self.g
+        lib = L.load()
+        if not L.use_shim():
+            raise L.CurveGSError("TrainStep(direct=True) needs the compiled host shim (curve_gaussian_amd/_cgs_torch.so)")
+        from .gaussian_renderer import _fused_route_ok
+        if not _fused_route_ok(g, self.pipe, 1.0, None):
+            raise ValueError("TrainStep(direct=True): the derived splat tensors of the model are stale (prepare_scaling_rot)")
+        dev = g._curve_points.device
+        m = g.n_gaussians
+        cp, wl, ol = g._curve_points.detach(), g._width.detach(), g._opacity.detach()
+        mask = g._mask.detach() if use_mask else None
+        B = cp.shape[0]
+        P = B * m
+        H, W = int(cam.image_height), int(cam.image_width)
+        tanx, tany = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+        isb, coef = _bezier_mask(g.is_bezier, dev), sample_coefficients(m, dev)
+        eps = getattr(g, "_derived_eps", 1e-8)
+        p, cf = L.ptr, C.c_float
+        gt1 = gt[:1].detach().float().contiguous()
+        n_pos = edge_pixel_count(gt1)
+        with L.device_guard(dev):
+            st = L.raw_stream(dev)
+            key = (str(dev), H, W, st)
+            ws = self._direct_ws.get(key)
+            if ws is None:
+                if len(self._direct_ws) >= 8:
+                    self._direct_ws.pop(next(iter(self._direct_ws)))
+                ws = self._direct_ws[key] = dict(
+                    photo=torch.zeros(int(lib.cgs_photometric_workspace_bytes(H, W)), dtype=torch.uint8, device=dev),
+                    reg=torch.zeros(int(lib.cgs_curve_regularizers_workspace_bytes()), dtype=torch.uint8, device=dev),
+                    gate={v: torch.full((1,), v, dtype=torch.float32, device=dev) for v in (0.0, 1.0)})
+            a, bb = self.lambda_mse * (1.0 - self.lambda_dssim), self.lambda_mse * self.lambda_dssim
+            while True:
+                cap = VR._capacity(lib, dev, P, W, H)
+                color, invd, amap, radii, _dir, _raw, saved, handle = L.shim().view_forward(
+                    cp, wl, ol, mask, isb, coef, m, self.mask_threshold, self.bg, cam.world_view_transform, cam.full_proj_transform,
+                    cam.camera_center, tanx, tany, H, W, cap, False, False, False, eps)
+                pend = VR.Pending(handle, (dev.index, P, W, H), cap, saved[6])
+                # value and d loss / d image behind the compositor (render()'s clamp inside the loss kernels), then the wait for
+                # the forward's 16-byte status readback -- the compositor and the loss are already queued behind it
+                g_img = torch.empty_like(color)
+                loss = torch.empty((), dtype=torch.float32, device=dev)
+                L.check(lib.cgs_photometric_loss(H, W, p(color), p(gt1), cf(0.1), p(n_pos), cf(a), cf(bb), 1, p(ws["photo"]), p(g_img),
+                                                 p(loss), st), "cgs_photometric_loss")
+                ok, _nvis = VR.finish(pend)
+                if ok:
+                    break
+            grads = self.flat
+            sinks = [grads.view("curve_points"), grads.view("width"), grads.view("opacity")] + ([grads.view("mask")] if use_mask else [])
+            extra = None
+            if self.regularisers:   # (train.py:113-131) forward quantities only: queued before the backward, which takes dL/drotation
+                f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+                r_rot, r_op, r_w, reg_loss = f32(P, 4), f32(B, 1), f32(B, 1), f32(())
+                gate = ws["gate"][1.0 if self.reset_timestep > 0 else 0.0]
+                L.check(lib.cgs_curve_regularizers(B, m, p(g._rotation.detach()), p(ol), p(wl), p(radii), cf(self.opacity_loss_weight),
+                                                   p(gate), cf(self.lambda_curve_smo), cf(self.lambda_width), cf(0.005), p(ws["reg"]),
+                                                   p(reg_loss), p(r_rot), p(r_op), p(r_w), st), "cgs_curve_regularizers")
+                extra = r_rot
+                loss = loss + reg_loss
+            _n, _n, _n, _n, g_m2d = L.shim().view_backward(*saved[:4], isb, coef, *saved[4:], m, self.mask_threshold, tanx, tany, H, W,
+                                                           eps, g_img, None, sinks, extra)
+            if self.regularisers:
+                sinks[2].add_(r_op)
+                sinks[1].add_(r_w)
+                if self._conn_active(self.iteration):
+                    conn_ws = torch.zeros(int(lib.cgs_endpoint_connection_workspace_bytes(B)), dtype=torch.uint8, device=dev)
+                    conn_loss = torch.zeros((), dtype=torch.float32, device=dev)
+                    L.check(lib.cgs_endpoint_connection_loss(B, p(cp), cf(0.05), cf(self.lambda_points_conn), p(conn_ws), p(conn_loss),
+                                                             p(sinks[0]), 1, st), "cgs_endpoint_connection_loss")
+                    loss = loss + conn_loss
+            if use_mask:            # train.py:110-111: lambda_mask * mean(sigmoid(mask)), gradient added by hand
+                sg = torch.sigmoid(mask)
+                loss = loss + self.lambda_mask * sg.mean()
+                sinks[3].add_(sg * (1 - sg), alpha=self.lambda_mask / mask.numel())
+        self.flat.all_reduce()
+        g.optimizer.step(zero_grad=True)
+        g.prepare_scaling_rot()
+        pkg = {"render": color, "viewspace_points": _GradHolder(g_m2d), "visibility_filter": None, "radii": radii, "depth": invd,
+               "rend_dir": None, "rend_alpha": amap[3:4]}
+        return loss, pkg
+
+
+class _GradHolder:
+    """Stands where render()'s `viewspace_points` leaf stands in the result dict: `.grad` is dL/dmeans2D [P,3] of the view
+    (what add_densification_stats reads, scene/gaussian_curve_model.py:604-607 of the reference)."""
+
+    def __init__(self, grad):
+        self.grad = grad
 
 
 class GraphedTrainStep(TrainStep):

@@ -1127,6 +1127,37 @@ def test_graphed_train_step_crosses_the_connection_phase():
                                    rtol=1e-3, atol=1e-5, err_msg=n)
 
 
+@pytest.mark.parametrize("phase", ["plain", "regularisers", "late"])
+def test_direct_eager_train_step_follows_the_autograd_one(phase):
+    """TrainStep(direct=True): the eager iteration as plain library calls (no autograd, gradients added into the flat buffer
+    by the kernels) -- same trajectory as the autograd form through the gate opening, the mask phase and the connection
+    phase of train.py; the result dict still feeds the densification statistics."""
+    from curve_gaussian_amd.train_step import TrainStep
+    torch.manual_seed(0); ga, cams, gts = _train_fixture()
+    torch.manual_seed(0); gb, _, _ = _train_fixture()
+    kw = dict(seed=8)
+    if phase != "plain":
+        kw.update(regularisers=True)
+    if phase == "late":
+        kw.update(densify_until_iter=4, conn_from_iter=5, lambda_points_conn=0.1)
+    ea = TrainStep(ga, cams, gts, **kw)
+    eb = TrainStep(gb, cams, gts, direct=True, **kw)
+    ea.reset_timestep = eb.reset_timestep = -3
+    for _ in range(9):
+        la, pa = ea.step()
+        lb, pb = eb.step()
+    np.testing.assert_allclose(float(lb), float(la), rtol=1e-4)
+    for n in ("_curve_points", "_width", "_opacity", "_mask"):
+        np.testing.assert_allclose(getattr(gb, n).detach().cpu().numpy(), getattr(ga, n).detach().cpu().numpy(),
+                                   rtol=1e-3, atol=1e-5, err_msg=n)
+    np.testing.assert_array_equal(pb["radii"].cpu().numpy(), pa["radii"].cpu().numpy())
+    ga_m2d, gb_m2d = pa["viewspace_points"].grad.cpu().numpy(), pb["viewspace_points"].grad.cpu().numpy()
+    np.testing.assert_allclose(gb_m2d, ga_m2d, rtol=2e-2, atol=2e-4 * np.abs(ga_m2d).max())
+    vis = pb["radii"] > 0
+    gb.add_densification_stats(pb["viewspace_points"], vis)          # what train.py:209 does with the dict
+    assert float(gb.xyz_gradient_accum.sum()) > 0
+
+
 def test_shared_sampling_over_a_view_batch_gives_the_summed_gradient():
     """cgs_view_forward_shared / CGS_VIEW_SHARED + cgs_view_shared_begin / _end: the grid-wide norm pass and the last pass of the sampling
     backward once per view BATCH (same parameters for every view of it) instead of once per view.  The batch gradient must be
