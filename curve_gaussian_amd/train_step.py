@@ -160,7 +160,10 @@ class TrainStep:
             raise L.CurveGSError("TrainStep(direct=True) needs the compiled host shim (curve_gaussian_amd/_cgs_torch.so)")
         from .gaussian_renderer import _fused_route_ok
         if not _fused_route_ok(g, self.pipe, 1.0, None):
-            raise ValueError("TrainStep(direct=True): the derived splat tensors of the model are stale (prepare_scaling_rot)")
+            # a parameter tensor was replaced since the last prepare_scaling_rot (reset_opacity, a topology edit made outside
+            # the loop): train.py refreshes the derived tensors at the end of every iteration (:242-243), so they are
+            # current whenever its next render starts -- same state here
+            g.prepare_scaling_rot()
         dev = g._curve_points.device
         m = g.n_gaussians
         cp, wl, ol = g._curve_points.detach(), g._width.detach(), g._opacity.detach()
