@@ -734,10 +734,7 @@ int cgs_sample_curves_forward(int B, int m, const float* curve_points, const flo
         set_error("cgs_sample_curves_forward: invalid argument (NULL or misaligned pointer, B=%d m=%d)", B, m);
         return CGS_ERR_INVALID_ARGUMENT;
     }
-    if (zero_async(norms, (size_t)sample_norm_words() * sizeof(double), s) != hipSuccess) {
-        set_error("zero_async(norms) failed");
-        return CGS_ERR_HIP;
-    }
+    // (no zero fill of norms: k_sample_f12 writes the forward sums and clears the backward's, csrc/curve_math.h)
     launch_sample_forward(s, B, m, curve_points, width, is_bezier, coef, eps, norms, xyz, rotation, scaling);
     if (!check_launch("sample_curves_forward", false, s)) return CGS_ERR_HIP;
     return CGS_OK;
@@ -842,14 +839,8 @@ static int64_t view_forward_impl(int mode, int B, int m, const float* curve_poin
     const size_t clear_bytes = (size_t)((char*)(img.total + TOTAL_WORDS) - (char*)img.tile_count);
     const bool shared = (mode & VIEW_MODE_SHARED) != 0;
     mode &= VIEW_MODE_MASK;
-    // all five grid-wide sums (forward norms AND the backward's two) start from zero here: one launch per view
-    if (!shared) {
-        if (zero_async(norms, (size_t)sample_norm_words() * sizeof(double), s) != hipSuccess) {
-            set_error("zero_async(norms) failed");
-            return CGS_ERR_HIP;
-        }
-        launch_sample_norms(s, B, m, curve_points, is_bezier, coef, norms);
-    }
+    // the norm pass writes the three forward sums and clears the backward's two: no zero-fill launch
+    if (!shared) launch_sample_norms(s, B, m, curve_points, is_bezier, coef, norms);
     launch_view_forward(s, B, m, curve_points, width, is_bezier, coef, eps, norms, opacity_logit, mask_logit, mask_thr,
                         colors_precomp, cam_pos, viewmatrix, projmatrix, tan_fovx, tan_fovy, focal_x, focal_y, width_px,
                         height_px, gx, gy, xyz, rotation, scaling, radii, geom.rec, geom.grad_acc, img.tile_count,
@@ -1087,8 +1078,7 @@ int cgs_view_shared_begin(int B, int m, const float* curve_points, const uint8_t
         set_error("cgs_view_shared_begin: invalid argument");
         return CGS_ERR_INVALID_ARGUMENT;
     }
-    if (zero_async(norms, (size_t)sample_norm_words() * sizeof(double), s) != hipSuccess ||
-        zero_async(scratch, cgs_view_backward_scratch_floats(B, m) * sizeof(float), s) != hipSuccess) {
+    if (zero_async(scratch, cgs_view_backward_scratch_floats(B, m) * sizeof(float), s) != hipSuccess) {
         set_error("zero_async failed");
         return CGS_ERR_HIP;
     }
@@ -1127,6 +1117,7 @@ int cgs_sample_curves_backward(int B, int m, const float* curve_points, const fl
         set_error("cgs_sample_curves_backward: invalid argument");
         return CGS_ERR_INVALID_ARGUMENT;
     }
+    // (a second backward over the same forward -- retain_graph -- must not see the first one's two sums)
     if (zero_async(norms + sample_norm_fwd_words(), (size_t)(sample_norm_words() - sample_norm_fwd_words()) * sizeof(double), s) != hipSuccess) {
         set_error("zero_async(norms) failed");
         return CGS_ERR_HIP;

@@ -6,9 +6,14 @@
 
 namespace cgs {
 
-// Grid-wide sums: every workgroup adds its partial to one of NORM_SLOTS f64 slots per quantity (same-address f64
-// atomics serialise at ~20 ns each: 782 blocks on one address cost more than the kernels themselves, 49 per slot do
-// not), and every consumer sums the slots while staging its constants.
+// Grid-wide sums live in NORM_SLOTS f64 slots per quantity; every consumer sums the slots while staging its constants.
+// The forward's three sums are WRITTEN, one slot per workgroup of k_sample_f12 (launched on exactly NORM_SLOTS
+// workgroups: no atomics, no zero-fill launch, the same bits on every run), which also clears the slots of the
+// backward's two; those are accumulated with one fire-and-forget f64 atomic per workgroup (same-address f64 atomics
+// serialise at ~20 ns each: 782 blocks on one address cost more than the kernels themselves, 49 per slot do not).
+// (Round 5 tried to let the last workgroup of k_sample_bwd<3> hand the backward's slots back cleared, by an arrival
+// ticket: a RETURNING device-scope atomic per workgroup -- one address or 64 -- took that kernel from 8.3 to 12.7 -
+// 17.1 us at 794 workgroups; on this multi-XCD part the answer comes from beyond the XCD's L2.  Not kept.)
 constexpr int NORM_SLOTS = 64;
 // norms[q * NORM_SLOTS + slot].  Forward (k_sample_f12, ONE pass): q0 = S1 = sum |c1v|^2, q1 = S2 = sum |cross(tan,c1v)|^2,
 // q2 = BS = sum dot(cross(cross(tan,c1v), tan), c1v), from which N1 = sqrt(S1), N2 = sqrt(S2) / N1 (c2v = cross(tan,
@@ -17,6 +22,7 @@ constexpr int NORM_SLOTS = 64;
 // linear in D2), so neither direction needs a second grid-wide pass.
 constexpr int NQ_FWD = 3, NQ_ALL = 5;
 constexpr int NORM_WORDS = NQ_ALL * NORM_SLOTS;
+static_assert(NORM_WORDS <= 384, "norms buffer layout");
 
 struct SampleCoef {  // per-sample coefficients, computed on the host with the reference's float32 torch expressions
     float c[4];      // Bezier point weights at t_i

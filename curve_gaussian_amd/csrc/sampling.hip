@@ -19,27 +19,46 @@
 namespace cgs {
 
 // ------------------------------------------------------------------------------------------------ forward
-__global__ void __launch_bounds__(256) k_sample_f12(int B, int m, const float* __restrict__ cp,
-                                                    const uint8_t* __restrict__ is_bezier,
-                                                    const SampleCoef* __restrict__ coef, double* __restrict__ norms) {
+constexpr int F12_BLOCK = 1024;
+__global__ void __launch_bounds__(F12_BLOCK) k_sample_f12(int B, int m, const float* __restrict__ cp,
+                                                         const uint8_t* __restrict__ is_bezier,
+                                                         const SampleCoef* __restrict__ coef, double* __restrict__ norms) {
+    // launched on exactly NORM_SLOTS workgroups: workgroup k owns slot k of the three forward sums (plain stores) and
+    // clears slot k of the backward's two
     __shared__ SampleCoef s_coef[MAX_M];
+    __shared__ double s_part[3][F12_BLOCK / 64];
     const float* src = reinterpret_cast<const float*>(coef);
     float* dst = reinterpret_cast<float*>(s_coef);
     for (int t = threadIdx.x; t < m * 16; t += blockDim.x) dst[t] = src[t];
     __syncthreads();
-    float a1 = 0, a2 = 0, a3 = 0;   // the grid covers every splat once: at most one addend per thread
+    double a1 = 0, a2 = 0, a3 = 0;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < B * m; p += gridDim.x * blockDim.x) {
         const int b = p / m, i = p - b * m;
         const CurveCP c = load_curve(cp, is_bezier, b);
         const V3 t = curve_tangent(c, s_coef[i]);
         const V3 c1 = {t.y, -t.x, 0.f};                 // cross(tan, (0,0,1))
         const V3 x = cross(t, c1);                      // N1 * c2v
-        a1 += t.y * t.y + t.x * t.x;
-        a2 += x.x * x.x + x.y * x.y + x.z * x.z;
-        a3 += dot(cross(x, t), c1);
+        a1 += (double)(t.y * t.y + t.x * t.x);
+        a2 += (double)(x.x * x.x + x.y * x.y + x.z * x.z);
+        a3 += (double)dot(cross(x, t), c1);
     }
-    const double acc3[3] = {(double)a1, (double)a2, (double)a3};
-    block_accumulate<3>(acc3, norms, 0);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        a1 += __shfl_xor(a1, off, 64);
+        a2 += __shfl_xor(a2, off, 64);
+        a3 += __shfl_xor(a3, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_part[0][threadIdx.x >> 6] = a1; s_part[1][threadIdx.x >> 6] = a2; s_part[2][threadIdx.x >> 6] = a3;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double t = 0;
+        for (int wv = 0; wv < (int)(blockDim.x >> 6); wv++) t += s_part[threadIdx.x][wv];
+        norms[threadIdx.x * NORM_SLOTS + blockIdx.x] = t;
+    } else if (threadIdx.x < NQ_ALL) {
+        norms[threadIdx.x * NORM_SLOTS + blockIdx.x] = 0.0;
+    }
 }
 
 __global__ void __launch_bounds__(256) k_sample_f3(int B, int m, const float* __restrict__ cp,
@@ -292,9 +311,8 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_attrs_bwd(
 void launch_sample_forward(hipStream_t s, int B, int m, const float* cp, const float* width, const uint8_t* is_bezier,
                            const void* coef, float eps, double* norms, float* xyz, float* rot, float* scaling) {
     const dim3 grid((B * m + 255) / 256), block(256);
-    const dim3 rgrid(std::max((B * m + 255) / 256, 1));
     const SampleCoef* k = reinterpret_cast<const SampleCoef*>(coef);
-    { ProfScope p("sample_f12", s); hipLaunchKernelGGL(k_sample_f12, rgrid, block, 0, s, B, m, cp, is_bezier, k, norms); }
+    { ProfScope p("sample_f12", s); hipLaunchKernelGGL(k_sample_f12, dim3(NORM_SLOTS), dim3(F12_BLOCK), 0, s, B, m, cp, is_bezier, k, norms); }
     { ProfScope p("sample_f3", s); hipLaunchKernelGGL(k_sample_f3, grid, block, 0, s, B, m, cp, width, is_bezier, k, eps, norms, xyz, rot, scaling); }
 }
 void launch_sample_backward(hipStream_t s, int B, int m, const float* cp, const float* width, const uint8_t* is_bezier,
@@ -328,7 +346,7 @@ void launch_attrs_backward(hipStream_t s, int B, int m, const float* rot_raw, co
 
 void launch_sample_norms(hipStream_t s, int B, int m, const float* cp, const uint8_t* is_bezier, const void* coef, double* norms) {
     ProfScope p("sample_f12", s);
-    hipLaunchKernelGGL(k_sample_f12, dim3(std::max((B * m + 255) / 256, 1)), dim3(256), 0, s, B, m, cp, is_bezier,
+    hipLaunchKernelGGL(k_sample_f12, dim3(NORM_SLOTS), dim3(F12_BLOCK), 0, s, B, m, cp, is_bezier,
                        reinterpret_cast<const SampleCoef*>(coef), norms);
 }
 void launch_sample_backward_pass3(hipStream_t s, int B, int m, const float* cp, const float* width, const uint8_t* is_bezier,

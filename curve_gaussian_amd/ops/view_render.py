@@ -188,6 +188,11 @@ class _ViewRender(torch.autograd.Function):
         dev = cp.device
         P = B * m
         mkp = mk if ctx.has_mask else None
+        if getattr(ctx, "ran_backward", False):
+            # a second backward over this forward (retain_graph): the two grid-wide sums of the sampling backward were cleared
+            # by the forward's norm pass once (include/curvegs.h: one view backward per view forward) -- clear them again
+            norms[192:320].zero_()
+        ctx.ran_backward = True
         if L.use_shim():   # clamp gradient + cgs_view_backward in one call (csrc/torch_shim.cpp::view_backward)
             # (ctx.sinks: the kernels add the curve-level gradients to the caller's buffers; None comes back for those inputs)
             return tuple(L.shim().view_backward(cp, w, ol, mkp, ctx.isb, ctx.coef, geom, binb, img, radii, norms, bgc, view, proj,

@@ -264,7 +264,9 @@ int cgs_view_backward_render(int B, int m, const float* curve_points, const floa
  *     {c0..c3 at t_i, c0..c3 at t_i-0.5/m, 3(1-t)^2, 6(1-t)t, 3t^2, (1-t), t, (1-t'), t', pad}.
  *   norms [384] f64 scratch: [0..191] = 64 partial sums each of three global sums written by the forward and needed
  *     by the backward (the two Frobenius norms of the reference's global normalisations and one cross term);
- *     [192..319] are backward scratch; the rest is reserved.
+ *     [192..319] are backward scratch (cleared by the forward's norm pass; cgs_sample_curves_backward clears them itself
+ *     on entry, the per-view backward of cgs_view_backward does not: ONE view backward per view forward); the rest is
+ *     reserved.  The buffer needs no initialisation by the caller.
  *   outputs xyz [P,3], rotation [P,4] (w,x,y,z, un-normalised), scaling [P,3].
  * The backward accepts NULL for any upstream gradient (treated as zero).  m <= 32.
  * ------------------------------------------------------------------------------------------------ */

@@ -173,6 +173,22 @@ def test_grad_sinks_put_the_same_gradients_into_existing_grad_buffers(use_mask):
         assert gm._mask.grad is None or float(gm._mask.grad.abs().max()) == 0.0
 
 
+def test_fused_route_backward_twice_over_one_forward():
+    """retain_graph + two backwards through one fused render(): the second one gives the same gradients again (the grid-wide
+    sums of the sampling backward are cleared by the forward once and by the node before any further backward)."""
+    from curve_gaussian_amd.gaussian_renderer import PipelineParams, render
+    c, mask, cam = _small()
+    cam = cam.to(DEV)
+    gm = _model(c, mask)
+    dimg = torch.randn(1, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(5)).to(DEV)
+    pkg = render(cam, gm, PipelineParams(), torch.zeros(3, device=DEV))
+    first = torch.autograd.grad(pkg["render"], [gm._curve_points, gm._width, gm._opacity], dimg, retain_graph=True)
+    second = torch.autograd.grad(pkg["render"], [gm._curve_points, gm._width, gm._opacity], dimg, retain_graph=True)
+    for a, b, n in zip(first, second, ("curve_points", "width", "opacity")):
+        assert float(a.abs().max()) > 0
+        assert_close(n, b.cpu(), a.cpu(), rel=2e-4)
+
+
 def test_fused_route_resamples_with_the_eps_of_prepare_scaling_rot(monkeypatch):
     """prepare_scaling_rot(eps) stamps the eps it used; the fused route (which samples the curves itself) renders with it, so
     both routes draw the same splats for any eps."""
