@@ -19,7 +19,7 @@
 namespace cgs {
 
 // ------------------------------------------------------------------------------------------------ forward
-constexpr int F12_BLOCK = 1024;
+constexpr int F12_BLOCK = 1024;   // upper bound; the launch picks the workgroup size by splat count (f12_threads)
 __global__ void __launch_bounds__(F12_BLOCK) k_sample_f12(int B, int m, const float* __restrict__ cp,
                                                          const uint8_t* __restrict__ is_bezier,
                                                          const SampleCoef* __restrict__ coef, double* __restrict__ norms) {
@@ -308,11 +308,17 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_attrs_bwd(
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
+// Workgroup size of the norm pass (always NORM_SLOTS workgroups): 256 threads up to 128 k splats, 512 up to 600 k, 1024 beyond.
+// Big workgroups only fit a CU once several compositor waves of the neighbouring views have drained; with three views in
+// flight at cfg3, 1024 threads cost 0.6 % of the headline against 256 / 512 (same box, twice: 813 - 814 vs 818 - 821 Msplats/s),
+// while a million splats want the shorter per-thread loop.
+static int f12_threads(long long P) { return P <= 128 * 1024 ? 256 : (P <= 600 * 1024 ? 512 : 1024); }
+
 void launch_sample_forward(hipStream_t s, int B, int m, const float* cp, const float* width, const uint8_t* is_bezier,
                            const void* coef, float eps, double* norms, float* xyz, float* rot, float* scaling) {
     const dim3 grid((B * m + 255) / 256), block(256);
     const SampleCoef* k = reinterpret_cast<const SampleCoef*>(coef);
-    { ProfScope p("sample_f12", s); hipLaunchKernelGGL(k_sample_f12, dim3(NORM_SLOTS), dim3(F12_BLOCK), 0, s, B, m, cp, is_bezier, k, norms); }
+    { ProfScope p("sample_f12", s); hipLaunchKernelGGL(k_sample_f12, dim3(NORM_SLOTS), dim3(f12_threads((long long)B * m)), 0, s, B, m, cp, is_bezier, k, norms); }
     { ProfScope p("sample_f3", s); hipLaunchKernelGGL(k_sample_f3, grid, block, 0, s, B, m, cp, width, is_bezier, k, eps, norms, xyz, rot, scaling); }
 }
 void launch_sample_backward(hipStream_t s, int B, int m, const float* cp, const float* width, const uint8_t* is_bezier,
@@ -346,7 +352,7 @@ void launch_attrs_backward(hipStream_t s, int B, int m, const float* rot_raw, co
 
 void launch_sample_norms(hipStream_t s, int B, int m, const float* cp, const uint8_t* is_bezier, const void* coef, double* norms) {
     ProfScope p("sample_f12", s);
-    hipLaunchKernelGGL(k_sample_f12, dim3(NORM_SLOTS), dim3(F12_BLOCK), 0, s, B, m, cp, is_bezier,
+    hipLaunchKernelGGL(k_sample_f12, dim3(NORM_SLOTS), dim3(f12_threads((long long)B * m)), 0, s, B, m, cp, is_bezier,
                        reinterpret_cast<const SampleCoef*>(coef), norms);
 }
 void launch_sample_backward_pass3(hipStream_t s, int B, int m, const float* cp, const float* width, const uint8_t* is_bezier,
