@@ -406,6 +406,7 @@ def main():
     stream_flats, stream_leaves = flat_sets[0], leaf_sets[0]
     reduced = [None] * n_sets      # event: this set's gradients have been reduced (it may be zeroed and refilled)
     step_no = [0]
+    view_seq = [0]     # views dispatched so far (stream choice)
 
     # ---- hipGraph mode: one captured per-view pipeline per stream (sync-free forward with fixed-capacity buckets),
     # replayed for any view after a 140-byte camera copy; the host cost per view drops from ~0.4 ms to ~0.02 ms
@@ -500,7 +501,12 @@ def main():
                         st.wait_stream(cur)
                     with torch.cuda.stream(st):
                         flats[i].zero_()
-            for j, cam in enumerate(view_list[g0:g0 + G]):
+            for cam in view_list[g0:g0 + G]:
+                # the view's stream: round-robin over ALL views, not restarted per step -- with 8 views per step on 3 streams
+                # a per-step restart hands streams 0 / 1 three views and stream 2 two, every step (the streams run on across
+                # step boundaries, so one of them idles a third of the time)
+                j = view_seq[0] % vstreams.n
+                view_seq[0] += 1
                 if use_graphs[0] and not collect:
                     replay_view(j, cam, q)
                 elif collect and prof_direct[0] is not None:   # per-kernel timing of the headline (fused direct) body
