@@ -51,6 +51,7 @@ SIGNATURES = {
     "cgs_status_words": (_i, []),
     "cgs_bucket_capacity_limit": (C.c_uint32, []),
     "cgs_adam_step_flat_dev": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _i, _vp, _vp]),
+    "cgs_adam_step_flat_dev_report": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _i, _vp, _vp, _vp, _i, _vp]),
     "cgs_adam_state_bytes": (C.c_size_t, []),
     "cgs_set_tile_culling": (_i, [_i]),
     "cgs_set_fused_tile_sort": (_i, [_i]),

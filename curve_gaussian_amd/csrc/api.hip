@@ -1334,6 +1334,21 @@ int cgs_adam_step_flat_dev(int64_t n, float* params, float* grads, float* exp_av
     if (!check_launch("adam_step_flat_dev", false, (hipStream_t)stream_)) return CGS_ERR_HIP;
     return CGS_OK;
 }
+int cgs_adam_step_flat_dev_report(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                                  const void* device_state, int n_segments, float beta1, float beta2, float eps, int zero_grads,
+                                  const uint32_t* skip_flag, uint32_t* report_seq, uint32_t* report_ring, int report_len,
+                                  void* stream_) {
+    if (n == 0) return CGS_OK;
+    if (n < 0 || !params || !grads || !exp_avg || !exp_avg_sq || !device_state || n_segments <= 0 ||
+        n_segments > adam_max_segments() || !report_seq || !report_ring || report_len <= 0) {
+        set_error("cgs_adam_step_flat_dev_report: invalid argument");
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    launch_adam_flat_dev((hipStream_t)stream_, (long long)n, params, grads, exp_avg, exp_avg_sq, device_state, n_segments,
+                         beta1, beta2, eps, zero_grads, skip_flag, report_seq, report_ring, report_len);
+    if (!check_launch("adam_step_flat_dev_report", false, (hipStream_t)stream_)) return CGS_ERR_HIP;
+    return CGS_OK;
+}
 size_t cgs_endpoint_connection_workspace_bytes(int B) { return endpoint_connection_workspace_bytes(B > 0 ? B : 1); }
 int cgs_endpoint_connection_loss(int B, const float* curve_points, float distance_threshold, float weight, void* workspace,
                                  float* loss, float* dL_dcurve_points, int accumulate, void* stream_) {

@@ -139,7 +139,8 @@ void launch_curve_regularizers(hipStream_t s, int B, int m, const float* rot_raw
 int adam_max_segments();
 size_t adam_state_bytes();
 void launch_adam_flat_dev(hipStream_t s, long long n, float* p, float* g, float* m, float* v, const void* dev_state,
-                          int nseg, float b1, float b2, float eps, int zero_grad, const unsigned int* skip_flag);
+                          int nseg, float b1, float b2, float eps, int zero_grad, const unsigned int* skip_flag,
+                          unsigned int* report_seq = nullptr, unsigned int* report_ring = nullptr, int report_len = 0);
 void launch_adam_flat(hipStream_t s, long long n, float* p, float* g, float* m, float* v, const void* host_segs, int nseg,
                       float b1, float b2, float eps, float bc1, float sqrt_bc2, int zero_grad);
 // knn.hip

@@ -460,8 +460,18 @@ struct AdamDevState { AdamSeg s[ADAM_MAX_SEGS]; float bc1; float sqrt_bc2; float
 __global__ void __launch_bounds__(256) k_adam_flat_dev(long long n, float* __restrict__ p, float* __restrict__ g,
                                                        float* __restrict__ m, float* __restrict__ v,
                                                        const AdamDevState* __restrict__ st, int nseg, float b1, float b2,
-                                                       float eps, int zero_grad, const unsigned int* __restrict__ skip_flag) {
+                                                       float eps, int zero_grad, const unsigned int* __restrict__ skip_flag,
+                                                       unsigned int* __restrict__ report_seq,
+                                                       unsigned int* __restrict__ report_ring, int report_len) {
     const bool skip = skip_flag && *skip_flag != 0u;
+    // Optional report for replayed iterations: the n-th execution (counted in device memory) leaves "was skipped" in entry
+    // n % report_len of a ring the host can read (pinned host memory mapped into the device: no device-to-host copy in the
+    // stream between one replay and the next).
+    if (report_ring && blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned int c = *report_seq;
+        *report_seq = c + 1u;
+        report_ring[c % (unsigned int)report_len] = skip ? 1u : 0u;
+    }
     const float bc1 = st->bc1, sqrt_bc2 = st->sqrt_bc2;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float gi = g[i];
@@ -479,11 +489,13 @@ __global__ void __launch_bounds__(256) k_adam_flat_dev(long long n, float* __res
 }
 size_t adam_state_bytes() { return sizeof(AdamDevState); }
 void launch_adam_flat_dev(hipStream_t s, long long n, float* p, float* g, float* m, float* v, const void* dev_state,
-                          int nseg, float b1, float b2, float eps, int zero_grad, const unsigned int* skip_flag) {
+                          int nseg, float b1, float b2, float eps, int zero_grad, const unsigned int* skip_flag,
+                          unsigned int* report_seq, unsigned int* report_ring, int report_len) {
     ProfScope pr("adam_flat", s);
     const int blocks = (int)std::min<long long>((n + 255) / 256, 2048);
     hipLaunchKernelGGL(k_adam_flat_dev, dim3(blocks), dim3(256), 0, s, n, p, g, m, v,
-                       reinterpret_cast<const AdamDevState*>(dev_state), nseg, b1, b2, eps, zero_grad, skip_flag);
+                       reinterpret_cast<const AdamDevState*>(dev_state), nseg, b1, b2, eps, zero_grad, skip_flag, report_seq,
+                       report_ring, report_len);
 }
 int adam_max_segments() { return ADAM_MAX_SEGS; }
 void launch_adam_flat(hipStream_t s, long long n, float* p, float* g, float* m, float* v, const void* host_segs, int nseg,

@@ -130,11 +130,22 @@ class FlatAdam:
         slot[:len(blob)].copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
         dev.copy_(slot, non_blocking=True)
 
-    def step_dev(self, zero_grad=True, skip_flag=None):
+    def step_dev(self, zero_grad=True, skip_flag=None, report=None):
         """Adam step whose scalars come from ``device_state()`` (call ``stage_step()`` first, outside any graph
-        capture); skip_flag: optional device int32/uint32 scalar -- non-zero leaves parameters and moments untouched."""
+        capture); skip_flag: optional device int32/uint32 scalar -- non-zero leaves parameters and moments untouched.
+        report = (seq, ring): device int32 scalar counting the executions and an int32 ring (device or PINNED HOST memory)
+        whose entry ``n % len(ring)`` receives 1 if execution n was skipped, else 0 (cgs_adam_step_flat_dev_report)."""
         dev, _ = self.device_state()
         lib = L.load()
+        if report is not None:
+            seq, ring = report
+            rc = lib.cgs_adam_step_flat_dev_report(
+                self.flat.numel(), L.ptr(self.flat), L.ptr(self.grads.flat), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), L.ptr(dev),
+                len(self.param_groups), C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
+                1 if zero_grad else 0, L.ptr(skip_flag) if skip_flag is not None else None, L.ptr(seq), L.ptr(ring),
+                int(ring.numel()), L.raw_stream(self.device))
+            L.check(rc, "cgs_adam_step_flat_dev_report")
+            return
         rc = lib.cgs_adam_step_flat_dev(self.flat.numel(), L.ptr(self.flat), L.ptr(self.grads.flat), L.ptr(self.exp_avg),
                                         L.ptr(self.exp_avg_sq), L.ptr(dev), len(self.param_groups),
                                         C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),

@@ -333,6 +333,11 @@ class GraphedTrainStep(TrainStep):
         self._use_mask = False
         self._use_conn = False      # graph constant like _use_mask: the switch at conn_from_iter re-captures
         self._flag_host = torch.zeros(64, dtype=torch.int32).pin_memory()
+        # single-GPU replays: the captured Adam kernel reports "this iteration was skipped" straight into that pinned ring
+        # (entry = its own execution count, kept in device memory, modulo 64) -- no device-to-host copy queued between one
+        # replay and the next.  _report_next mirrors the device counter on the host.
+        self._report_seq = torch.zeros(1, dtype=torch.int32, device=self.g.device)
+        self._report_next = 0
         self._inflight = []   # (event, slot, view index, iteration)
         self.recaptures = 0
         self._t0 = self.g.optimizer.step_count - self.iteration   # Adam step number = _t0 + iteration
@@ -356,7 +361,7 @@ class GraphedTrainStep(TrainStep):
             loss = loss + self._regulariser_terms(pkg["radii"], self._opa_gate, with_conn=self._use_conn)
         loss.backward(gradient=unit_grad(loss.device))
         status = sink[0]
-        g.optimizer.step_dev(zero_grad=True, skip_flag=status[2:3])
+        g.optimizer.step_dev(zero_grad=True, skip_flag=status[2:3], report=self._report())
         return loss.detach(), status
 
     # -- the same sequence without autograd: every kernel of the iteration called through the C ABI on preallocated
@@ -486,7 +491,7 @@ class GraphedTrainStep(TrainStep):
             dist.all_reduce(g.optimizer.grads.flat)
             dist.all_reduce(status[2:3], op=dist.ReduceOp.MAX)   # any rank overflowed -> every rank skips
         if not self._collective or self._capture_coll:   # view-parallel: the all-reduce sits between backward and optimizer
-            g.optimizer.step_dev(zero_grad=True, skip_flag=status[2:3])
+            g.optimizer.step_dev(zero_grad=True, skip_flag=status[2:3], report=self._report())
         self.last = dict(radii=b["radii"], dL_dmeans2D=b["g_m2d"], render=b["color"], depth=b["invd"], all_map=b["omap"])
         return loss, status
 
@@ -541,10 +546,17 @@ class GraphedTrainStep(TrainStep):
             dist.all_reduce(g.optimizer.grads.flat)
             dist.all_reduce(status[2:3], op=dist.ReduceOp.MAX)   # any rank overflowed -> every rank skips
         if not self._collective or self._capture_coll:
-            g.optimizer.step_dev(zero_grad=True, skip_flag=status[2:3])
+            g.optimizer.step_dev(zero_grad=True, skip_flag=status[2:3], report=self._report())
         self.last = dict(radii=b["radii"], dL_dmeans2D=b["g_m2d"], render=b["color"],
                          depth=b["invd"] if self.aux_outputs else None, all_map=b["omap"] if self.aux_outputs else None)
         return loss, status
+
+    def _report(self):
+        """(execution counter, pinned flag ring) for the captured Adam kernel, or None where the optimizer runs outside the
+        replayed sequence (view-parallel mode without captured collectives: the flag is all-reduced first)."""
+        if self._collective and not self._capture_coll:
+            return None
+        return self._report_seq, self._flag_host
 
     def _probe_capacity(self):
         """Longest tile list over a few eager (exact-path) renders -> bucket capacity."""
@@ -623,6 +635,7 @@ class GraphedTrainStep(TrainStep):
         opt.step_count = snap[3]
         opt.grads.zero_()
         self.g.prepare_scaling_rot()
+        self._report_seq.fill_(self._report_next)   # (the warm-up executions of the body counted too)
         self._graph = graph
         self.recaptures += 1
 
@@ -681,8 +694,12 @@ class GraphedTrainStep(TrainStep):
             dist.all_reduce(self._status[2:3], op=dist.ReduceOp.MAX)   # any rank overflowed -> every rank skips
             g.optimizer.step_dev(zero_grad=True, skip_flag=self._status[2:3])
         self._derived_stale = True   # g._xyz/_rotation/_scaling now hold the values of BEFORE this step's update
-        slot = self.iteration % 64
-        self._flag_host[slot:slot + 1].copy_(self._status[2:3], non_blocking=True)
+        if self._report() is not None:
+            slot = self._report_next % 64             # written by the replay's own Adam kernel
+            self._report_next += 1
+        else:
+            slot = self.iteration % 64
+            self._flag_host[slot:slot + 1].copy_(self._status[2:3], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self._inflight.append((ev, slot, vi, self.iteration))

@@ -381,6 +381,14 @@ int cgs_adam_step_flat(int64_t n, float* params, float* grads, float* exp_avg, f
 int cgs_adam_step_flat_dev(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                            const void* device_state, int n_segments, float beta1, float beta2, float eps, int zero_grads,
                            const uint32_t* skip_flag, void* stream);
+/* The same step with a report for replayed iterations: report_seq (device u32, set by the caller once) counts the executions;
+ * execution number n writes 1 (skipped) or 0 into report_ring[n % report_len].  report_ring may be pinned host memory mapped into
+ * the device (hipHostMalloc / torch pin_memory): the host then learns about skipped iterations without a device-to-host copy
+ * queued between one replay and the next -- it reads entry n once an event recorded behind replay n has completed. */
+int cgs_adam_step_flat_dev_report(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                                  const void* device_state, int n_segments, float beta1, float beta2, float eps, int zero_grads,
+                                  const uint32_t* skip_flag, uint32_t* report_seq, uint32_t* report_ring, int report_len,
+                                  void* stream);
 size_t cgs_adam_state_bytes(void);
 
 /* ------------------------------------------------------------------------------------------------
