@@ -798,9 +798,11 @@ def test_unit_colour_instances_agree_with_the_general_ones_on_random_scenes():
     import random
     cams_at = [((0.5, -1.6, 0.7), (0.5, 0.5, 0.5), (0, 0, 1)), ((2.0, 1.4, 1.1), (0.4, 0.5, 0.6), (0, 0, 1)),
                ((0.5, 0.5, 0.5), (0.9, 0.2, 0.5), (0, 0, 1)), ((0.5, -0.6, 0.5), (0.5, 0.5, 0.5), (0, 0, 1))]
-    rng = random.Random(3)
+    # (CGS_FUZZ_SEED / CGS_FUZZ_CASES: longer one-off campaigns; the defaults are the suite's fixed 16 scenes)
+    rng = random.Random(int(os.environ.get("CGS_FUZZ_SEED", "3")))
+    want = int(os.environ.get("CGS_FUZZ_CASES", "16"))
     done = 0
-    for case in range(24):
+    for case in range(want * 3 // 2):
         B = rng.choice([40, 150, 600, 2500, 8000])
         H, W = rng.choice([64, 77, 128, 200, 333]), rng.choice([64, 130, 176, 256, 401])
         seed = rng.randrange(10000)
@@ -841,9 +843,9 @@ def test_unit_colour_instances_agree_with_the_general_ones_on_random_scenes():
             assert l2(a, b) < 1e-3 + 4.0 * noise and bool(torch.isfinite(a).all()), \
                 f"{where}: dL/d{name} {l2(a, b):.2e} (run-to-run noise of the general instances {noise:.2e})"
         done += 1
-        if done == 16:
+        if done == want:
             break
-    assert done >= 12
+    assert done >= want * 3 // 4
 
 
 def test_graphed_train_step_image_only_forward_follows_the_same_trajectory():
