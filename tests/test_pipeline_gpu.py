@@ -836,12 +836,20 @@ def test_unit_colour_instances_agree_with_the_general_ones_on_random_scenes():
         where = f"case {case}: B={B} {W}x{H} bg={bg} seed={seed}"
         for k in ("color", "omap", "invd"):
             assert amax(u[k], gen[k]) < 2e-5, f"{where}: {k} {amax(u[k], gen[k]):.2e}"
-        assert l2(u["m2d"], gen["m2d"]) < 1e-3, f"{where}: dL_dmeans2D {l2(u['m2d'], gen['m2d']):.2e}"
+        # dL/dmeans2D per splat: equal up to the alpha >= 1/255 decisions that flip between the two exponent roundings -- one
+        # flipped (pixel, splat) pair moves that ONE splat by alpha * |conic d| * T * dL/dpixel * W/2, which on a 150-curve scene
+        # is several per cent of the splat (seeds 204 / 215 / 219 of the CGS_FUZZ_SEED campaign: one pair each, alpha within
+        # 2e-6 of the threshold, the general instance equal to the oracle to 5e-6) -- so: at most a few such splats, the rest tight
+        d_m2d = (u["m2d"] - gen["m2d"]).norm(dim=1)
+        moved = d_m2d > 1e-3 * float(gen["m2d"].norm(dim=1).max())
+        assert int(moved.sum()) <= max(2, int(2e-3 * int((gen["radii"] > 0).sum()))), f"{where}: {int(moved.sum())} splats moved in dL_dmeans2D"
+        assert l2(u["m2d"][~moved], gen["m2d"][~moved]) < 1e-3, f"{where}: dL_dmeans2D {l2(u['m2d'][~moved], gen['m2d'][~moved]):.2e}"
+        keep = ~moved.view(B, 12).any(dim=1)          # curves none of whose splats carries a flipped pair
         for name, a, b, b2 in zip(("curve_points", "width", "opacity"), u["g"], gen["g"], out["general_again"]["g"]):
             noise = l2(b2, b)
             assert noise < 1e-3, f"{where}: dL/d{name}: the general instances differ from themselves by {noise:.2e}"
-            assert l2(a, b) < 1e-3 + 4.0 * noise and bool(torch.isfinite(a).all()), \
-                f"{where}: dL/d{name} {l2(a, b):.2e} (run-to-run noise of the general instances {noise:.2e})"
+            assert l2(a[keep], b[keep]) < 1e-3 + 4.0 * noise and bool(torch.isfinite(a).all()), \
+                f"{where}: dL/d{name} {l2(a[keep], b[keep]):.2e} (run-to-run noise of the general instances {noise:.2e})"
         done += 1
         if done == want:
             break
