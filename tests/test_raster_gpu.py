@@ -6,6 +6,8 @@ Integer / index work (radii, num_rendered, tile ranges, per-tile splat order) mu
 """
 import math
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -821,7 +823,8 @@ def test_bucket_path_equals_exact_path_on_random_scenes():
     from curve_gaussian_amd import _lib
     from curve_gaussian_amd.diff_cur_rasterization import _C
     dev = torch.device(DEV)
-    rng = random.Random(3)
+    rng = random.Random(int(os.environ.get("CGS_FUZZ_SEED", "3")))   # (CGS_FUZZ_SEED / CGS_FUZZ_CASES: one-off campaigns)
+    n_cases = int(os.environ.get("CGS_FUZZ_CASES", "14"))
     lib = _lib.load()
     e = torch.empty(0, device=dev)
 
@@ -840,11 +843,11 @@ def test_bucket_path_equals_exact_path_on_random_scenes():
         torch.cuda.synchronize()
         return r
     try:
-        for case in range(14):
+        for case in range(n_cases):
             H, W = rng.choice([16, 33, 64, 100, 160]), rng.choice([16, 47, 64, 128, 208])
             P = rng.choice([1, 7, 64, 500, 3000, 12000])
             lo = rng.choice([0.002, 0.01, 0.05, 0.3])
-            sp = S.random_splats(P, 2000 + case, scale_range=(lo, lo * rng.choice([2, 10, 40])))
+            sp = S.random_splats(P, 2000 + case + 1000 * (int(os.environ.get("CGS_FUZZ_SEED", "3")) - 3), scale_range=(lo, lo * rng.choice([2, 10, 40])))
             if case % 3 == 0:
                 sp["means3D"] = sp["means3D"][torch.arange(P) % max(1, P // 20)]      # depth ties
             cam = S.make_camera(*CAMS[case % len(CAMS)], H, W)
@@ -857,6 +860,9 @@ def test_bucket_path_equals_exact_path_on_random_scenes():
             lens = rr[:, 1] - rr[:, 0]
             g = [torch.randn(1, H, W, device=dev), torch.randn(1, H, W, device=dev), torch.randn(4, H, W, device=dev)]
             gref = bwd(ref, d, rs, g)
+            # (the same backward over the same state once more: what the order of the float atomics alone moves -- up to
+            # 2e-4 of the maximum in 1 of 640 campaign scenes, CGS_FUZZ_SEED=414)
+            noise = [float((a - b).abs().max()) if a.numel() else 0.0 for a, b in zip(bwd(ref, d, rs, g), gref)]
             for k in range(3):
                 o = fwd(d, rs, H, W, False)
                 assert o[0] == R, (case, k)
@@ -866,8 +872,8 @@ def test_bucket_path_equals_exact_path_on_random_scenes():
                 assert ((orr[:, 1] - orr[:, 0]) == lens).all(), (case, k)
                 for t in range(len(lens)):
                     assert (ol[orr[t, 0]:orr[t, 1]] == rl[rr[t, 0]:rr[t, 1]]).all(), (case, k, t)
-                for a, b in zip(bwd(o, d, rs, g), gref):
+                for a, b, nz in zip(bwd(o, d, rs, g), gref, noise):
                     if a.numel():
-                        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-9, (case, k)
+                        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 4.0 * nz + 1e-9, (case, k)
     finally:
         lib.cgs_reset_binning_hints()
