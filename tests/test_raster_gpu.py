@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import (ORA, S, assert_close, carve_offsets, hip_settings, oracle_forward)
+from util import (ORA, S, assert_close, carve_offsets, hip_settings, near_threshold_pairs, oracle_forward)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -83,13 +83,25 @@ def assert_radii(got, ref):
         assert (np.abs(got[bad].astype(np.int64) - ref[bad]) == 1).all() and (got[bad] > 0).all() and (ref[bad] > 0).all()
 
 
-def compare(sp, cam, bg, grads, grad_outlier_frac=None, grad_outlier_frac_big=None, **kw):
+def compare(sp, cam, bg, grads, grad_outlier_frac=None, grad_outlier_frac_big=None, min_outliers=0, image_cap_abs=None,
+            campaign=False, **kw):
     fw = oracle_forward(sp, cam, bg, **{k: v for k, v in kw.items() if k not in ("debug", "colour_grad")})
     hip = run_hip(sp, cam, bg, grads, **kw)
     assert_radii(hip["radii"], fw.radii)
-    assert_close("color", hip["color"], fw.color)
-    assert_close("invdepth", hip["invdepth"], fw.invdepth)
-    assert_close("all_map", hip["all_map"], fw.out_all_map)
+    if campaign:
+        # budgets that do not round to zero on tiny tensors: the fractional budgets of assert_close OR the count of decisions
+        # that can legally flip in THIS scene -- the oracle's (pixel, splat) pairs whose alpha >= 1/255 or T' < 1e-4 test is
+        # decided within 1e-4 relative (the two exponents differ by a few 1e-6 of the LARGEST term of the quadratic form, which
+        # cancellation leaves several times the exponent itself).  A flipped pair moves its own splat AND, through T (1 - 1/255),
+        # every splat behind it at that pixel (diagnosed: CGS_FUZZ_SEED 679 / 780, r05_experiments.md): four rows per decision.
+        # One flip moves a pixel by 1/255 of the splat's own value: caps in absolute units, from the inputs.
+        min_outliers = 4 * (2 + near_threshold_pairs(fw, window=1e-4))
+        image_cap_abs = 1.3 / 255.0
+    cap = lambda scale: None if image_cap_abs is None else image_cap_abs * max(float(scale), 1e-3)
+    assert_close("color", hip["color"], fw.color, min_outliers=min_outliers, max_outlier_abs=cap(sp["colors"].abs().max()))
+    assert_close("invdepth", hip["invdepth"], fw.invdepth, min_outliers=min_outliers, max_outlier_abs=cap(5.0))   # 1 / near plane
+    assert_close("all_map", hip["all_map"], fw.out_all_map, min_outliers=4 * min_outliers,
+                 max_outlier_abs=cap(sp["all_map"].abs().max()))
     if grads is not None:
         n = lambda t: None if t is None else t.numpy()
         gr = ORA.backward(fw, n(grads[0]), n(grads[1]), n(grads[2]))
@@ -105,10 +117,12 @@ def compare(sp, cam, bg, grads, grad_outlier_frac=None, grad_outlier_frac_big=No
                 flat[:Pn * Mn] = ref.reshape(-1)
                 ref = flat.reshape(Pn, Mn, 3).sum(-1)
                 v = v.reshape(Pn, Mn)
+            row = int(np.prod(ref.shape[1:])) if ref.ndim > 1 else 1     # elements one splat owns in this tensor
             if grad_outlier_frac is None:
-                assert_close(k, v, ref, abs_floor=1e-6, outlier_frac_big=grad_outlier_frac_big)
+                assert_close(k, v, ref, abs_floor=1e-6, outlier_frac_big=grad_outlier_frac_big, min_outliers=min_outliers * row)
             else:
-                assert_close(k, v, ref, abs_floor=1e-6, outlier_frac=grad_outlier_frac, outlier_frac_big=grad_outlier_frac_big)
+                assert_close(k, v, ref, abs_floor=1e-6, outlier_frac=grad_outlier_frac, outlier_frac_big=grad_outlier_frac_big,
+                             min_outliers=min_outliers * row)
     fw.free()
     return hip
 
@@ -124,6 +138,28 @@ def test_forward_backward_random(P, H, W, seed, cam_i):
     eye, tgt, up = CAMS[cam_i]
     cam = S.make_camera(eye, tgt, up, H, W)
     compare(sp, cam, torch.tensor([0.3, 0.0, 0.0]), rand_grads(H, W, seed + 100))
+
+
+@pytest.mark.skipif("CGS_FUZZ_CASES" not in os.environ, reason="one-off campaign: CGS_FUZZ_SEED=<s> CGS_FUZZ_CASES=<n>")
+def test_oracle_campaign_on_random_scenes():
+    """The general operator instances (forward + every gradient) against the C oracle on CGS_FUZZ_CASES random scenes drawn
+    from CGS_FUZZ_SEED: 1 .. 6 000 splats, image sizes that are not tile multiples, splat scales over two decades, the three
+    test cameras (one inside the cloud), black / coloured background, which upstream gradients are present."""
+    import random
+    rng = random.Random(int(os.environ.get("CGS_FUZZ_SEED", "3")))
+    for case in range(int(os.environ["CGS_FUZZ_CASES"])):
+        P = rng.choice([1, 9, 130, 700, 2500, 6000])
+        H, W = rng.choice([16, 33, 77, 128, 150]), rng.choice([16, 47, 100, 160, 209])
+        lo = rng.choice([0.003, 0.01, 0.04])
+        seed = rng.randrange(100000)
+        sp = S.random_splats(P, seed, scale_range=(lo, lo * rng.choice([2, 10, 30])))
+        cam = S.make_camera(*CAMS[rng.randrange(len(CAMS))], H, W)
+        bg = torch.tensor([rng.choice([0.0, 0.3]), 0.0, 0.0])
+        which = rng.choice([(True, True, True), (True, False, False), (True, False, True), (False, True, True)])
+        try:
+            compare(sp, cam, bg, rand_grads(H, W, seed + 1, which), campaign=True)
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: P={P} {W}x{H} lo={lo} seed={seed} which={which}: {e}") from e
 
 
 def test_training_configuration_only_colour_grad():

@@ -57,7 +57,7 @@ BIG_FRAC = 1e-2         # ... those above this fraction of the tensor's maximum
 
 
 def assert_close(name, a, b, rel=REL_TOL, outlier_frac=OUTLIER_FRAC, abs_floor=None, max_outlier=None, tile_cluster=8,
-                 rel_big=REL_BIG, big_frac=BIG_FRAC, outlier_frac_big=None):
+                 rel_big=REL_BIG, big_frac=BIG_FRAC, outlier_frac_big=None, min_outliers=0, max_outlier_abs=None):
     """|a - b| <= rel * max|b| on all but `outlier_frac` of the elements -- the budget for alpha >= 1/255 and T < 1e-4 decisions
     that flip under a different rounding of the exponent -- AND the budget is capped in magnitude and in space:
 
@@ -67,11 +67,15 @@ def assert_close(name, a, b, rel=REL_TOL, outlier_frac=OUTLIER_FRAC, abs_floor=N
       sums by a large fraction while the tensor's maximum sits elsewhere) -- callers pass the cap they measured.
     * tile_cluster: for image-shaped tensors, at most this many outliers inside one 16x16 tile -- flips are isolated
       pixels; a fault in a rare branch (a border quadrant, the long-list sort path, a chunk's padding lane) shows up as a
-      cluster and must not hide in the fraction."""
+      cluster and must not hide in the fraction.
+    * min_outliers: the fractional budgets round to zero on small tensors (a 47 x 150 image: 0.7 pixels), where a single
+      flipped decision is still a legal outcome -- campaigns over tiny random scenes pass the element count of one or two
+      flips here; the suite's fixed cases keep 0."""
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     frac, worst = close_frac(a, b, rel, abs_floor)
-    assert frac <= outlier_frac, f"{name}: {frac:.2e} of elements exceed rel tol {rel} (worst normalised err {worst:.3e})"
+    assert frac * a.size <= max(outlier_frac * a.size, min_outliers) + 1e-9, \
+        f"{name}: {frac:.2e} of elements exceed rel tol {rel} (worst normalised err {worst:.3e})"
     # `rel * max|b|` is an ABSOLUTE tolerance: an element at 1 % of the maximum may be off by 1 % of itself and pass.  So, on top:
     # every element above big_frac of the maximum agrees to rel_big RELATIVE to itself, within the same outlier budget
     # (counted against the whole tensor, like the flips above; `outlier_frac_big` when the caller measured another budget for
@@ -84,11 +88,14 @@ def assert_close(name, a, b, rel=REL_TOL, outlier_frac=OUTLIER_FRAC, abs_floor=N
         big = np.abs(b) > big_frac * scale
         bad_rel = big & (np.abs(a - b) > rel_big * np.abs(b))
         n_bad = int(bad_rel.sum())
-        assert n_bad <= outlier_frac_big * a.size, (
+        assert n_bad <= max(outlier_frac_big * a.size, min_outliers), (
             f"{name}: {n_bad} of {int(big.sum())} elements above {big_frac:g} of the maximum differ by more than {rel_big:g} "
             f"relative (budget {outlier_frac_big * a.size:.1f}); worst {float((np.abs(a - b)[big] / np.abs(b)[big]).max()):.3e}")
     image_like = a.ndim == 3 and a.shape[1] >= 16 and a.shape[2] >= 16
-    if max_outlier is None and image_like:
+    if max_outlier_abs is not None:   # the cap in the tensor's own units (a flip moves a pixel by <= 1/255 of the SPLAT's value:
+        # on a scene of nine splats the image maximum is a fraction of that, and a cap relative to it means nothing)
+        assert worst * np.abs(b).max() <= max_outlier_abs, f"{name}: worst element off by {worst * np.abs(b).max():.3e} (cap {max_outlier_abs:.1e})"
+    elif max_outlier is None and image_like:
         max_outlier = MAX_OUTLIER["image"]
     if max_outlier is not None:
         assert worst <= max_outlier, f"{name}: worst element off by {worst:.3e} of max (cap {max_outlier:.1e})"
@@ -103,6 +110,36 @@ def assert_close(name, a, b, rel=REL_TOL, outlier_frac=OUTLIER_FRAC, abs_floor=N
             assert per_tile.max() <= tile_cluster, (f"{name}: {int(per_tile.max())} outliers inside one 16x16 tile "
                                                     f"(tile {np.unravel_index(per_tile.argmax(), per_tile.shape)}): clustered")
     return worst
+
+
+def near_threshold_pairs(fw, window=1e-5):
+    """Decisions of an oracle forward that may legally fall the other way under another rounding of the exponent (the HIP
+    path's differs by ~2e-6): (pixel, splat) pairs whose alpha lies within `window` (relative) of the 1/255 cut
+    (forward.cu:369), and pairs whose transmittance test T (1 - alpha) < 1e-4 (forward.cu:374) is decided within `window`.
+    Plain numpy over the oracle's tile lists, float32 in list order like the kernel; for campaign-sized scenes only."""
+    H, W = fw.H, fw.W
+    tiles_x = (W + 15) // 16
+    m2, co, pl, ranges = fw.means2D.astype(np.float32), fw.conic_opacity.astype(np.float32), fw.point_list, fw.ranges
+    near = 0
+    for t, (r0, r1) in enumerate(ranges):
+        if r1 <= r0:
+            continue
+        ty, tx = divmod(t, tiles_x)
+        ys, xs = np.arange(ty * 16, min(H, ty * 16 + 16), dtype=np.float32), np.arange(tx * 16, min(W, tx * 16 + 16), dtype=np.float32)
+        px, py = np.meshgrid(xs, ys)
+        ids = pl[r0:r1]
+        dx = m2[ids, 0][:, None] - px.reshape(1, -1)
+        dy = m2[ids, 1][:, None] - py.reshape(1, -1)
+        c = co[ids]
+        power = np.float32(-0.5) * (c[:, 0:1] * dx * dx + c[:, 2:3] * dy * dy) - c[:, 1:2] * dx * dy
+        alpha = np.minimum(np.float32(0.99), c[:, 3:4] * np.exp(power))
+        blends = (power <= 0) & (alpha >= np.float32(1.0 / 255.0))
+        Tn = np.cumprod(np.where(blends, np.float32(1.0) - alpha, np.float32(1.0)), axis=0, dtype=np.float32)   # T after pair j
+        alive = np.vstack([np.ones((1, Tn.shape[1]), bool), Tn[:-1] >= np.float32(1e-4)])                       # pair j is reached
+        alive = np.logical_and.accumulate(alive, axis=0)
+        near += int((alive & (power <= 0) & (np.abs(alpha * np.float32(255.0) - 1.0) < window)).sum())
+        near += int((alive & blends & (np.abs(Tn * np.float32(1e4) - 1.0) < window)).sum())
+    return near
 
 
 def carve_offsets(base_ptr_mod, counts_and_sizes):
