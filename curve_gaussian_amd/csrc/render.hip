@@ -72,6 +72,13 @@ struct ViewEpilogue {
 // (the kernel is bound by exactly those two: VALU issue and LDS return traffic).  Each wave compacts the staged entries
 // its quadrant accepted into a private list and walks it in groups of 16.
 constexpr int GROUP = 16;
+// What-if builds (profiles/probes/kernel_times.py, profiles/r06_experiments.md): the forward with ONE cost removed -- wrong
+// images on purpose, only the times mean something.  Bits: 1 no pair walk (operands + MFMAs stay), 2 no groups at all (sort,
+// staging and lists stay), 4 walk without the per-pair LDS read of the splat's channels, 8 walk without v_exp, 16 walk without the
+// termination test, 32 fused rank + stage path without the ranking loop, 64 no per-pixel output stores.  0 in every product build.
+#ifndef CGS_WHATIF
+#define CGS_WHATIF 0
+#endif
 // 6 waves per SIMD (80 VGPRs, a dozen spills): 136 us at the natural 104 VGPRs / 4 waves, 124 at 5, 122 at 6, 128 at 7
 #ifndef CGS_FWD3_WAVES
 #define CGS_FWD3_WAVES 6
@@ -186,7 +193,7 @@ __global__ void __launch_bounds__(256, UNIT ? CGS_FWD3_WAVES : CGS_FWD3_WAVES_GE
             uint32_t lost = 0u;
             if (((uint32_t)__builtin_amdgcn_readfirstlane((int)tid) & ~63u) < n) {   // wave-uniform
                 // (depths are positive finite floats -- view-space z > 0.2 -- whose order is the order of their bit patterns)
-                const uint32_t rk[1] = {rank_loop_f32(reinterpret_cast<const float*>(s_ord), n, __uint_as_float(depth))};
+                const uint32_t rk[1] = {(CGS_WHATIF & 32) ? tid : rank_loop_f32(reinterpret_cast<const float*>(s_ord), n, __uint_as_float(depth))};
                 if (has) {
                     float4 sa, sb;
                     stage_splat(ra, rb, sa, sb);
@@ -285,7 +292,7 @@ __global__ void __launch_bounds__(256, UNIT ? CGS_FWD3_WAVES : CGS_FWD3_WAVES_GE
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         uint32_t last_off = 0;   // byte offset (16 * (staged index + 1)) of the last splat this pixel blended in this batch
-        for (int g0 = 0; g0 < n; g0 += GROUP) {
+        for (int g0 = 0; g0 < ((CGS_WHATIF & 2) ? 0 : n); g0 += GROUP) {
             // exponents of the group's 16 splats at this wave's 64 pixels.  (Issuing the NEXT group's MFMAs before this
             // group's blends was tried: 16 more live registers, 122 -> 135 us.)
             f32x16 P;
@@ -295,7 +302,8 @@ __global__ void __launch_bounds__(256, UNIT ? CGS_FWD3_WAVES : CGS_FWD3_WAVES_GE
                 const float2 cl = *reinterpret_cast<const float2*>(at_bytes + joff + 8);
                 P = p2_mfma(p2_splat_operand(lane, ge.x, ge.y, ge.z, ge.w, cl.x, cl.y, hx, hy), pix);
             }
-            const int cnt = min(GROUP, n - g0);
+            const int cnt = (CGS_WHATIF & 1) ? 0 : min(GROUP, n - g0);
+            if (CGS_WHATIF & 1) Dacc += P[0] + P[15];
             uint4 w4 = make_uint4(0u, 0u, 0u, 0u);   // four list offsets at a time, same in every lane
 #pragma unroll
             for (int s = 0; s < GROUP; s += 2) {
@@ -308,13 +316,16 @@ __global__ void __launch_bounds__(256, UNIT ? CGS_FWD3_WAVES : CGS_FWD3_WAVES_GE
                     t1 = *reinterpret_cast<const float2*>(at_bytes + j1);
                 }
                 float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
-                if (GEO) {
+                if (GEO && !(CGS_WHATIF & 4)) {
                     c0 = *reinterpret_cast<const float4*>(c_bytes + j0);
                     c1 = *reinterpret_cast<const float4*>(c_bytes + j1);
+                } else if (GEO) {
+                    c0 = make_float4(hx, hy, k.big, k.cA);
+                    c1 = make_float4(hy, hx, k.cA, k.big);
                 }
                 // alpha = min(0.99, opacity * G) = min(0.99, exp2(P)); reference: alpha < 1/255 -> skip
-                const float al0 = fminf(0.99f, __builtin_amdgcn_exp2f(P[s]));
-                const float al1 = fminf(0.99f, __builtin_amdgcn_exp2f(P[s + 1]));
+                const float al0 = fminf(0.99f, (CGS_WHATIF & 8) ? P[s] : __builtin_amdgcn_exp2f(P[s]));
+                const float al1 = fminf(0.99f, (CGS_WHATIF & 8) ? P[s + 1] : __builtin_amdgcn_exp2f(P[s + 1]));
                 const float a0 = al0 * sat01(fmaf(al0, k.big, cA));
                 const float a1 = al1 * sat01(fmaf(al1, k.big, cA));
                 // two splats blended together, one termination test (see k_render_fwd)
@@ -322,7 +333,7 @@ __global__ void __launch_bounds__(256, UNIT ? CGS_FWD3_WAVES : CGS_FWD3_WAVES_GE
                 float T1 = fmaf(-Tw, a0, Tw);
                 float wb = a1 * T1;
                 float T2 = fmaf(-T1, a1, T1);
-                if (__builtin_expect(ballot64(T2 < 0.0001f) != 0ull, 0)) {
+                if (!(CGS_WHATIF & 16) && __builtin_expect(ballot64(T2 < 0.0001f) != 0ull, 0)) {
                     const bool d0 = T1 < 0.0001f;
                     T_dead = d0 ? Tw : T_dead;
                     wa = d0 ? 0.f : wa;
@@ -365,7 +376,7 @@ __global__ void __launch_bounds__(256, UNIT ? CGS_FWD3_WAVES : CGS_FWD3_WAVES_GE
     }
     const bool terminated = !(cA > -0x1p120f);
     if (UNIT && !terminated) last_contributor = (uint32_t)total;   // never terminated: no cut
-    if (g.inside) {
+    if ((CGS_WHATIF & 64) ? (g.inside && Tw + Dacc + A0 + A1 + A2 == 12345.f) : g.inside) {
         const size_t HW = (size_t)H * W;
         const float T = terminated ? T_dead : Tw;
         final_T[g.pix_id] = T;

@@ -28,6 +28,11 @@
 
 namespace cgs {
 
+// What-if builds (profiles/probes/kernel_times.py, profiles/r06_experiments.md): 1 no pixel rows, 2 no output phase (shift to the
+// centre, swaps, run sums, atomics), 4 no chunks at all (prologue, staging and the pair list stay).  0 in every product build.
+#ifndef CGS_UB_WHATIF
+#define CGS_UB_WHATIF 0
+#endif
 #ifndef CGS_UBWD_WAVES
 #define CGS_UBWD_WAVES 6
 #endif
@@ -301,7 +306,7 @@ __global__ void __launch_bounds__(256, CGS_UBWD_WAVES) k_render_bwd_unit(
         }
         __syncthreads();
         const int nch = (int)((n_pairs + CH - 1) / CH);
-        for (int c = g.wave; c < nch; c += 4) {
+        for (int c = g.wave; c < ((CGS_UB_WHATIF & 4) ? 0 : nch); c += 4) {
             // ---- the chunk's 32 pairs: lane (n, hh) builds K half hh of pair n's coefficient set
             const uint32_t ent = s_list[c * CH + n];
             const uint32_t J = ent & 511u, q = (ent >> 9) & 3u, run_k = (ent >> 11) & 3u, run_last = (ent >> 13) & 3u;
@@ -334,12 +339,13 @@ __global__ void __launch_bounds__(256, CGS_UBWD_WAVES) k_render_bwd_unit(
                 P = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, px.k0), __builtin_bit_cast(bf16x8, bf.k0), P, 0, 0, 0);
                 P = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pix0.k1), __builtin_bit_cast(bf16x8, bf.k1), P, 0, 0, 0);
                 float r0, r1, r2;
-                const int variant = (slow ? 2 : 0) + (lean ? 1 : 0);   // wave-uniform
+                if (CGS_UB_WHATIF & 1) { r0 = P[0]; r1 = P[7]; r2 = P[15]; }
+                const int variant = (CGS_UB_WHATIF & 1) ? 4 : (slow ? 2 : 0) + (lean ? 1 : 0);   // wave-uniform
 #define CGS_UB_ROW(R)                                                                                        \
     if (variant == 3) ub_walk_row<true, true>(P, R, krow + 16 * b, lrow + 16 * b, lpos, wk, r0, r1, r2);        \
     else if (variant == 2) ub_walk_row<true, false>(P, R, krow + 16 * b, lrow + 16 * b, lpos, wk, r0, r1, r2);  \
     else if (variant == 1) ub_walk_row<false, true>(P, R, krow + 16 * b, lrow + 16 * b, lpos, wk, r0, r1, r2);  \
-    else ub_walk_row<false, false>(P, R, krow + 16 * b, lrow + 16 * b, lpos, wk, r0, r1, r2)
+    else if (variant == 0) ub_walk_row<false, false>(P, R, krow + 16 * b, lrow + 16 * b, lpos, wk, r0, r1, r2)
                 CGS_UB_ROW(0);    // row j = 2 b
                 N00 += r0; X1 += r1; X2 += r2;
                 if (b) { Y1 = fmaf(2.f, r0, Y1); Y2 = fmaf(4.f, r0, Y2); XY = fmaf(2.f, r1, XY); }
@@ -348,6 +354,10 @@ __global__ void __launch_bounds__(256, CGS_UBWD_WAVES) k_render_bwd_unit(
                 N00 += r0; X1 += r1; X2 += r2;
                 const float j = (float)(2 * b + 1);
                 Y1 = fmaf(j, r0, Y1); Y2 = fmaf(j * j, r0, Y2); XY = fmaf(j, r1, XY);
+            }
+            if (CGS_UB_WHATIF & 2) {
+                if (N00 + X1 + X2 + Y1 + Y2 + XY == 12345.f) grad_acc[lane] = 1.f;
+                continue;
             }
             // ---- to the splat centre: pixel = (qox + x, qoy + hh + 2 j), d = centre - pixel (backward.cu:655-672 are
             // linear in these sums; applied once per splat in splat_math.h::splat_backward)
