@@ -535,6 +535,28 @@ def main():
         prof_direct = list(make_direct_view(torch.zeros_like(flat_grads), cap))
 
     use_graphs = [view_graphs is not None]
+    reps = [1]
+    own_n1 = None   # this rank's single-GPU rate on the same workload, measured BEFORE the process group exists
+    if (world > 1 or os.environ.get("CGS_BENCH_FORCE_DIST")) and args.mode == "view":
+        # Self-diagnosis of a multi-GPU run: the same K-step region with no collective and no other rank
+        # in the schedule -- what this process does alone, in this process, on this GPU.  efficiency_vs_own_n1 = per-rank
+        # rate of the timed run / this; a low value with a small all_reduce_ms points at the host (N ranks' Python on one
+        # node), a large all_reduce_ms at the wire / RCCL channels.
+        run_views(my_cams[:Wm * G])
+        torch.cuda.synchronize()
+        t_own, n_own = 0.0, 0
+        while t_own < min(1.0, args.min_seconds) or n_own == 0:
+            t0 = time.perf_counter()
+            run_views(my_cams[Wm * G:(Wm + K) * G])
+            torch.cuda.synchronize()
+            t_own += time.perf_counter() - t0
+            n_own += 1
+            if n_own >= 10000:
+                break
+        own_n1 = {"ms_per_step": t_own / (n_own * K) * 1e3, "msplats_per_s": P * G * K * n_own / t_own / 1e6}
+        for flats in flat_sets:
+            for f in flats:
+                f.zero_()
     if world > 1 or os.environ.get("CGS_BENCH_FORCE_DIST"):   # (the env switch exercises RCCL with a single rank)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -550,8 +572,6 @@ def main():
         flag = torch.tensor([1 if use_graphs[0] else 0], device=dev, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         use_graphs[0] = bool(int(flag.item()))
-
-    reps = [1]
 
     def timed():
         """Wm warm-up steps, then the K-step region `reps` times back to back inside ONE barrier + synchronize bracket."""
@@ -584,10 +604,35 @@ def main():
         print("bench: bucket overflow in graph mode, re-timing with eager launches", file=sys.stderr)
         use_graphs[0] = False
         elapsed = timed_long()
+    rank_diag = None
     if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        # per-rank times of the timed region (the headline takes the MAX), each rank's own N = 1 rate, and the all-reduce of the
+        # step's flat gradient buffer timed ALONE with events on the stream it is issued on
+        mine = torch.tensor([elapsed, own_n1["ms_per_step"] if own_n1 else 0.0, own_n1["msplats_per_s"] if own_n1 else 0.0],
+                            device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, mine)
+        per_rank = [float(t[0].item()) for t in every]
+        ar_ms = None
+        if args.mode == "view":
+            buf = flat_sets[0][0]
+            for _ in range(3):
+                dist.all_reduce(buf)
+            barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n_ar = 20
+            e0.record()
+            for _ in range(n_ar):
+                dist.all_reduce(buf)
+            e1.record()
+            e1.synchronize()
+            ar = torch.tensor([e0.elapsed_time(e1) / n_ar], device=dev, dtype=torch.float64)
+            dist.all_reduce(ar, op=dist.ReduceOp.MAX)
+            ar_ms = float(ar.item())
+            buf.zero_()
+        rank_diag = {"per_rank_elapsed_s": per_rank, "own_n1": [(float(t[1].item()), float(t[2].item())) for t in every],
+                     "all_reduce_ms": ar_ms}
+        elapsed = max(per_rank)
 
     # the step's summed gradient under the timed schedule (streams, graphs, double-buffered sets) against the same views
     # run one at a time, eagerly, on one stream: the overlap machinery must not change what is computed
@@ -788,6 +833,25 @@ def main():
                                       "cfg5": {"step_ms": 5.6, "all_reduce_bytes": 12667000}},
             "if_below": "check step_boundary == double-buffered (else the all-reduce serialises with the views); then "
                         "NCCL_MAX_NCHANNELS=4 (RCCL channels starving the compositors of CUs)"}
+    if rank_diag is not None:
+        # measured, beside the prediction above: a bad first multi-GPU run says WHERE it lost
+        n_steps = K * reps[0]
+        per = [t / n_steps * 1e3 for t in rank_diag["per_rank_elapsed_s"]]
+        slow = max(range(len(per)), key=per.__getitem__)
+        out["all_reduce_ms"] = None if rank_diag["all_reduce_ms"] is None else round(rank_diag["all_reduce_ms"], 4)
+        out["all_reduce_note"] = ("one all-reduce of the flat gradient buffer (38 floats / curve) timed alone, max over ranks; "
+                                  "in the timed schedule it overlaps the next step's views")
+        out["per_rank_ms_per_step"] = {"min": round(min(per), 4), "max": round(max(per), 4), "slowest_rank": slow,
+                                       "all": [round(x, 4) for x in per]}
+        if own_n1 is not None:
+            own = rank_diag["own_n1"]
+            out["own_n1"] = {"ms_per_step_rank0": round(own[0][0], 4), "msplats_per_s_rank0": round(own[0][1], 1),
+                             "msplats_per_s_min_over_ranks": round(min(o[1] for o in own), 1),
+                             "msplats_per_s_max_over_ranks": round(max(o[1] for o in own), 1),
+                             "note": "the same K-step region on this GPU before the process group formed: no collective, "
+                                     "no barrier; every rank measures its own while the others measure theirs"}
+            # whole-job rate / (N x the mean of the ranks' own single-GPU rates)
+            out["efficiency_vs_own_n1"] = round(out["value"] / max(sum(o[1] for o in own), 1e-9), 4)
     if vp_train_ms is not None:   # one optimizer step = `world` views (one per rank), gradients summed by ONE all-reduce
         out["train_step_view_parallel_ms"] = round(vp_train_ms, 4)
     if grad_check is not None:

@@ -69,60 +69,70 @@ struct BinHints { int64_t R = 0, max = 0, big = 0; };
 // bucket scatter: splats per wave from the instance count the shape binned last time (profiles/r04_experiments.md #19: 12 wins
 // at cfg3 / cfg5 -- 1.6 M / 8 M instances --, 8 at cfg2 / cfg4 -- 0.4 M / 0.17 M)
 static inline int scatter_spw(const BinHints& h) { return (h.R > 0 && h.R < 800000) ? 8 : 12; }
-struct HintEntry { int P = -1, W = 0, H = 0; uint64_t stamp = 0; BinHints h; };
+struct HintEntry { int dev = -1, P = -1, W = 0, H = 0; uint64_t stamp = 0; BinHints h; };   // dev: the HIP device the shape was seen on
 static std::mutex g_hint_mu;
 static HintEntry g_hint_tab[32];
 static uint64_t g_hint_clock = 0;
 // Exact match, or nullptr.  (A pure lookup never inserts: cgs_view_forward / cgs_rasterize_forward_static only ask.)
-static HintEntry* hint_find_locked(int P, int W, int H) {
+static int current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) d = 0;
+    return d;
+}
+static HintEntry* hint_find_locked(int dev, int P, int W, int H) {
     for (auto& e : g_hint_tab)
-        if (e.P == P && e.W == W && e.H == H) { e.stamp = ++g_hint_clock; return &e; }
+        if (e.dev == dev && e.P == P && e.W == W && e.H == H) { e.stamp = ++g_hint_clock; return &e; }
     return nullptr;
 }
 // Most recently used entry of the same resolution but another splat count: a topology edit (densify / prune / split) changes
 // P by a few curves, and the new cloud bins almost like the old one -- its history seeds the new shape (R scaled by the
 // splat ratio) instead of sending the next forward of every resolution through the exact path again.
-static const HintEntry* hint_neighbour_locked(int W, int H) {
+static const HintEntry* hint_neighbour_locked(int dev, int W, int H) {
     const HintEntry* best = nullptr;
     for (auto& e : g_hint_tab)
-        if (e.P > 0 && e.W == W && e.H == H && (!best || e.stamp > best->stamp)) best = &e;
+        if (e.dev == dev && e.P > 0 && e.W == W && e.H == H && (!best || e.stamp > best->stamp)) best = &e;
     return best;
 }
-static BinHints hint_seed_locked(int P, int W, int H) {
+static BinHints hint_seed_locked(int dev, int P, int W, int H) {
     BinHints h;
-    if (const HintEntry* nb = hint_neighbour_locked(W, H)) {
+    if (const HintEntry* nb = hint_neighbour_locked(dev, W, H)) {
         h = nb->h;
         h.R = (int64_t)((double)nb->h.R * (double)P / (double)nb->P);
     }
     return h;
 }
-static HintEntry* hint_entry_locked(int P, int W, int H) {   // find or insert (LRU eviction)
-    if (HintEntry* e = hint_find_locked(P, W, H)) return e;
-    const BinHints seed = hint_seed_locked(P, W, H);
+static HintEntry* hint_entry_locked(int dev, int P, int W, int H) {   // find or insert (LRU eviction)
+    if (HintEntry* e = hint_find_locked(dev, P, W, H)) return e;
+    const BinHints seed = hint_seed_locked(dev, P, W, H);
     HintEntry* lru = &g_hint_tab[0];
     for (auto& e : g_hint_tab)
         if (e.stamp < lru->stamp) lru = &e;
     *lru = HintEntry{};
-    lru->P = P; lru->W = W; lru->H = H; lru->stamp = ++g_hint_clock; lru->h = seed;
+    lru->dev = dev; lru->P = P; lru->W = W; lru->H = H; lru->stamp = ++g_hint_clock; lru->h = seed;
     return lru;
 }
-static BinHints hints_load(int P, int W, int H) {
+// (the shape's history belongs to the CURRENT device: two ranks' or two models' views on different GPUs of one process do not
+// share bucket capacities; `dev` < 0 = ask the runtime)
+static BinHints hints_load(int P, int W, int H, int dev = -1) {
+    if (dev < 0) dev = current_device();
     std::lock_guard<std::mutex> lk(g_hint_mu);
-    if (HintEntry* e = hint_find_locked(P, W, H)) return e->h;
-    return hint_seed_locked(P, W, H);
+    if (HintEntry* e = hint_find_locked(dev, P, W, H)) return e->h;
+    return hint_seed_locked(dev, P, W, H);
 }
 // R < 0 / big < 0: leave that field; longest: folded into the decaying maximum
-static void hints_update(int P, int W, int H, int64_t R, uint32_t longest, int64_t big) {
+static void hints_update(int P, int W, int H, int64_t R, uint32_t longest, int64_t big, int dev = -1) {
+    if (dev < 0) dev = current_device();
     std::lock_guard<std::mutex> lk(g_hint_mu);
-    BinHints& h = hint_entry_locked(P, W, H)->h;
+    BinHints& h = hint_entry_locked(dev, P, W, H)->h;
     if (R >= 0) h.R = R;
     if (big >= 0) h.big = big;
     // Slowly decaying maximum.  A bucket overflow costs a whole second forward through the exact path, spare capacity only
     // memory (12 bytes per slot and tile), and a training loop cycles through dozens of views whose longest lists differ by
     // tens of per cent: at the round-4 rate of 1/16 per call seven sparser views in a row shrank the capacity by a third
     // and the next dense view overflowed (the general route's eager time was bimodal, 0.40 / 0.53 ms at cfg3).  1/1024 per
-    // call keeps 94 % after 64 calls -- inside the 25 % margin -- and still follows a cloud that thins out for good.
-    h.max = std::max<int64_t>((int64_t)longest, h.max - (h.max >> 10));
+    // call (at least one entry: below 1 024 the shift alone would never decay) keeps 94 % after 64 calls -- inside the 25 %
+    // margin -- and still follows a cloud that thins out for good.
+    h.max = std::max<int64_t>((int64_t)longest, h.max - std::max<int64_t>(1, h.max >> 10));
 }
 static thread_local int64_t g_last_visible = -1;   // radii > 0 count of the last cgs_view_forward_checked
 static thread_local int64_t g_last_stats[3] = {0, 0, 0};  // num_rendered, longest tile list, binning path (0 exact, 1 bucket)
@@ -399,16 +409,27 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
     // tile_count and tile_cursor are adjacent 128B-aligned carve-outs: clear both (+total) with one memset
     const size_t clear_bytes = (size_t)((char*)(img.total + TOTAL_WORDS) - (char*)img.tile_count);
     const int cull = g_tile_cull.load(std::memory_order_relaxed);
-    static thread_local uint32_t* h_tot = nullptr;  // pinned copy of img.total
-    static thread_local hipEvent_t ev = nullptr;
-    if (!h_tot) {
-        if (hipHostMalloc((void**)&h_tot, TOTAL_WORDS * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
-            hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+    // pinned copy of img.total + the event behind it: per calling thread AND per device (an event only records on streams of
+    // the device it was created on)
+    constexpr int MAX_DEV = 16;
+    static thread_local uint32_t* h_tot_dev[MAX_DEV] = {};
+    static thread_local hipEvent_t ev_dev[MAX_DEV] = {};
+    const int dev_ix = current_device();
+    if (dev_ix < 0 || dev_ix >= MAX_DEV) {
+        set_error("cgs_rasterize_forward: device index %d out of range", dev_ix);
+        return CGS_ERR_INVALID_ARGUMENT;
+    }
+    if (!h_tot_dev[dev_ix]) {
+        if (hipHostMalloc((void**)&h_tot_dev[dev_ix], TOTAL_WORDS * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_dev[dev_ix], hipEventDisableTiming) != hipSuccess) {
             set_error("pinned readback buffer / event creation failed");
-            h_tot = nullptr;
+            if (h_tot_dev[dev_ix]) (void)hipHostFree(h_tot_dev[dev_ix]);
+            h_tot_dev[dev_ix] = nullptr;
             return CGS_ERR_HIP;
         }
     }
+    uint32_t* const h_tot = h_tot_dev[dev_ix];
+    const hipEvent_t ev = ev_dev[dev_ix];
     auto read_totals = [&]() -> bool {  // async copy of img.total + event; the caller waits on the event later
         hipError_t e = hipMemcpyAsync(h_tot, img.total, TOTAL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipEventRecord(ev, s);
@@ -748,35 +769,51 @@ int cgs_sample_curves_forward(int B, int m, const float* curve_points, const flo
 // releases it.  Forwards begun by different threads, on different devices or streams, or for different models are
 // independent; a caller that drops a handle (an exception between begin and wait) leaks nothing but the slot until
 // cgs_view_forward_abandon(handle).
-struct ViewStat { uint32_t* h = nullptr; hipEvent_t ev = nullptr; int P = 0, W = 0, H = 0; uint64_t cap = 0; bool busy = false; };
+// A slot belongs to the device its event was created on (hipEventRecord rejects an event / stream pair of different devices):
+// a forward only takes slots of the current device.
+struct ViewStat { uint32_t* h = nullptr; hipEvent_t ev = nullptr; int dev = -1, P = 0, W = 0, H = 0; uint64_t cap = 0; bool busy = false; };
 constexpr int VIEW_SLOTS = 64;
 static ViewStat g_view_slots[VIEW_SLOTS];
 static std::mutex g_view_mu;
 static int view_slot_acquire() {   // -> slot index, or a negative status
+    const int dev = current_device();
     std::lock_guard<std::mutex> lk(g_view_mu);
+    int fresh = -1;
     for (int i = 0; i < VIEW_SLOTS; i++) {
         ViewStat& v = g_view_slots[i];
         if (v.busy) continue;
-        if (!v.h) {
-            if (hipHostMalloc((void**)&v.h, 4 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
-                hipEventCreateWithFlags(&v.ev, hipEventDisableTiming) != hipSuccess) {
-                set_error("pinned readback buffer / event creation failed");
-                v.h = nullptr;
-                return CGS_ERR_HIP;
-            }
-        }
+        if (!v.h) { if (fresh < 0) fresh = i; continue; }   // never used: taken only when no idle slot of this device exists
+        if (v.dev != dev) continue;
         v.busy = true;
         return i;
     }
-    set_error("cgs_view_forward_begin: %d checked forwards outstanding (every begin needs its cgs_view_forward_wait)", VIEW_SLOTS);
+    if (fresh >= 0) {
+        ViewStat& v = g_view_slots[fresh];
+        if (hipHostMalloc((void**)&v.h, 4 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&v.ev, hipEventDisableTiming) != hipSuccess) {
+            set_error("pinned readback buffer / event creation failed");
+            if (v.h) (void)hipHostFree(v.h);
+            v.h = nullptr;
+            return CGS_ERR_HIP;
+        }
+        v.dev = dev;
+        v.busy = true;
+        return fresh;
+    }
+    set_error("cgs_view_forward_begin: no free status slot for device %d (%d slots; every begin needs its cgs_view_forward_wait)", dev,
+              VIEW_SLOTS);
     return CGS_ERR_INVALID_ARGUMENT;
+}
+static bool view_slot_busy(int i) {
+    std::lock_guard<std::mutex> lk(g_view_mu);
+    return g_view_slots[i].busy;
 }
 static void view_slot_release(int i) {
     std::lock_guard<std::mutex> lk(g_view_mu);
     g_view_slots[i].busy = false;
 }
 static int64_t view_forward_wait(int handle, int64_t* n_visible) {
-    if (handle < 0 || handle >= VIEW_SLOTS || !g_view_slots[handle].busy) {
+    if (handle < 0 || handle >= VIEW_SLOTS || !view_slot_busy(handle)) {
         set_error("cgs_view_forward_wait: handle %d is not an outstanding checked forward", handle);
         return CGS_ERR_INVALID_ARGUMENT;
     }
@@ -788,7 +825,7 @@ static int64_t view_forward_wait(int handle, int64_t* n_visible) {
         return CGS_ERR_HIP;
     }
     const uint32_t longest = v.h[1];
-    hints_update(v.P, v.W, v.H, (uint64_t)longest <= v.cap ? (int64_t)v.h[0] : -1, longest, (int64_t)v.h[3]);
+    hints_update(v.P, v.W, v.H, (uint64_t)longest <= v.cap ? (int64_t)v.h[0] : -1, longest, (int64_t)v.h[3], v.dev);
     g_last_stats[0] = (int64_t)v.h[0]; g_last_stats[1] = (int64_t)longest; g_last_stats[2] = 1;
     g_last_visible = (int64_t)v.h[2];
     if (n_visible) *n_visible = (int64_t)v.h[2];
@@ -947,7 +984,7 @@ int cgs_view_forward_render(int checked, int B, int m, const float* curve_points
 }
 int64_t cgs_view_forward_wait(int handle, int64_t* n_visible) { return view_forward_wait(handle, n_visible); }
 void cgs_view_forward_abandon(int handle) {
-    if (handle < 0 || handle >= VIEW_SLOTS || !g_view_slots[handle].busy) return;
+    if (handle < 0 || handle >= VIEW_SLOTS || !view_slot_busy(handle)) return;
     // the slot's readback may still be in flight: let it land before the pinned words can be handed to another forward (a
     // later forward on ANOTHER stream would otherwise race with it)
     (void)hipEventSynchronize(g_view_slots[handle].ev);

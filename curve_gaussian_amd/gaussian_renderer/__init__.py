@@ -86,12 +86,17 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_
     if separate_sh:   # (:108-119) GaussianRasterizer.forward() got an unexpected keyword argument 'dc'
         raise TypeError("GaussianRasterizer.forward() got an unexpected keyword argument 'dc' (render(separate_sh=True): the "
                         "reference's rasterizer has no separate-SH entry point, gaussian_renderer/__init__.py:108-119)")
-    dev = pc.get_xyz.device
+    use_fused = _fused_route_ok(pc, pipe, scaling_modifier, override_color) if fused is None else bool(fused)
+    if use_fused and hasattr(pc, "n_splats"):   # (the fused route never reads the derived tensors: a lazy model keeps them deferred)
+        dev = pc._curve_points.device
+        new_points = lambda: torch.zeros(pc.n_splats, 3, dtype=pc._curve_points.dtype, requires_grad=True, device=dev)
+    else:
+        dev = pc.get_xyz.device
+        new_points = lambda: torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True, device=dev)
     # (:30-34) a zero tensor whose .grad receives the screen-space gradients; a leaf needs no retain_grad()
-    screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True, device=dev)
+    screenspace_points = new_points()
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
-    use_fused = _fused_route_ok(pc, pipe, scaling_modifier, override_color) if fused is None else bool(fused)
     if fused and not _fused_route_ok(pc, pipe, scaling_modifier, override_color):
         raise ValueError("render(fused=True): the fused view path needs a GaussianCurveModel whose derived tensors are current "
                          "and the reference's default pipeline flags")
@@ -121,7 +126,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_
             if ok:
                 break
             # a tile list outgrew its bucket (first view of a new scene, or a much denser one): the capacity has been raised
-            screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True, device=dev)
+            screenspace_points = new_points()
         if compute_visibility:
             pkg["visibility_filter"] = VR.visible_indices(radii, n_visible, this)
         return pkg

@@ -98,9 +98,13 @@ class GaussianCurveModel:
         self._features_dc = torch.empty(0)
         self._features_rest = torch.empty(0)
         self.is_bezier = torch.empty(0)
-        self._xyz = torch.empty(0)
-        self._rotation = torch.empty(0)
-        self._scaling = torch.empty(0)
+        # Derived per-splat tensors.  lazy_derived (set by loops that own the parameter updates, train_step.TrainStep): a
+        # prepare_scaling_rot() only records what to derive from, the sampling kernels run when `_xyz` / `_rotation` /
+        # `_scaling` are first READ -- the fused render route samples inside its own kernels and never reads them, so a
+        # training iteration runs the grid-wide norm pass once, not twice.  Off: derived on the spot, like the reference.
+        self.lazy_derived = False
+        self._derived_pending = None          # (eps, grad mode) of a prepare_scaling_rot() that has not run its kernels yet
+        self._derived = [torch.empty(0), torch.empty(0), torch.empty(0)]
         self.optimizer = None
         self.exposure_optimizer = None
         self.exposure_mapping = {}
@@ -302,14 +306,51 @@ class GaussianCurveModel:
     # ------------------------------------------------------------------ per-step derivation
     def prepare_scaling_rot(self, eps=1e-8):
         """:180-198 -- fused HIP sampling kernel (forward + hand-written backward)."""
-        self._xyz, self._rotation, self._scaling = curve_sampling.sample_curves(
-            self._curve_points, self._width, self.is_bezier, self.n_gaussians, eps)
+        if self.lazy_derived and self._curve_points.is_cuda:
+            self._derived_pending = (float(eps), torch.is_grad_enabled())
+        else:
+            self._derived_pending = None
+            self._derived = list(curve_sampling.sample_curves(self._curve_points, self._width, self.is_bezier,
+                                                              self.n_gaussians, eps))
         # which parameter state the derived tensors belong to: render() takes its fused per-view route (which samples the
         # curves itself) only while they are current, so both routes draw the same splats
         self._derived_eps = float(eps)
-        self._derived_from = (self._curve_points.data_ptr(), self._curve_points._version, self._width.data_ptr(),
-                              self._width._version, tuple(self._curve_points.shape), self.is_bezier.data_ptr(),
-                              self.is_bezier._version)
+        self._derived_from = self._param_stamp()
+
+    def _param_stamp(self):
+        return (self._curve_points.data_ptr(), self._curve_points._version, self._width.data_ptr(), self._width._version,
+                tuple(self._curve_points.shape), self.is_bezier.data_ptr(), self.is_bezier._version)
+
+    def _derive(self, k):
+        """The k-th derived tensor; runs the deferred sampling first (lazy_derived).  The deferred tensors are derived from the
+        parameters as they are when first READ.  The loop that switched laziness on only changes the curve tensors through its
+        optimizer step, which is followed by the next prepare_scaling_rot(), so that is the state the call saw -- except when
+        a parameter's STORAGE was replaced with equal values in between (reset_opacity / a topology edit rebuilding the flat
+        buffers): the stamp then names the storage that was actually sampled, and render() may keep its fused route."""
+        pend = self._derived_pending
+        if pend is not None:
+            self._derived_pending = None
+            # (grad mode: the prepare_scaling_rot() call's, or the reader's -- a topology edit made under no_grad followed by a
+            # training render must still reach the curve parameters through the derived tensors)
+            with torch.set_grad_enabled(pend[1] or torch.is_grad_enabled()):
+                self._derived = list(curve_sampling.sample_curves(self._curve_points, self._width, self.is_bezier,
+                                                                  self.n_gaussians, pend[0]))
+            self._derived_from = self._param_stamp()
+        return self._derived[k]
+
+    def _set_derived(self, k, v):
+        if self._derived_pending is not None:
+            self._derive(k)                      # materialise the other two before one of the three is replaced
+        self._derived[k] = v
+
+    _xyz = property(lambda self: self._derive(0), lambda self, v: self._set_derived(0, v))
+    _rotation = property(lambda self: self._derive(1), lambda self, v: self._set_derived(1, v))
+    _scaling = property(lambda self: self._derive(2), lambda self, v: self._set_derived(2, v))
+
+    @property
+    def n_splats(self):
+        """Number of splats (rows of `_xyz`) without touching the derived tensors."""
+        return int(self._curve_points.shape[0]) * self.n_gaussians if self._curve_points.dim() == 3 else 0
 
     # ------------------------------------------------------------------ accessors (:66-140)
     @property
@@ -370,9 +411,10 @@ class GaussianCurveModel:
 
     def add_densification_stats(self, viewspace_point_tensor, update_filter):
         """scene/gaussian_model.py:618-620 -- consumer of means2D.grad[:, :2] (NDC-scaled, quirk 9)."""
-        if not hasattr(self, "xyz_gradient_accum") or self.xyz_gradient_accum.shape[0] != self._xyz.shape[0]:
-            self.xyz_gradient_accum = torch.zeros((self._xyz.shape[0], 1), device=self._xyz.device)
-            self.denom = torch.zeros((self._xyz.shape[0], 1), device=self._xyz.device)
+        if not hasattr(self, "xyz_gradient_accum") or self.xyz_gradient_accum.shape[0] != self.n_splats:
+            dev = self._curve_points.device
+            self.xyz_gradient_accum = torch.zeros((self.n_splats, 1), device=dev)
+            self.denom = torch.zeros((self.n_splats, 1), device=dev)
         self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1,
                                                              keepdim=True)
         self.denom[update_filter] += 1

@@ -59,6 +59,10 @@ class TrainStep:
             gaussians.optimizer = FlatAdam(named, lrs, self.flat, eps=1e-15)
             if carried is not None and carried["step"] > 0:
                 _load_optimizer_state(gaussians.optimizer, carried)
+            # this loop owns the parameter updates (optimizer step -> prepare_scaling_rot, train.py:235-243): the derived splat
+            # tensors are only computed when something reads them.  The fused render route samples inside its own kernels, so
+            # an iteration runs the grid-wide norm pass of prepare_scaling_rot once instead of twice.
+            gaussians.lazy_derived = True
             gaussians.prepare_scaling_rot()   # parameters moved into the flat buffer: rebuild the derived tensors
         self.iteration = 0
         if hasattr(gaussians, "add_topology_listener"):

@@ -18,10 +18,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _model(curves, mask=None):
+def _model(curves, mask=None, device=None):
     from curve_gaussian_amd.scene import GaussianCurveModel
-    return GaussianCurveModel(0, 12, device=DEV).create_from_curves(curves["curve_points"], curves["width"], curves["opacity"],
-                                                                    mask, curves["is_bezier"])
+    return GaussianCurveModel(0, 12, device=device or DEV).create_from_curves(curves["curve_points"], curves["width"],
+                                                                              curves["opacity"], mask, curves["is_bezier"])
 
 
 def _small(B=300, seed=5, H=96, W=128):
@@ -260,6 +260,62 @@ def test_two_models_interleave_their_fused_forwards():
         del p
     img2b, p2b = begin(gm2, cam2)
     assert VR.finish(p2b)[0] and torch.equal(img2b, ref2)
+
+
+def _render_loop(gm, cam, bg, n, out, key):
+    from curve_gaussian_amd.gaussian_renderer import PipelineParams, render
+    try:
+        with torch.cuda.device(cam.world_view_transform.device):
+            imgs = [render(cam, gm, PipelineParams(), bg)["render"].clone() for _ in range(n)]
+            torch.cuda.synchronize()
+        out[key] = imgs
+    except Exception as e:   # noqa: BLE001 -- handed to the asserting thread
+        out[key] = e
+
+
+def test_checked_forwards_of_two_threads_share_the_status_slot_pool():
+    """the readback slots (pinned words + event) are a process-wide pool; two threads that render
+    concurrently take and release slots under the pool's mutex and every image equals the one the thread renders alone."""
+    import threading
+    from curve_gaussian_amd.gaussian_renderer import PipelineParams, render
+    c1, mask1, cam1 = _small(B=150, seed=5)
+    c2, mask2, cam2 = _small(B=260, seed=6, H=64, W=80)
+    gm1, gm2 = _model(c1, mask1), _model(c2, mask2)
+    cam1, cam2 = cam1.to(DEV), cam2.to(DEV)
+    bg = torch.zeros(3, device=DEV)
+    ref1 = render(cam1, gm1, PipelineParams(), bg)["render"].clone()
+    ref2 = render(cam2, gm2, PipelineParams(), bg)["render"].clone()
+    out = {}
+    ts = [threading.Thread(target=_render_loop, args=(gm1, cam1, bg, 40, out, 1)),
+          threading.Thread(target=_render_loop, args=(gm2, cam2, bg, 40, out, 2))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for key, ref in ((1, ref1), (2, ref2)):
+        assert not isinstance(out[key], Exception), out[key]
+        assert all(torch.equal(i, ref) for i in out[key])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_checked_forwards_on_two_devices():
+    """a status slot's event belongs to the device it was created on; a checked forward on cuda:1 after one on
+    cuda:0 must not reuse cuda:0's slot (hipEventRecord rejects an event / stream pair of different devices).  The binning
+    hints are per device as well."""
+    from curve_gaussian_amd.gaussian_renderer import PipelineParams, render
+    c1, mask1, cam1 = _small(B=150, seed=5)
+    imgs = []
+    for dev in ("cuda:0", "cuda:1", "cuda:0", "cuda:1"):
+        with torch.cuda.device(dev):
+            gm = _model(c1, mask1, device=dev)
+            cam = cam1.to(dev)
+            out = render(cam, gm, PipelineParams(), torch.zeros(3, device=dev))
+            loss = out["render"].sum()
+            loss.backward()
+            torch.cuda.synchronize()
+            imgs.append(out["render"].detach().cpu())
+    assert torch.equal(imgs[0], imgs[2]) and torch.equal(imgs[1], imgs[3])
+    assert torch.allclose(imgs[0], imgs[1], atol=1e-6)
 
 
 def test_fused_route_grows_its_buckets_and_remembers_the_capacity():
