@@ -92,7 +92,7 @@ ISSUE_PEAK_G = 1024 * 2.4 / 2.0   # G wave-instructions/s: 1024 SIMDs, 2.4 GHz, 
 # gradients / what requires grad):
 #   reference_call    colours == 1 without grad, only dL/dcolour flowing in (gaussian_renderer/__init__.py:96-129) -> the gated
 #                     pair-major unit kernel
-#   training_general  the same call with the unit route switched off (cgs_set_operator_unit_route(0)) -> k_render_bwd3<0,0,0>
+#   training_general  the same call with OPT_GENERAL_BACKWARD in its settings (per-call option)    -> k_render_bwd3<0,0,0>
 #   colour_grad       arbitrary colours that require grad, dL/dcolour only                            -> k_render_bwd3<0,0,1>
 #   colour_allmap     ... + dL/dall_map                                                               -> k_render_bwd3<1,0,1>
 #   all_grad          ... + dL/dinvdepth + dL/dall_map                                                -> k_render_bwd3<1,1,1>
@@ -136,11 +136,11 @@ def time_instances(cfg="cfg3", n_rep=6, cases=CASES, dev=None):
     out = {}
     for case in cases:
         unit = case in ("reference_call", "training_general")
-        prev = lib.cgs_set_operator_unit_route(0 if case == "training_general" else 1)
+        from curve_gaussian_amd.diff_cur_rasterization import OPT_GENERAL_BACKWARD
         colors = torch.ones(P, 1, device=dev) if unit else rand_col.clone().requires_grad_(True)
         ins = {k: v.clone().requires_grad_(True) for k, v in sp.items()}
         m2d = torch.zeros(P, 3, device=dev, requires_grad=True)
-        rast = GaussianRasterizer(rs)
+        rast = GaussianRasterizer(rs._replace(options=OPT_GENERAL_BACKWARD) if case == "training_general" else rs)
 
         def once():
             color, radii, invd, amap = rast(means3D=ins["means3D"], means2D=m2d, opacities=ins["opacities"],
@@ -165,7 +165,6 @@ def time_instances(cfg="cfg3", n_rep=6, cases=CASES, dev=None):
         lib.cgs_prof_enable(0)
         prof = L.prof_collect()
         lib.cgs_prof_reset()
-        lib.cgs_set_operator_unit_route(prev)
         out[case] = {k: round(ms / max(n, 1) * 1e3, 1) for k, (ms, n) in sorted(prof.items())}
     stats = lib.cgs_last_forward_stats
     import ctypes as C
@@ -221,7 +220,7 @@ def main():
                     help="view mode: views per rank whose gradients are summed before the all-reduce (one optimizer "
                          "step's view batch per rank)")
     ap.add_argument("--fused-sort", type=int, default=-1, choices=[-1, 0, 1],
-                    help="A/B: tile sort inside the forward compositor (cgs_set_fused_tile_sort); -1 = library default")
+help="A/B: tile sort inside the forward compositor (sets CGS_FUSED_TILE_SORT, which the library reads once); -1 = library default")
     args = ap.parse_args()
 
     # Control-flow rehearsal of the multi-rank path on a box with ONE GPU (tests only): every rank uses device 0 and the
@@ -263,9 +262,9 @@ def main():
     from curve_gaussian_amd import synthetic as S
     from curve_gaussian_amd.diff_cur_rasterization import _C
     from curve_gaussian_amd.ops import curve_sampling
-    lib = L.load()
     if args.fused_sort >= 0:
-        lib.cgs_set_fused_tile_sort(args.fused_sort)
+        os.environ["CGS_FUSED_TILE_SORT"] = str(args.fused_sort)   # read once by the library, at its first forward
+    lib = L.load()
 
     # ---------------------------------------------------------------- workload (resident in HBM before timing)
     K, Wm = args.steps, args.warmup
@@ -727,17 +726,14 @@ def main():
                 stats["R"] += R_i
             # ... and the REFERENCE algorithm's instance count for the same views: every tile of the 3-sigma rect, no
             # alpha >= 1/255 tile culling (SURVEY 8d's byte formula is the reference's compulsory traffic)
-            prev_cull = lib.cgs_set_tile_culling(0)
-            try:
-                for i in range(min(n_prof, 6)):
-                    (R_i, *_rest) = _C.rasterize_gaussians(
-                        bg, xyz, colors, opac, scl, rotn, 1.0, empty, amaps[id(prof_cams[i])],
-                        prof_cams[i].world_view_transform, prof_cams[i].full_proj_transform, tanx, tany, H, W, empty,
-                        0, prof_cams[i].camera_center, False, False, True, False)
-                    stats["R_ref"] = stats.get("R_ref", 0) + R_i
-                stats["R_ref"] /= min(n_prof, 6)
-            finally:
-                lib.cgs_set_tile_culling(prev_cull)
+            from curve_gaussian_amd.diff_cur_rasterization import OPT_NO_TILE_CULLING
+            for i in range(min(n_prof, 6)):
+                (R_i, *_rest) = _C.rasterize_gaussians(
+                    bg, xyz, colors, opac, scl, rotn, 1.0, empty, amaps[id(prof_cams[i])],
+                    prof_cams[i].world_view_transform, prof_cams[i].full_proj_transform, tanx, tany, H, W, empty,
+                    0, prof_cams[i].camera_center, False, False, True, OPT_NO_TILE_CULLING)
+                stats["R_ref"] = stats.get("R_ref", 0) + R_i
+            stats["R_ref"] /= min(n_prof, 6)
         R_mean = stats["R"] / n_prof
         vis_mean = stats["visible"] / n_prof
     else:

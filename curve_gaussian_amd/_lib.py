@@ -53,9 +53,6 @@ SIGNATURES = {
     "cgs_adam_step_flat_dev": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _i, _vp, _vp]),
     "cgs_adam_step_flat_dev_report": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _i, _vp, _vp, _vp, _i, _vp]),
     "cgs_adam_state_bytes": (C.c_size_t, []),
-    "cgs_set_tile_culling": (_i, [_i]),
-    "cgs_set_fused_tile_sort": (_i, [_i]),
-    "cgs_set_operator_unit_route": (_i, [_i]),
     "cgs_reset_binning_hints": (None, []),
     "cgs_last_forward_stats": (None, [C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i)]),
     "cgs_prof_enable": (None, [_i]),

@@ -57,7 +57,6 @@ bool check_launch(const char* what, bool debug, hipStream_t s) {
     return true;
 }
 
-static std::atomic<int> g_tile_cull{1};   // exact tile-level culling of (splat, tile) instances (cgs_set_tile_culling)
 // Binning capacity hints, one set per workload shape (P, width, height): a process that alternates train and test cameras,
 // two resolutions or two models keeps a separate history for each instead of thrashing one (each mismatch used to cost a
 // bucket overflow and an exact-path redo).  Small LRU table behind a mutex; the three numbers of an entry:
@@ -166,12 +165,14 @@ static hipError_t zero_async(void* p, size_t bytes, hipStream_t s) {
 // Operator API (cgs_rasterize_forward / _backward): the forward tags its tile lists and lets the scatter raise a device word
 // when some visible splat's colour or all_map[3] is not exactly 1; a backward that needs neither colour nor depth / all_map
 // gradients then launches the pair-major unit-colour kernel AND the general training instance, and that word decides on the
-// device which of the two runs (no host sync).  cgs_set_operator_unit_route(0) keeps the general instance only (A/B, tests).
-static std::atomic<int> g_op_unit{1};
+// device which of the two runs (no host sync).  CGS_OPT_GENERAL_BACKWARD in that call's `debug` bits keeps the general instance only (A/B, tests).
 static inline bool list_tags_fit(int P) { return (long long)P < (1ll << LIST_TAG_SHIFT); }
 constexpr int NONUNIT_WORD = 8;            // index into ImageState::work (cleared with the tile histogram)
-static std::atomic<int> g_fuse_sort{1};    // tile sort inside the forward compositor (cgs_set_fused_tile_sort)
-static inline bool fuse_sort() { return g_fuse_sort.load(std::memory_order_relaxed) != 0; }
+// tile sort inside the forward compositor; CGS_FUSED_TILE_SORT=0 (read once) selects the separate sort launch for A/B runs
+static inline bool fuse_sort() {
+    static const bool on = [] { const char* e = getenv("CGS_FUSED_TILE_SORT"); return !(e && e[0] == '0'); }();
+    return on;
+}
 // Shared curve sampling for several views of ONE parameter state (cgs_view_forward_shared, CGS_VIEW_SHARED in
 // cgs_view_backward's flags): the grid-wide norm pass of the forward and the last pass of the sampling backward run once per
 // view BATCH (cgs_view_shared_begin / _end) instead of once per view -- the parameters do not change inside a batch and that
@@ -313,13 +314,6 @@ void cgs_reset_binning_hints(void) {
     std::lock_guard<std::mutex> lk(g_hint_mu);
     for (auto& e : g_hint_tab) e = HintEntry{};
 }
-int cgs_set_tile_culling(int on) {
-    return g_tile_cull.exchange(on ? 1 : 0, std::memory_order_relaxed);
-}
-int cgs_set_fused_tile_sort(int on) {
-    return g_fuse_sort.exchange(on ? 1 : 0, std::memory_order_relaxed);
-}
-int cgs_set_operator_unit_route(int on) { return g_op_unit.exchange(on ? 1 : 0, std::memory_order_relaxed); }
 void cgs_prof_enable(int on) { g_prof_on = on != 0; }
 void cgs_prof_reset(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -408,7 +402,8 @@ int64_t cgs_rasterize_forward(cgs_alloc_fn geometry_alloc, void* geometry_user, 
 
     // tile_count and tile_cursor are adjacent 128B-aligned carve-outs: clear both (+total) with one memset
     const size_t clear_bytes = (size_t)((char*)(img.total + TOTAL_WORDS) - (char*)img.tile_count);
-    const int cull = g_tile_cull.load(std::memory_order_relaxed);
+    const int cull = (debug & CGS_OPT_NO_TILE_CULLING) ? 0 : 1;   // per call (include/curvegs.h)
+    debug &= CGS_OPT_DEBUG;
     // pinned copy of img.total + the event behind it: per calling thread AND per device (an event only records on streams of
     // the device it was created on)
     constexpr int MAX_DEV = 16;
@@ -674,6 +669,8 @@ int cgs_rasterize_backward(int P, int D, int M, int64_t R, const float* backgrou
     (void)colors_precomp;
     (void)all_map;
     hipStream_t s = (hipStream_t)stream_;
+    const bool general_only = (debug & CGS_OPT_GENERAL_BACKWARD) != 0;   // per call (include/curvegs.h)
+    debug &= CGS_OPT_DEBUG;
     if (P == 0) return CGS_OK;
     if (P < 0 || width <= 0 || height <= 0 || !geometry_buffer || !binning_buffer || !image_buffer || !radii ||
         !dL_dout_color || !dL_dmean2D || !dL_dopacity || (shs && !dL_dcolor) || !dL_dmean3D || !dL_dcov3D ||
@@ -713,7 +710,7 @@ int cgs_rasterize_backward(int P, int D, int M, int64_t R, const float* backgrou
         // closed form of render_unit_bwd.hip.  The ABI receives tensors and cannot know that on the host; the scatter of the
         // forward raised img.work[NONUNIT_WORD] if any visible splat deviates, and the two kernels test that word on entry.
         const uint32_t* gate = nullptr;
-        if (tagged && !geo && !invd && !colg && g_op_unit.load(std::memory_order_relaxed)) {
+        if (tagged && !geo && !invd && !colg && !general_only) {
             gate = img.work + NONUNIT_WORD;
             launch_render_bwd_unit(s, tiles, img.ranges, bin.point_list, width, height, gx, background, geom.rec, img.final_T,
                                    img.n_contrib, dL_dout_color, geom.grad_acc, ACC_STRIDE, gate);

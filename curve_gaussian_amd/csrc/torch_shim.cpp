@@ -69,7 +69,8 @@ std::tuple<int64_t, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> rast
     const Tensor& background, const Tensor& means3D, const Tensor& colors, const Tensor& opacity, const Tensor& scales,
     const Tensor& rotations, double scale_modifier, const Tensor& cov3D_precomp, const Tensor& all_map, const Tensor& viewmatrix,
     const Tensor& projmatrix, double tan_fovx, double tan_fovy, int64_t image_height, int64_t image_width, const Tensor& sh,
-    int64_t degree, const Tensor& campos, bool prefiltered, bool antialiasing, bool render_geo, bool debug) {
+    int64_t degree, const Tensor& campos, bool prefiltered, bool antialiasing, bool render_geo, int64_t debug) {   // debug: the
+    // reference's bool, or a CGS_OPT_* bit set (include/curvegs.h) -- per-call options ride in the same argument
     if (means3D.dim() != 2 || means3D.size(1) != 3) throw std::runtime_error("means3D must have dimensions (num_points, 3)");   // :60-62
     require_gpu(means3D, "means3D");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
@@ -89,7 +90,7 @@ std::tuple<int64_t, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> rast
         alloc_cb, &geom, alloc_cb, &bin, alloc_cb, &img, P, (int)degree, M, fp(bg), W, H, fp(m3), fp(shs), fp(col), fp(op), fp(sc),
         (float)scale_modifier, fp(rot), fp(cov), fp(am), fp(vm), fp(pm), fp(cp), (float)tan_fovx, (float)tan_fovy, prefiltered ? 1 : 0,
         out_color.data_ptr<float>(), out_invdepth.data_ptr<float>(), out_all_map.data_ptr<float>(), antialiasing ? 1 : 0,
-        render_geo ? 1 : 0, P > 0 ? radii.data_ptr<int>() : nullptr, debug ? 1 : 0, stream_of(m3)), "cgs_rasterize_forward");
+        render_geo ? 1 : 0, P > 0 ? radii.data_ptr<int>() : nullptr, (int)debug, stream_of(m3)), "cgs_rasterize_forward");
     const Tensor empty = at::empty({0}, m3.options().dtype(at::kByte));
     return {rendered, out_color, radii, geom.t.defined() ? geom.t : empty, bin.t.defined() ? bin.t : empty,
             img.t.defined() ? img.t : empty, out_invdepth, out_all_map};
@@ -142,7 +143,7 @@ std::tuple<Tensor, c10::optional<Tensor>, Tensor, Tensor, Tensor, Tensor, Tensor
     const Tensor& cov3D_precomp, const Tensor& viewmatrix, const Tensor& projmatrix, double tan_fovx, double tan_fovy,
     const Tensor& dL_dout_color, const Tensor& dL_dout_invdepth, const Tensor& dL_dout_all_map, const Tensor& sh, int64_t degree,
     const Tensor& campos, const Tensor& geomBuffer, int64_t R, const Tensor& binningBuffer, const Tensor& imageBuffer,
-    bool antialiasing, bool render_geo, bool debug, bool need_color_grad) {
+    bool antialiasing, bool render_geo, int64_t debug, bool need_color_grad) {
     require_gpu(means3D, "means3D");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
     const int64_t P = means3D.size(0);
@@ -182,7 +183,7 @@ std::tuple<Tensor, c10::optional<Tensor>, Tensor, Tensor, Tensor, Tensor, Tensor
             has_invd ? fp(g_inv) : nullptr, fp(g_map), fpm(dL_dmeans2D), fpm(dL_dconic), fpm(dL_dopacity),
             want_col ? fpm(dL_dcolors) : nullptr, has_invd ? fpm(dL_dinvdepths) : nullptr, fpm(dL_dmeans3D), fpm(dL_dcov3D),
             M > 0 ? fpm(dL_dsh) : nullptr, has_scales ? fpm(dL_dscales) : nullptr, has_scales ? fpm(dL_drotations) : nullptr,
-            fpm(dL_dall_map), antialiasing ? 1 : 0, render_geo ? 1 : 0, debug ? 1 : 0, stream_of(m3)), "cgs_rasterize_backward");
+            fpm(dL_dall_map), antialiasing ? 1 : 0, render_geo ? 1 : 0, (int)debug, stream_of(m3)), "cgs_rasterize_backward");
     // need_color_grad=False (extension, training configuration): the colour gradient is not computed -> None
     return {dL_dmeans2D, want_col ? c10::optional<Tensor>(dL_dcolors) : c10::nullopt, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
             dL_dscales, dL_drotations, dL_dall_map};

@@ -30,6 +30,17 @@ def _f32c(t, name):
     return t
 
 
+# Per-call options of the operator API (include/curvegs.h, CGS_OPT_*): they ride in the `debug` argument of the reference's
+# signatures -- bit 0 is the reference's bool -- via GaussianRasterizationSettings.options.  Nothing process-wide.
+OPT_NO_TILE_CULLING = 0x100    # forward: bin every tile of the 3-sigma rect like the reference (num_rendered, lists bit-identical)
+OPT_GENERAL_BACKWARD = 0x200   # backward: never the unit-colour kernel
+
+
+def _dbg(debug):
+    """bool (the reference's flag) or an int bit set -> the C ABI's int."""
+    return int(debug) if isinstance(debug, int) and not isinstance(debug, bool) else int(bool(debug))
+
+
 class _Ext:
     """Stand-in for the pybind module ``diff_cur_rasterization._C`` (reference ext.cpp:15-19)."""
 
@@ -72,7 +83,7 @@ class _Ext:
                 L.ptr(rotations), L.ptr(cov3D_precomp), L.ptr(all_map), L.ptr(viewmatrix), L.ptr(projmatrix),
                 L.ptr(campos), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), L.ptr(out_color),
                 L.ptr(out_invdepth), L.ptr(out_all_map), int(bool(antialiasing)), int(bool(render_geo)),
-                L.ptr(radii) if P > 0 else None, int(bool(debug)), stream)
+                L.ptr(radii) if P > 0 else None, _dbg(debug), stream)
             L.check(rendered, "cgs_rasterize_forward")
             empty = torch.empty((0,), dtype=torch.uint8, device=dev)
         return (int(rendered), out_color, radii, bufs.get("geom", empty), bufs.get("bin", empty),
@@ -189,7 +200,7 @@ class _Ext:
                     L.ptr(dL_dinvdepths) if has_invd else None, L.ptr(dL_dmeans3D), L.ptr(dL_dcov3D),
                     L.ptr(dL_dsh) if M > 0 else None, L.ptr(dL_dscales) if has_scales else None,
                     L.ptr(dL_drotations) if has_scales else None, L.ptr(dL_dall_map), int(bool(antialiasing)),
-                    int(bool(render_geo)), int(bool(debug)), stream)
+                    int(bool(render_geo)), _dbg(debug), stream)
                 L.check(rc, "cgs_rasterize_backward")
         # need_color_grad=False (extension, training configuration): the colour gradient is not computed -> None
         return (dL_dmeans2D, dL_dcolors if want_col else None, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
@@ -240,7 +251,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = raster_settings
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 all_maps, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
-                rs.sh_degree, rs.campos, rs.prefiltered, rs.antialiasing, rs.render_geo, rs.debug)
+                rs.sh_degree, rs.campos, rs.prefiltered, rs.antialiasing, rs.render_geo,
+                _dbg(rs.debug) | int(getattr(rs, "options", 0)))
         cap = getattr(rs, "static_bucket_cap", 0)
         if cap:   # extension: sync-free forward with caller-chosen bucket capacity (stream-ordered / graph capture)
             num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, invdepths, out_all_map = \
@@ -274,7 +286,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
                 grad_out_color, grad_out_depth if grad_out_depth is not None else empty,
                 grad_out_all_map if grad_out_all_map is not None else empty, sh, rs.sh_degree, rs.campos, geomBuffer,
-                ctx.num_rendered, binningBuffer, imgBuffer, rs.antialiasing, rs.render_geo, rs.debug)
+                ctx.num_rendered, binningBuffer, imgBuffer, rs.antialiasing, rs.render_geo,
+                _dbg(rs.debug) | int(getattr(rs, "options", 0)))
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations, grad_all_map) = _C.rasterize_gaussians_backward(*args, need_color_grad=ctx.needs_input_grad[3])
         grads = (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
@@ -303,6 +316,8 @@ class GaussianRasterizationSettings(NamedTuple):
     # (cgs_rasterize_forward_static) with that many slots per tile; its status-word tensor is appended to status_sink
     static_bucket_cap: int = 0
     status_sink: object = None
+    # per-call option bits (OPT_NO_TILE_CULLING | OPT_GENERAL_BACKWARD): parity tests and A/B measurements
+    options: int = 0
 
 
 class GaussianRasterizer(nn.Module):

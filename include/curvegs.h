@@ -400,26 +400,32 @@ size_t cgs_knn_workspace_bytes(int P);
 int cgs_knn_mean_dist2(int P, const float* points /*[P,3]*/, float* mean_dist2 /*[P]*/, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Tile-level culling switch (process-wide, default on).  The reference bins a splat into EVERY tile of the
+ * Per-call options of the operator API.  The `debug` argument of cgs_rasterize_forward / cgs_rasterize_backward is a bit
+ * set: bit 0 is the reference's debug flag (rasterize_points.cu:53: synchronise and check after every kernel), the bits
+ * below select measurement / parity variants FOR THAT CALL ONLY -- nothing process-wide, nothing another thread's call
+ * can see (rounds 1-5 had cgs_set_tile_culling / cgs_set_fused_tile_sort / cgs_set_operator_unit_route here).
+ * ------------------------------------------------------------------------------------------------ */
+#define CGS_OPT_DEBUG 0x1
+#define CGS_OPT_NO_TILE_CULLING 0x100   /* cgs_rasterize_forward: bin like the reference (below) */
+#define CGS_OPT_GENERAL_BACKWARD 0x200  /* cgs_rasterize_backward: never the unit-colour kernel (below) */
+/* Tile-level culling (default on; CGS_OPT_NO_TILE_CULLING switches it off for one forward).  The reference bins a splat into EVERY tile of the
  * bounding square of radius ceil(3 sigma) (forward.cu:318-321 getRect, rasterizer_impl.cu:70-110) and lets the
  * compositor skip it per pixel when alpha < 1/255 (forward.cu:371-377).  With culling on, an instance
  * (splat, tile) is only created when the splat can reach alpha >= 1/255 at some pixel of that tile, so
  * num_rendered is smaller than the reference's while images, radii and every gradient are unchanged (the
  * dropped instances are exactly those the compositor would skip at all 256 pixels).  With culling off,
- * num_rendered and the per-tile lists are bit-identical to the reference's.  Returns the previous setting.
+ * num_rendered and the per-tile lists are bit-identical to the reference's.
+ *
+ * Unit-colour route of the backward (default on; CGS_OPT_GENERAL_BACKWARD keeps the general instance for one backward): a
+ * cgs_rasterize_backward that is asked for neither colour nor depth / all_map gradients (the training configuration of the
+ * reference's own call, gaussian_renderer/__init__.py:96-129) lets the GPU choose between the pair-major unit-colour compositor
+ * and the general one: the forward's scatter raises a word of the image buffer when some visible splat's colour or all_map[3]
+ * is not exactly 1, and both kernels test it on entry (no host sync; the forward tags its tile-list entries with quadrant
+ * masks whenever P < 2^28).
+ *
+ * The tile sort inside the forward compositor (sync-free forwards whose bucket capacity allows it) has a read-once environment
+ * switch for A/B measurements: CGS_FUSED_TILE_SORT=0 -> separate per-tile sort launch.
  * ------------------------------------------------------------------------------------------------ */
-int cgs_set_tile_culling(int on);
-/* A/B switches for measurements (process-wide; each returns the previous setting).
- *   cgs_set_fused_tile_sort: 1 (default) = the sync-free forward sorts each tile's bucket inside the compositor kernel when the
- *     bucket capacity allows; 0 = separate per-tile sort launch.
- */
-int cgs_set_fused_tile_sort(int on);
-/*   cgs_set_operator_unit_route: 1 (default) = a cgs_rasterize_backward that is asked for neither colour nor depth / all_map
- *     gradients (the training configuration of the reference's own call, gaussian_renderer/__init__.py:96-129) lets the GPU choose
- *     between the pair-major unit-colour compositor and the general one: the forward's scatter raises a word of the image buffer
- *     when some visible splat's colour or all_map[3] is not exactly 1, and both kernels test it on entry (no host sync; the
- *     forward tags its tile-list entries with quadrant masks whenever P < 2^28).  0 = always the general instance. */
-int cgs_set_operator_unit_route(int on);
 /* Introspection of the calling thread's last cgs_rasterize_forward: num_rendered, the longest per-tile list and
  * which binning path produced it (0 = exact count/scan/scatter layout, 1 = single-pass fixed-capacity buckets). */
 /* ------------------------------------------------------------------------------------------------

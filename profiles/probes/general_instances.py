@@ -6,7 +6,7 @@ diff_cur_rasterization/__init__.py:46-151), per BASELINE config, measured with t
 Cases (upstream gradients / what requires grad):
     reference_call    colours == 1 without grad, only dL/dcolour flowing in (gaussian_renderer/__init__.py:96-129) -> the gated
                       pair-major unit kernel
-    training_general  the same call with the unit route switched off (cgs_set_operator_unit_route(0)) -> k_render_bwd3<0,0,0>
+    training_general  the same call with the unit route switched off (OPT_GENERAL_BACKWARD in the settings) -> k_render_bwd3<0,0,0>
     colour_grad       arbitrary colours that require grad, dL/dcolour only                            -> k_render_bwd3<0,0,1>
     colour_allmap     ... + dL/dall_map                                                               -> k_render_bwd3<1,0,1>
     all_grad          ... + dL/dinvdepth + dL/dall_map                                                -> k_render_bwd3<1,1,1>

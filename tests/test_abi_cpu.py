@@ -56,8 +56,8 @@ def test_rasterizer_argument_checks_match_reference():
     # the reference's 14 fields in the reference's order (:153-167), then the optional extensions with defaults
     assert fields[:14] == ("image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix",
                            "projmatrix", "sh_degree", "campos", "prefiltered", "debug", "antialiasing", "render_geo")
-    assert fields[14:] == ("static_bucket_cap", "status_sink")
-    assert GaussianRasterizationSettings._field_defaults == {"static_bucket_cap": 0, "status_sink": None}
+    assert fields[14:] == ("static_bucket_cap", "status_sink", "options")
+    assert GaussianRasterizationSettings._field_defaults == {"static_bucket_cap": 0, "status_sink": None, "options": 0}
     rs = GaussianRasterizationSettings(8, 8, 0.3, 0.3, torch.zeros(3), 1.0, torch.eye(4), torch.eye(4), 0,
                                        torch.zeros(3), False, False, False, True)
     r = GaussianRasterizer(rs)

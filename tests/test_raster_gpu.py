@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 import torch
 
+import util
 from util import (ORA, S, assert_close, carve_offsets, hip_settings, near_threshold_pairs, oracle_forward)
 
 pytestmark = pytest.mark.gpu
@@ -175,10 +176,10 @@ def test_training_configuration_only_colour_grad():
 
 @pytest.fixture
 def general_backward_only():
-    from curve_gaussian_amd import _lib
-    prev = _lib.load().cgs_set_operator_unit_route(0)
+    from curve_gaussian_amd.diff_cur_rasterization import OPT_GENERAL_BACKWARD
+    prev, util.OPTIONS[0] = util.OPTIONS[0], util.OPTIONS[0] | OPT_GENERAL_BACKWARD
     yield
-    _lib.load().cgs_set_operator_unit_route(prev)
+    util.OPTIONS[0] = prev
 
 
 def _reference_call_splats(P, seed, H, W):
@@ -201,12 +202,12 @@ def test_operator_api_reaches_the_unit_backward_on_the_reference_call(P, H, W, s
     bg = torch.tensor([bg0, 0.0, 0.0])
     grads = rand_grads(H, W, seed + 5, (True, False, False))
     hip = compare(sp, cam, bg, grads, colour_grad=False, debug=False)
-    from curve_gaussian_amd import _lib
-    prev = _lib.load().cgs_set_operator_unit_route(0)
+    from curve_gaussian_amd.diff_cur_rasterization import OPT_GENERAL_BACKWARD
+    prev, util.OPTIONS[0] = util.OPTIONS[0], util.OPTIONS[0] | OPT_GENERAL_BACKWARD   # per call: rides in the settings
     try:
         gen = run_hip(sp, cam, bg, grads, colour_grad=False, debug=False)
     finally:
-        _lib.load().cgs_set_operator_unit_route(prev)
+        util.OPTIONS[0] = prev
     for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dscales", "dL_drotations"):
         assert_close("unit vs general " + k, hip["g"][k], gen["g"][k], abs_floor=1e-6)
     assert np.abs(hip["g"]["dL_dall_map"]).max() == 0.0
@@ -366,10 +367,10 @@ def _binning_case(case):
 
 @pytest.fixture
 def no_tile_culling():
-    from curve_gaussian_amd import _lib
-    prev = _lib.load().cgs_set_tile_culling(0)
+    from curve_gaussian_amd.diff_cur_rasterization import OPT_NO_TILE_CULLING
+    prev, util.OPTIONS[0] = util.OPTIONS[0], util.OPTIONS[0] | OPT_NO_TILE_CULLING
     yield
-    _lib.load().cgs_set_tile_culling(prev)
+    util.OPTIONS[0] = prev
 
 
 def _raster_raw(sp, cam, H, W, dev, reset_hints=False):
@@ -382,14 +383,14 @@ def _raster_raw(sp, cam, H, W, dev, reset_hints=False):
     empty = torch.empty(0, device=dev)
     out = _C.rasterize_gaussians(
         rs.bg, d["means3D"], d["colors"], d["opacities"], d["scales"], d["rotations"], 1.0, empty, d["all_map"],
-        rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, empty, 0, rs.campos, False, False, True, False)
+        rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, empty, 0, rs.campos, False, False, True, int(util.OPTIONS[0]))
     torch.cuda.synchronize()
     return out
 
 
 @pytest.mark.parametrize("case", ["ties", "ties_mid", "oversized_bucket", "screen_filling", "elongated"])
 def test_tile_culling_drops_only_invisible_instances(case):
-    """Default mode (cgs_set_tile_culling(1)): every tile list is a SUBSEQUENCE of the reference's stable-sorted list
+    """Default mode (tile culling on): every tile list is a SUBSEQUENCE of the reference's stable-sorted list
     (same relative order), every dropped (splat, tile) instance stays below alpha 1/255 at all 256 pixels of its tile
     (checked in float64 from the oracle's conics), and the image is unchanged."""
     dev = torch.device(DEV)

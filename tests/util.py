@@ -26,6 +26,11 @@ def oracle_forward(sp, cam, bg, render_geo=True, antialiasing=False, scale_modif
                        antialiasing=antialiasing, render_geo=render_geo)
 
 
+# per-call option bits (curve_gaussian_amd.diff_cur_rasterization.OPT_*) the helpers below put into every settings object they
+# build: fixtures set them for one test (the library has no process-wide switches)
+OPTIONS = [0]
+
+
 def hip_settings(cam, bg, dev, render_geo=True, antialiasing=False, scale_modifier=1.0, degree=0, debug=False):
     from curve_gaussian_amd.diff_cur_rasterization import GaussianRasterizationSettings
     tfx, tfy = tanfov(cam)
@@ -34,7 +39,7 @@ def hip_settings(cam, bg, dev, render_geo=True, antialiasing=False, scale_modifi
         image_height=cam.image_height, image_width=cam.image_width, tanfovx=tfx, tanfovy=tfy, bg=bg.to(dev),
         scale_modifier=scale_modifier, viewmatrix=c.world_view_transform, projmatrix=c.full_proj_transform,
         sh_degree=degree, campos=c.camera_center, prefiltered=False, debug=debug, antialiasing=antialiasing,
-        render_geo=render_geo)
+        render_geo=render_geo, options=OPTIONS[0])
 
 
 def close_frac(a, b, rel=REL_TOL, abs_floor=None):
