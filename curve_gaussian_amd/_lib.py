@@ -45,6 +45,7 @@ SIGNATURES = {
     "cgs_view_shared_begin": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cgs_view_shared_end": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _vp]),
     "cgs_view_backward_scratch_floats": (C.c_size_t, [_i, _i]),
+    "cgs_view_norms_backward_range": (_i, [C.POINTER(_i), C.POINTER(_i)]),
     "cgs_view_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp,
                                _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "cgs_image_status_offset": (C.c_size_t, [_i, _i]),
@@ -120,7 +121,12 @@ def use_shim() -> bool:
     """The compiled torch <-> C-ABI host shim (csrc/torch_shim.cpp) is the default binding of the operator API and of the fused
     view route; CGS_TORCH_SHIM=0 selects the ctypes bindings instead (A/B measurements of the host floor).  Same library, same
     kernels either way."""
-    return os.environ.get("CGS_TORCH_SHIM", "1") != "0"
+    if os.environ.get("CGS_TORCH_SHIM", "1") == "0":
+        return False
+    # _cgs_torch.so is linked against $ORIGIN/libcurvegs.so: with CGS_LIB pointing at an experiment build it would run the
+    # DEFAULT kernels (and hand out handles of another library instance) while ctypes drives the experiment -- an A/B run
+    # must use one library, so an overridden CGS_LIB selects the ctypes bindings (ADVICE r5)
+    return os.path.realpath(LIB_PATH) == os.path.realpath(os.path.join(_HERE, "libcurvegs.so"))
 
 
 def shim():
@@ -128,7 +134,7 @@ def shim():
     global _shim
     if _shim is not None:
         return _shim
-    load()   # libcurvegs.so first, through the path CGS_LIB may override: the shim binds to that same library instance
+    load()   # libcurvegs.so first (use_shim() is False when CGS_LIB names another build: the shim binds $ORIGIN/libcurvegs.so)
     if not os.path.exists(SHIM_PATH):
         raise CurveGSError(
             f"{SHIM_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -1020,6 +1020,11 @@ uint32_t cgs_bucket_capacity_hint(int P, int width, int height) {
     return (uint32_t)std::min<uint64_t>(cap, bucket_cap_limit());
 }
 
+int cgs_view_norms_backward_range(int* first, int* count) {
+    if (first) *first = sample_norm_fwd_words();
+    if (count) *count = sample_norm_words() - sample_norm_fwd_words();
+    return 384;
+}
 size_t cgs_view_backward_scratch_floats(int B, int m) { return (size_t)(B > 0 ? B : 0) * (size_t)(m > 0 ? m : 0) * 15; }
 
 }  // extern "C"

@@ -60,7 +60,8 @@ def _grad_sinks(pc, use_mask):
         return None
     for p in ps:
         g = p.grad
-        if not p.requires_grad or g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape:
+        if (not p.requires_grad or g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape
+                or g.device != p.device or g.data_ptr() % 16):   # (the kernels write 16-byte rows: a misaligned view cannot serve)
             return None
     return [p.grad for p in ps]
 

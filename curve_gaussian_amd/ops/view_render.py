@@ -40,6 +40,18 @@ class Pending:
             self.handle = None
 
 
+_NORMS_RANGE = []
+
+
+def _norms_backward_range():
+    """(first, count) of the f64 words of `norms` the sampling backward accumulates into -- asked of the library once."""
+    if not _NORMS_RANGE:
+        a, b = C.c_int(0), C.c_int(0)
+        L.load().cgs_view_norms_backward_range(C.byref(a), C.byref(b))
+        _NORMS_RANGE.extend((int(a.value), int(b.value)))
+    return _NORMS_RANGE[0], _NORMS_RANGE[1]
+
+
 def _capacity(lib, dev, P, W, H):
     with _caps_mu:
         cap = _caps.get((dev.index, P, W, H), 0)
@@ -60,6 +72,7 @@ class _ViewRender(torch.autograd.Function):
                 static_cap=0, status_sink=None, clamp=False, want_dir=False, pending_out=None, eps=1e-8, grad_sinks=None):
         L.require_gpu_tensor(curve_points, "curve_points")
         ctx.sinks = grad_sinks
+        ctx.sink_owners = ((curve_points, width, opacity_logit) + ((mask_logit,) if mask_logit is not None else ())) if grad_sinks else None
         L.require_gpu_tensor(bg, "bg_color")                       # "Background tensor (bg_color) must be on GPU!" (:23)
         L.require_gpu_tensor(cam.world_view_transform, "viewpoint_camera.world_view_transform")
         lib = L.load()
@@ -191,13 +204,23 @@ class _ViewRender(torch.autograd.Function):
         if getattr(ctx, "ran_backward", False):
             # a second backward over this forward (retain_graph): the two grid-wide sums of the sampling backward were cleared
             # by the forward's norm pass once (include/curvegs.h: one view backward per view forward) -- clear them again
-            norms[192:320].zero_()
-        ctx.ran_backward = True
+            first, count = _norms_backward_range()
+            norms[first:first + count].zero_()
+        sinks = ctx.sinks
+        if sinks is not None:
+            # the sinks are the `.grad` tensors the parameters had at FORWARD time: if one was replaced since (zero_grad(
+            # set_to_none=True), a rebound flat buffer, a topology edit) the kernels would add into an orphan -- hand the
+            # gradients to autograd the ordinary way instead
+            owners = getattr(ctx, "sink_owners", None)
+            if owners is None or any(p.grad is not s for p, s in zip(owners, sinks)):
+                sinks = None
         if L.use_shim():   # clamp gradient + cgs_view_backward in one call (csrc/torch_shim.cpp::view_backward)
-            # (ctx.sinks: the kernels add the curve-level gradients to the caller's buffers; None comes back for those inputs)
-            return tuple(L.shim().view_backward(cp, w, ol, mkp, ctx.isb, ctx.coef, geom, binb, img, radii, norms, bgc, view, proj,
-                                                campos, m, mask_thr, tanx, tany, H, W, eps, g_color, ctx.raw,
-                                                ctx.sinks)) + (None,) * 14
+            # (sinks: the kernels add the curve-level gradients to the caller's buffers; None comes back for those inputs)
+            out = tuple(L.shim().view_backward(cp, w, ol, mkp, ctx.isb, ctx.coef, geom, binb, img, radii, norms, bgc, view, proj,
+                                               campos, m, mask_thr, tanx, tany, H, W, eps, g_color, ctx.raw, sinks)) + (None,) * 14
+            ctx.ran_backward = True
+            return out
+        ctx.ran_backward = True   # (ctypes bindings: the kernels below are queued before anything can raise)
         with L.device_guard(dev):
             f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
             g_cp, g_w, g_ol, g_m2d = f32(B, 4, 3), f32(B, 1), f32(B, 1), f32(P, 3)

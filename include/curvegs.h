@@ -234,6 +234,10 @@ int cgs_view_shared_end(int B, int m, const float* curve_points, const float* wi
                         float eps, double* norms, float* scratch, float* dL_dcurve_points, float* dL_dwidth, int accumulate,
                         void* stream);
 size_t cgs_view_backward_scratch_floats(int B, int m);
+/* Layout of the `norms` buffer (f64 words): [0, *first) are the forward's grid-wide sums (written by the norm pass),
+ * [*first, *first + *count) the two sums the sampling backward ACCUMULATES -- cleared by the forward's norm pass, so a caller that
+ * runs a second backward over one forward (retain_graph) zeroes exactly this range in between.  Returns the buffer's size in words. */
+int cgs_view_norms_backward_range(int* first, int* count);
 /* flags of cgs_view_backward (a plain 0 / 1 keeps its old meaning: overwrite / accumulate) */
 #define CGS_VIEW_ACCUMULATE 1 /* add to dL_dcurve_points, dL_dwidth, dL_dopacity_logit, dL_dmask_logit instead of writing them */
 #define CGS_VIEW_SHARED 2     /* shared curve sampling of a view batch (above): per-splat gradients go to `scratch` only */

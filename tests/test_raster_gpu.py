@@ -469,7 +469,7 @@ def test_binning_bit_exact(case, no_tile_culling):
     empty = torch.empty(0, device=dev)
     (R, color, radii, geomB, binB, imgB, invd, amap) = _C.rasterize_gaussians(
         rs.bg, d["means3D"], d["colors"], d["opacities"], d["scales"], d["rotations"], 1.0, empty, d["all_map"],
-        rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, empty, 0, rs.campos, False, False, True, True)
+        rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, empty, 0, rs.campos, False, False, True, 1 | int(util.OPTIONS[0]))
     torch.cuda.synchronize()
     assert R == fw.num_rendered
     ranges, point_list, n_contrib, final_T = _decode_state(geomB, binB, imgB, P, H, W, R)

@@ -173,6 +173,33 @@ def test_grad_sinks_put_the_same_gradients_into_existing_grad_buffers(use_mask):
         assert gm._mask.grad is None or float(gm._mask.grad.abs().max()) == 0.0
 
 
+def test_grad_sinks_replaced_between_forward_and_backward_fall_back_to_autograd():
+    """the sinks are the `.grad` tensors of FORWARD time.  zero_grad(set_to_none=True) (or a rebound flat buffer)
+    between forward and backward must not make the kernels add into an orphaned tensor: the node then returns its gradients and
+    autograd accumulates them into whatever `.grad` is current."""
+    from curve_gaussian_amd.gaussian_renderer import PipelineParams, render
+    c, mask, cam = _small()
+    cam = cam.to(DEV)
+    bg = torch.zeros(3, device=DEV)
+    dimg = torch.randn(1, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(3)).to(DEV)
+    names = ["_curve_points", "_width", "_opacity"]
+    ref = _model(c, mask)
+    (render(cam, ref, PipelineParams(), bg)["render"] * dimg).sum().backward()
+    gm = _model(c, mask)
+    orphans = {}
+    for n in names:
+        p = getattr(gm, n)
+        p.grad = torch.zeros_like(p)
+        orphans[n] = p.grad
+    pkg = render(cam, gm, PipelineParams(), bg, grad_sinks=True)
+    for n in names:
+        getattr(gm, n).grad = None                     # zero_grad(set_to_none=True)
+    (pkg["render"] * dimg).sum().backward()
+    for n in names:
+        assert float(orphans[n].abs().max()) == 0.0, n            # nothing was added behind the caller's back
+        assert_close(n, getattr(gm, n).grad.cpu(), getattr(ref, n).grad.cpu(), rel=2e-4)
+
+
 def test_fused_route_backward_twice_over_one_forward():
     """retain_graph + two backwards through one fused render(): the second one gives the same gradients again (the grid-wide
     sums of the sampling backward are cleared by the forward once and by the node before any further backward)."""
