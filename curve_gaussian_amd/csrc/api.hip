@@ -1025,7 +1025,8 @@ int cgs_view_norms_backward_range(int* first, int* count) {
     if (count) *count = sample_norm_words() - sample_norm_fwd_words();
     return 384;
 }
-size_t cgs_view_backward_scratch_floats(int B, int m) { return (size_t)(B > 0 ? B : 0) * (size_t)(m > 0 ? m : 0) * 15; }
+// 13 floats per curve are used (16 asked for: the size stays a multiple of 64 bytes); rounds 2-5: 15 per splat
+size_t cgs_view_backward_scratch_floats(int B, int m) { (void)m; return (size_t)(B > 0 ? B : 0) * 16; }
 
 }  // extern "C"
 static int view_backward_impl(int B, int m, const float* curve_points, const float* width, const uint8_t* is_bezier, const float* coef,
@@ -1061,9 +1062,8 @@ static int view_backward_impl(int B, int m, const float* curve_points, const flo
     GeomState geom = geom_from_chunk(gchunk, (size_t)P);
     BinState bin = bin_from_chunk(bchunk, 1);
     ImageState img = image_from_chunk(ichunk, npix, (size_t)tiles);
-    float* gv = scratch;                       // [P,9] dL/d{v0,v1,v2}
-    float* g_xyz = scratch + (size_t)P * 9;    // [P,3]
-    float* g_scl = scratch + (size_t)P * 12;   // [P,3]
+    // scratch: [B,13] per-curve partials of dL/d{curve_points, width} (k_view_bwd -> k_sample_bwd_close; curve_math.h,
+    // sample_backward_tail).  Rounds 2-5 sent 15 floats per SPLAT through here.
     // training configuration: only dL/dcolour flows in, the colours themselves need no gradient; the forward wrote unit
     // colours unless it was given colors_precomp (same argument here): closed-form dL/dalpha, no recurrences (render.hip, UNIT)
     if (colors_precomp == nullptr)
@@ -1074,11 +1074,11 @@ static int view_backward_impl(int B, int m, const float* curve_points, const flo
                           img.final_T, img.n_contrib, dL_dout_color, nullptr, nullptr, geom.grad_acc, ACC_STRIDE_VIEW);
     launch_view_backward(s, B, m, curve_points, width, is_bezier, coef, eps, norms, opacity_logit, mask_logit, mask_thr,
                          cam_pos, viewmatrix, projmatrix, tan_fovx, tan_fovy, focal_x, focal_y, width_px, height_px, radii,
-                         geom.rec, geom.grad_acc, dL_drotation_extra, dL_dmeans2D, dL_dopacity_logit, dL_dmask_logit, g_xyz,
-                         g_scl, gv, ((flags & CGS_VIEW_ACCUMULATE) ? 1 : 0) | ((flags & CGS_VIEW_SHARED) ? 2 : 0));
+                         geom.rec, geom.grad_acc, dL_drotation_extra, dL_dmeans2D, dL_dopacity_logit, dL_dmask_logit, scratch,
+                         ((flags & CGS_VIEW_ACCUMULATE) ? 1 : 0) | ((flags & CGS_VIEW_SHARED) ? 2 : 0));
     if (!(flags & CGS_VIEW_SHARED))
-        launch_sample_backward_pass3(s, B, m, curve_points, width, is_bezier, coef, eps, norms, g_xyz, gv, g_scl,
-                                     dL_dcurve_points, dL_dwidth, gv, (flags & CGS_VIEW_ACCUMULATE) ? 1 : 0);
+        launch_sample_backward_close(s, B, m, curve_points, width, is_bezier, coef, eps, norms, scratch, dL_dcurve_points,
+                                     dL_dwidth, (flags & CGS_VIEW_ACCUMULATE) ? 1 : 0);
     if (!check_launch("view_backward", false, s)) return CGS_ERR_HIP;
     return CGS_OK;
 }
@@ -1134,12 +1134,8 @@ int cgs_view_shared_end(int B, int m, const float* curve_points, const float* wi
         set_error("cgs_view_shared_end: invalid argument");
         return CGS_ERR_INVALID_ARGUMENT;
     }
-    const int P = B * m;
-    float* gv = scratch;
-    float* g_xyz = scratch + (size_t)P * 9;
-    float* g_scl = scratch + (size_t)P * 12;
-    launch_sample_backward_pass3(s, B, m, curve_points, width, is_bezier, coef, eps, norms, g_xyz, gv, g_scl, dL_dcurve_points,
-                                 dL_dwidth, gv, accumulate);
+    launch_sample_backward_close(s, B, m, curve_points, width, is_bezier, coef, eps, norms, scratch, dL_dcurve_points, dL_dwidth,
+                                 accumulate);
     if (!check_launch("view_shared_end", false, s)) return CGS_ERR_HIP;
     return CGS_OK;
 }

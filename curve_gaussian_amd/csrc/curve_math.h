@@ -207,6 +207,78 @@ __device__ __forceinline__ void rot_matrix(const SampleFwd& s, float M[3][3]) { 
     M[2][0] = s.v0.z; M[2][1] = s.v1.z; M[2][2] = s.v2.z;
 }
 
+// Tail of the sampling backward for ONE sample: from dL/d{v0, v1, v2} (columns of the rotation), dL/dxyz and dL/dscaling to
+// this sample's contribution to dL/d{p0..p3} and dL/dwidth (reference: autograd of scene/gaussian_curve_model.py:180-198).
+// D2 = sum_all <g_v2, c2v> and D1 (stage_consts) are the two grid-wide sums the global Frobenius norms bring in.  The map is
+// LINEAR in (g_v0, g_v1, g_v2, g_x, g_scaling, D2, D1) with forward-only coefficients, so
+//     tail(g, D2, D1) = tail(g, 0, 0) + tail(0, D2, D1):
+// the fused view backward evaluates the first term per sample and keeps only its per-CURVE sum (13 floats per curve instead of
+// 15 per splat through HBM); the closing pass evaluates the second from the curve alone and adds the two.
+struct CurveGrad { V3 gp0, gp1, gp2, gp3; float gw; };
+__device__ __forceinline__ CurveGrad sample_backward_tail(const CurveCP& c, const SampleCoef& k, const SampleFwd& s, float w, float eps,
+                                                          float N1, float N2, float D2, float D1, V3 g_v0, V3 g_v1, V3 g_v2, V3 g_x,
+                                                          bool has_scaling, V3 g_scl) {
+    CurveGrad o;
+    o.gp0 = o.gp1 = o.gp2 = o.gp3 = V3{0.f, 0.f, 0.f};
+    o.gw = 0.f;
+    const float iN2 = 1.f / N2;
+    const V3 g_c2v = iN2 * g_v2 - (D2 * iN2 * iN2 * iN2) * s.c2v;
+    // c2v = cross(tan, v1)
+    V3 g_tan = cross(s.v1, g_c2v);
+    const V3 g_v1t = g_v1 + cross(g_c2v, s.tan);
+    const float iN1 = 1.f / N1;
+    const V3 g_c1v = iN1 * g_v1t - (D1 * iN1 * iN1 * iN1) * s.c1v;
+    g_tan.y += g_c1v.x;  // c1v = (ty, -tx, 0)
+    g_tan.x -= g_c1v.y;
+    if (s.n > 0.f) {     // v0 = tan / (n + eps)
+        const float ne = s.n + eps;
+        const float coefv = dot(g_v0, s.tan) / (s.n * ne * ne);
+        g_tan = g_tan + (1.f / ne) * g_v0 - coefv * s.tan;
+    } else {
+        g_tan = g_tan + (1.f / eps) * g_v0;
+    }
+    // scaling = (dist, exp(w), exp(w))
+    V3 g_front = {0, 0, 0};
+    if (has_scaling) {
+        const float gd = g_scl.x;
+        o.gw = (g_scl.y + g_scl.z) * w;
+        if (s.dist > 0.f) {
+            const V3 gdv = (gd / s.dist) * s.dvec;
+            g_x = g_x + gdv;
+            g_front = {-gdv.x, -gdv.y, -gdv.z};
+        }
+    }
+    if (c.bez) {
+        o.gp0 = k.c[0] * g_x + k.cf[0] * g_front - k.d[0] * g_tan;
+        o.gp1 = k.c[1] * g_x + k.cf[1] * g_front + (k.d[0] - k.d[1]) * g_tan;
+        o.gp2 = k.c[2] * g_x + k.cf[2] * g_front + (k.d[1] - k.d[2]) * g_tan;
+        o.gp3 = k.c[3] * g_x + k.cf[3] * g_front + k.d[2] * g_tan;
+    } else {
+        o.gp0 = k.l[0] * g_x + k.lf[0] * g_front - g_tan;
+        o.gp3 = k.l[1] * g_x + k.lf[1] * g_front + g_tan;
+    }
+    return o;
+}
+constexpr int CURVE_PART = 13;   // per-curve partial of the fused view backward: dL/d{p0..p3} (12) + dL/dwidth
+// Sum the 13 per-sample values of every curve of the block over its m samples (sample order: deterministic) and hand each
+// (curve, field) sum to fn(local curve, field, sum).  s_part: [13][SAMPLE_BLOCK + 1] floats of LDS.
+template <typename F>
+__device__ __forceinline__ void curve_reduce(const CurveGrad& g, float (*s_part)[256 + 1], int m, int curves_per_block, F fn) {
+    const int t = threadIdx.x;
+    s_part[0][t] = g.gp0.x; s_part[1][t] = g.gp0.y; s_part[2][t] = g.gp0.z;
+    s_part[3][t] = g.gp1.x; s_part[4][t] = g.gp1.y; s_part[5][t] = g.gp1.z;
+    s_part[6][t] = g.gp2.x; s_part[7][t] = g.gp2.y; s_part[8][t] = g.gp2.z;
+    s_part[9][t] = g.gp3.x; s_part[10][t] = g.gp3.y; s_part[11][t] = g.gp3.z;
+    s_part[12][t] = g.gw;
+    __syncthreads();
+    for (int o = threadIdx.x; o < curves_per_block * CURVE_PART; o += blockDim.x) {
+        const int c2 = o / CURVE_PART, f = o - c2 * CURVE_PART;
+        float sum = 0.f;
+        for (int q = 0; q < m; q++) sum += s_part[f][c2 * m + q];
+        fn(c2, f, sum);
+    }
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 // ---------------------------------------------------------------- per-view splat attributes (one splat)

@@ -81,9 +81,9 @@ void launch_render_bwd_unit(hipStream_t s, int tiles, const uint2* ranges, const
 // sampling.hip
 int sample_norm_words();
 void launch_sample_norms(hipStream_t s, int B, int m, const float* cp, const uint8_t* is_bezier, const void* coef, double* norms);
-void launch_sample_backward_pass3(hipStream_t s, int B, int m, const float* cp, const float* width, const uint8_t* is_bezier,
-                                  const void* coef, float eps, double* norms, const float* g_xyz, const float* g_rot,
-                                  const float* g_scaling, float* g_cp, float* g_width, float* gv_cache, int accumulate);
+void launch_sample_backward_close(hipStream_t s, int B, int m, const float* cp, const float* width, const uint8_t* is_bezier,
+                                  const void* coef, float eps, const double* norms, const float* part, float* g_cp, float* g_width,
+                                  int accumulate);
 // view.hip
 void launch_view_forward(hipStream_t s, int B, int m, const float* cp, const float* width, const uint8_t* is_bezier,
                          const void* coef, float eps, const double* norms, const float* opacity_logit,
@@ -96,8 +96,7 @@ void launch_view_backward(hipStream_t s, int B, int m, const float* cp, const fl
                           float mask_thr, const float* campos, const float* viewmatrix, const float* projmatrix,
                           float tan_fovx, float tan_fovy, float focal_x, float focal_y, int W, int H, const int* radii,
                           const SplatRec* rec, float* grad_acc, const float* g_rot_raw_extra, float* dL_dmean2D,
-                          float* g_opacity_logit, float* g_mask_logit, float* g_xyz, float* g_scaling, float* gv_cache,
-                          int accumulate);
+                          float* g_opacity_logit, float* g_mask_logit, float* curve_part, int accumulate);
 int sample_norm_fwd_words();
 void launch_sample_forward(hipStream_t s, int B, int m, const float* cp, const float* width, const uint8_t* is_bezier,
                            const void* coef, float eps, double* norms, float* xyz, float* rot, float* scaling);

@@ -159,12 +159,10 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_sample_bwd(int B, int m, int c
             i = sp - b * m;
             continue;
         }
-        const float iN2 = 1.f / N2;
-        const V3 g_c2v = iN2 * g_v2 - (D2 * iN2 * iN2 * iN2) * s.c2v;
-        // c2v = cross(tan, v1)
-        V3 g_tan = cross(s.v1, g_c2v);
-        const V3 g_v1t = g_v1 + cross(g_c2v, s.tan);
         if (PASS == 2) {
+            const float iN2 = 1.f / N2;
+            const V3 g_c2v = iN2 * g_v2 - (D2 * iN2 * iN2 * iN2) * s.c2v;
+            const V3 g_v1t = g_v1 + cross(g_c2v, s.tan);
             acc += (double)dot(g_v1t, s.c1v);
             sp += gridDim.x * blockDim.x;
             valid = sp < B * m;
@@ -172,39 +170,11 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_sample_bwd(int B, int m, int c
             i = sp - b * m;
             continue;
         }
-        const float iN1 = 1.f / N1;
-        const V3 g_c1v = iN1 * g_v1t - (D1 * iN1 * iN1 * iN1) * s.c1v;
-        g_tan.y += g_c1v.x;  // c1v = (ty, -tx, 0)
-        g_tan.x -= g_c1v.y;
-        if (s.n > 0.f) {     // v0 = tan / (n + eps)
-            const float ne = s.n + eps;
-            const float coefv = dot(g_v0, s.tan) / (s.n * ne * ne);
-            g_tan = g_tan + (1.f / ne) * g_v0 - coefv * s.tan;
-        } else {
-            g_tan = g_tan + (1.f / eps) * g_v0;
-        }
-        // scaling = (dist, exp(w), exp(w))
-        V3 g_x = {0, 0, 0};
+        V3 g_x = {0, 0, 0}, g_s = {0, 0, 0};
         if (g_xyz) g_x = {g_xyz[3 * p], g_xyz[3 * p + 1], g_xyz[3 * p + 2]};
-        V3 g_front = {0, 0, 0};
-        if (g_scaling) {
-            const float gd = g_scaling[3 * p];
-            gw = (g_scaling[3 * p + 1] + g_scaling[3 * p + 2]) * w;
-            if (s.dist > 0.f) {
-                const V3 gdv = (gd / s.dist) * s.dvec;
-                g_x = g_x + gdv;
-                g_front = {-gdv.x, -gdv.y, -gdv.z};
-            }
-        }
-        if (c.bez) {
-            gp0 = k.c[0] * g_x + k.cf[0] * g_front - k.d[0] * g_tan;
-            gp1 = k.c[1] * g_x + k.cf[1] * g_front + (k.d[0] - k.d[1]) * g_tan;
-            gp2 = k.c[2] * g_x + k.cf[2] * g_front + (k.d[1] - k.d[2]) * g_tan;
-            gp3 = k.c[3] * g_x + k.cf[3] * g_front + k.d[2] * g_tan;
-        } else {
-            gp0 = k.l[0] * g_x + k.lf[0] * g_front - g_tan;
-            gp3 = k.l[1] * g_x + k.lf[1] * g_front + g_tan;
-        }
+        if (g_scaling) g_s = {g_scaling[3 * p], g_scaling[3 * p + 1], g_scaling[3 * p + 2]};
+        const CurveGrad cg = sample_backward_tail(c, k, s, w, eps, N1, N2, D2, D1, g_v0, g_v1, g_v2, g_x, g_scaling != nullptr, g_s);
+        gp0 = cg.gp0; gp1 = cg.gp1; gp2 = cg.gp2; gp3 = cg.gp3; gw = cg.gw;
         break;
     }
     if (PASS == 1) {
@@ -212,24 +182,53 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_sample_bwd(int B, int m, int c
         block_accumulate<2>(acc2, norms, 3);
     }
     if (PASS == 3) {
-        const int t = threadIdx.x;
-        s_part[0][t] = gp0.x; s_part[1][t] = gp0.y; s_part[2][t] = gp0.z;
-        s_part[3][t] = gp1.x; s_part[4][t] = gp1.y; s_part[5][t] = gp1.z;
-        s_part[6][t] = gp2.x; s_part[7][t] = gp2.y; s_part[8][t] = gp2.z;
-        s_part[9][t] = gp3.x; s_part[10][t] = gp3.y; s_part[11][t] = gp3.z;
-        s_part[12][t] = gw;
-        __syncthreads();
+        CurveGrad cg;
+        cg.gp0 = gp0; cg.gp1 = gp1; cg.gp2 = gp2; cg.gp3 = gp3; cg.gw = gw;
         // 13 outputs per curve, summed over its m samples in sample order (deterministic)
-        for (int o = threadIdx.x; o < curves_per_block * 13; o += blockDim.x) {
-            const int c2 = o / 13, f = o - c2 * 13;
+        curve_reduce(cg, s_part, m, curves_per_block, [&](int c2, int f, float sum) {
             const int bb = blockIdx.x * curves_per_block + c2;
-            if (bb >= B) continue;
-            float sum = 0.f;
-            for (int q = 0; q < m; q++) sum += s_part[f][c2 * m + q];
+            if (bb >= B) return;
             float* dst = f < 12 ? g_cp + (size_t)bb * 12 + f : g_width + bb;
             *dst = accumulate ? *dst + sum : sum;
-        }
+        });
     }
+}
+
+// Closing pass of the FUSED view backward (k_view_bwd left, per curve, the 13 sums of the tail's gradient-dependent part in
+// `part`): the part that carries the two grid-wide sums is evaluated from the curve alone -- tail(0, D2, D1) -- and added.
+// Reads 48 + 52 bytes per curve, no per-splat data.
+__global__ void __launch_bounds__(SAMPLE_BLOCK) k_sample_bwd_close(int B, int m, int curves_per_block, const float* __restrict__ cp,
+                                                                   const float* __restrict__ width,
+                                                                   const uint8_t* __restrict__ is_bezier,
+                                                                   const SampleCoef* __restrict__ coef, float eps,
+                                                                   const double* __restrict__ norms, const float* __restrict__ part,
+                                                                   float* __restrict__ g_cp, float* __restrict__ g_width,
+                                                                   int accumulate) {
+    // thread = sample, blocks hold whole curves, like pass 3.  (Thread = curve with a loop over its samples -- no LDS, no
+    // barrier -- was measured: 14.6 against 9.3 us at cfg3, 20.3 against 19.5 at cfg5: 260 waves do not fill 1 024 SIMDs.)
+    __shared__ float s_part[CURVE_PART][SAMPLE_BLOCK + 1];
+    __shared__ SampleCoef s_coef[MAX_M];
+    __shared__ BlockConst s_bc;
+    stage_consts(coef, m, norms, s_coef, &s_bc);
+    const int lc = threadIdx.x / m, i = threadIdx.x - lc * m;
+    const int b = blockIdx.x * curves_per_block + lc;
+    CurveGrad cg;
+    cg.gp0 = cg.gp1 = cg.gp2 = cg.gp3 = V3{0.f, 0.f, 0.f};
+    cg.gw = 0.f;
+    if (lc < curves_per_block && b < B) {
+        const CurveCP c = load_curve(cp, is_bezier, b);
+        const SampleCoef k = s_coef[i];
+        const SampleFwd s = sample_forward(c, k, s_bc.N1, s_bc.N2, eps);
+        const V3 z = {0.f, 0.f, 0.f};
+        cg = sample_backward_tail(c, k, s, expf(width[b]), eps, s_bc.N1, s_bc.N2, s_bc.D2, s_bc.D1, z, z, z, z, false, z);
+    }
+    curve_reduce(cg, s_part, m, curves_per_block, [&](int c2, int f, float sum) {
+        const int bb = blockIdx.x * curves_per_block + c2;
+        if (bb >= B) return;
+        const float v = part[(size_t)bb * CURVE_PART + f] + sum;
+        float* dst = f < 12 ? g_cp + (size_t)bb * 12 + f : g_width + bb;
+        *dst = accumulate ? *dst + v : v;
+    });
 }
 
 // ------------------------------------------------------------------------------------------------ splat attributes
@@ -355,14 +354,13 @@ void launch_sample_norms(hipStream_t s, int B, int m, const float* cp, const uin
     hipLaunchKernelGGL(k_sample_f12, dim3(NORM_SLOTS), dim3(f12_threads((long long)B * m)), 0, s, B, m, cp, is_bezier,
                        reinterpret_cast<const SampleCoef*>(coef), norms);
 }
-void launch_sample_backward_pass3(hipStream_t s, int B, int m, const float* cp, const float* width, const uint8_t* is_bezier,
-                                  const void* coef, float eps, double* norms, const float* g_xyz, const float* g_rot,
-                                  const float* g_scaling, float* g_cp, float* g_width, float* gv_cache, int accumulate) {
+void launch_sample_backward_close(hipStream_t s, int B, int m, const float* cp, const float* width, const uint8_t* is_bezier,
+                                  const void* coef, float eps, const double* norms, const float* part, float* g_cp, float* g_width,
+                                  int accumulate) {
     const int cpb = SAMPLE_BLOCK / m;
     ProfScope p("sample_b3", s);
-    hipLaunchKernelGGL(k_sample_bwd<3>, dim3((B + cpb - 1) / cpb), dim3(SAMPLE_BLOCK), 0, s, B, m, cpb, cp, width, is_bezier,
-                       reinterpret_cast<const SampleCoef*>(coef), eps, norms, g_xyz, g_rot, g_scaling, g_cp, g_width, gv_cache,
-                       accumulate);
+    hipLaunchKernelGGL(k_sample_bwd_close, dim3((B + cpb - 1) / cpb), dim3(SAMPLE_BLOCK), 0, s, B, m, cpb, cp, width, is_bezier,
+                       reinterpret_cast<const SampleCoef*>(coef), eps, norms, part, g_cp, g_width, accumulate);
 }
 
 int sample_norm_words() { return NORM_WORDS; }

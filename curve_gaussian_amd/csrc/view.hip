@@ -87,12 +87,13 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK, WAVES) k_view_bwd(
     const float* __restrict__ opacity_logit, const float* __restrict__ mask_logit, float mask_thr,
     const float* __restrict__ campos, ViewParams vp, const int* __restrict__ radii, const SplatRec* __restrict__ rec,
     float* __restrict__ grad_acc, const float* __restrict__ g_rot_raw_extra, float* __restrict__ dL_dmean2D,
-    float* __restrict__ g_opacity_logit, float* __restrict__ g_mask_logit, float* __restrict__ g_xyz,
-    float* __restrict__ g_scaling, float* __restrict__ gv_cache, int accumulate_flags) {
-    // bit 0: add to the caller's gradient outputs; bit 1: add to the per-splat scratch as well (shared-sampling mode: the
-    // sampling backward's last pass runs once for several views and is linear in these per-splat gradients)
+    float* __restrict__ g_opacity_logit, float* __restrict__ g_mask_logit, float* __restrict__ curve_part,
+    int accumulate_flags) {
+    // bit 0: add to the caller's gradient outputs; bit 1: add to the per-curve partials as well (shared-sampling mode: the
+    // sampling backward's closing pass runs once for several views and is linear in them)
     const int accumulate = accumulate_flags & 1;
     const bool acc_scr = (accumulate_flags & 2) != 0;
+    __shared__ float s_part[CURVE_PART][SAMPLE_BLOCK + 1];
     __shared__ SampleCoef s_coef[MAX_M];
     __shared__ BlockConst s_bc;
     __shared__ float s_go[SAMPLE_BLOCK];
@@ -102,6 +103,9 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK, WAVES) k_view_bwd(
     const bool valid = lc < curves_per_block && b < B;
     float g_op_term = 0.f;
     double acc_d2 = 0, acc_a = 0;
+    CurveGrad cg;
+    cg.gp0 = cg.gp1 = cg.gp2 = cg.gp3 = V3{0.f, 0.f, 0.f};
+    cg.gw = 0.f;
     if (valid) {
         const size_t p = (size_t)b * m + i;
         const float N1 = s_bc.N1, N2 = s_bc.N2;
@@ -149,30 +153,29 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK, WAVES) k_view_bwd(
             const float4 e = reinterpret_cast<const float4*>(g_rot_raw_extra)[p];
             grr = make_float4(grr.x + e.x, grr.y + e.y, grr.z + e.z, grr.w + e.w);
         }
-        // ---- sampling backward, pass 1: dL/d{v0,v1,v2} cached for pass 3, the two grid-wide sums
+        // ---- sampling backward: the two grid-wide sums, and the part of this sample's dL/d{p0..p3, width} that does not
+        // depend on them (sample_backward_tail with D2 = D1 = 0; the closing pass k_sample_bwd_close adds the rest) -- summed
+        // over the curve below: 13 floats per CURVE leave the kernel where 15 per SPLAT used to (and came back)
         float gM[3][3];
         const float go[4] = {grr.x, grr.y, grr.z, grr.w};
         quat_backward(f, go, gM);
         const V3 g_v0 = {gM[0][0], gM[1][0], gM[2][0]};
         const V3 g_v1 = {gM[0][1], gM[1][1], gM[2][1]};
         const V3 g_v2 = {gM[0][2], gM[1][2], gM[2][2]};
-        float* gv = gv_cache + p;             // planes [9][P]: a wave's accesses are contiguous
-        const size_t PS = (size_t)B * m;
-        const float gvv[9] = {g_v0.x, g_v0.y, g_v0.z, g_v1.x, g_v1.y, g_v1.z, g_v2.x, g_v2.y, g_v2.z};
-#pragma unroll
-        for (int e = 0; e < 9; e++) gv[e * PS] = acc_scr ? gv[e * PS] + gvv[e] : gvv[e];
         acc_d2 = (double)dot(g_v2, s.c2v);
         acc_a = (double)dot(g_v1, s.c1v) + (double)((1.f / N2) * dot(cross(g_v2, s.tan), s.c1v));
-        const float gxs[6] = {o.dmean.x, o.dmean.y, o.dmean.z, gs.x * ab.mk, gs.y * ab.mk, gs.z * ab.mk};
-#pragma unroll
-        for (int e = 0; e < 3; e++) {
-            g_xyz[3 * p + e] = acc_scr ? g_xyz[3 * p + e] + gxs[e] : gxs[e];
-            g_scaling[3 * p + e] = acc_scr ? g_scaling[3 * p + e] + gxs[3 + e] : gxs[3 + e];
-        }
+        const V3 g_x = {o.dmean.x, o.dmean.y, o.dmean.z}, g_s = {gs.x * ab.mk, gs.y * ab.mk, gs.z * ab.mk};
+        cg = sample_backward_tail(c, s_coef[i], s, w, eps, N1, N2, 0.f, 0.f, g_v0, g_v1, g_v2, g_x, true, g_s);
     }
     s_go[threadIdx.x] = g_op_term;
     const double acc2v[2] = {acc_d2, acc_a};
     block_accumulate<2>(acc2v, norms, 3);     // (contains the barrier that publishes s_go)
+    curve_reduce(cg, s_part, m, curves_per_block, [&](int c2, int f, float sum) {
+        const int bb = blockIdx.x * curves_per_block + c2;
+        if (bb >= B) return;
+        float* dst = curve_part + (size_t)bb * CURVE_PART + f;
+        *dst = acc_scr ? *dst + sum : sum;
+    });
     if (valid && i == 0) {
         float sum = 0.f;
         for (int k = 0; k < m; k++) sum += s_go[threadIdx.x + k];
@@ -198,8 +201,7 @@ void launch_view_backward(hipStream_t s, int B, int m, const float* cp, const fl
                           float mask_thr, const float* campos, const float* viewmatrix, const float* projmatrix,
                           float tan_fovx, float tan_fovy, float focal_x, float focal_y, int W, int H, const int* radii,
                           const SplatRec* rec, float* grad_acc, const float* g_rot_raw_extra, float* dL_dmean2D,
-                          float* g_opacity_logit, float* g_mask_logit, float* g_xyz, float* g_scaling, float* gv_cache,
-                          int accumulate) {
+                          float* g_opacity_logit, float* g_mask_logit, float* curve_part, int accumulate) {
     ProfScope p("view_bwd", s);
     const int cpb = SAMPLE_BLOCK / m;
     const ViewParams vp{viewmatrix, projmatrix, tan_fovx, tan_fovy, focal_x, focal_y, W, H, 0, 0};
@@ -207,12 +209,12 @@ void launch_view_backward(hipStream_t s, int B, int m, const float* cp, const fl
         hipLaunchKernelGGL(k_view_bwd<CGS_VIEW_BWD_WAVES_LARGE>, dim3((B + cpb - 1) / cpb), dim3(SAMPLE_BLOCK), 0, s, B, m, cpb, cp,
                            width, is_bezier, reinterpret_cast<const SampleCoef*>(coef), eps, norms, opacity_logit, mask_logit,
                            mask_thr, campos, vp, radii, rec, grad_acc, g_rot_raw_extra, dL_dmean2D, g_opacity_logit, g_mask_logit,
-                           g_xyz, g_scaling, gv_cache, accumulate);
+                           curve_part, accumulate);
     else
         hipLaunchKernelGGL(k_view_bwd<CGS_VIEW_BWD_WAVES>, dim3((B + cpb - 1) / cpb), dim3(SAMPLE_BLOCK), 0, s, B, m, cpb, cp, width,
                            is_bezier, reinterpret_cast<const SampleCoef*>(coef), eps, norms, opacity_logit, mask_logit, mask_thr,
-                           campos, vp, radii, rec, grad_acc, g_rot_raw_extra, dL_dmean2D, g_opacity_logit, g_mask_logit, g_xyz,
-                           g_scaling, gv_cache, accumulate);
+                           campos, vp, radii, rec, grad_acc, g_rot_raw_extra, dL_dmean2D, g_opacity_logit, g_mask_logit, curve_part,
+                           accumulate);
 }
 
 }  // namespace cgs

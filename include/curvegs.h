@@ -146,7 +146,9 @@ size_t cgs_binning_bytes(int64_t R);
  *     Outputs: dL_dmeans2D [P,3] (NDC-scaled, feeds add_densification_stats), dL_dcurve_points [B,4,3], dL_dwidth [B,1],
  *     dL_dopacity_logit [B,1], dL_dmask_logit [P] (required iff mask_logit) -- overwritten, or added to when `flags`
  *     has CGS_VIEW_ACCUMULATE (several views summed into one gradient buffer without extra kernels).  scratch:
- *     cgs_view_backward_scratch_floats(B, m) floats.
+ *     cgs_view_backward_scratch_floats(B, m) floats (13 per curve are used: the part of dL/d{curve_points, width} that does not
+ *     depend on the two grid-wide sums of the sampling backward, summed per curve inside the per-splat kernel; the closing
+ *     pass adds the rest from the curve alone -- rounds 2-5 sent 15 floats per SPLAT through this buffer and back).
  *   cgs_view_forward_checked: the same forward for eager callers (the drop-in render(): gaussian_renderer/__init__.py:18-157
  *     as train.py:95-97 calls it).  Like the reference's forward it reports how much it binned -- but the host only waits for
  *     a 16-byte readback queued right behind the SCATTER, with the compositor already enqueued behind it (the reference blocks
@@ -216,7 +218,7 @@ int64_t cgs_last_forward_visible(void);
 int cgs_visible_indices(int P, const int* radii, const void* image_buffer, int width, int height, int64_t* out_indices, void* stream);
 /* Several views of ONE parameter state (a view batch between two optimizer steps; not the reference's one-view iteration):
  * cgs_view_forward_shared is cgs_view_forward without the grid-wide norm pass of prepare_scaling_rot, and cgs_view_backward
- * with CGS_VIEW_SHARED in its flags adds its per-splat gradients into `scratch` and skips the last pass of the sampling
+ * with CGS_VIEW_SHARED in its flags adds its per-curve partial gradients into `scratch` and skips the closing pass of the sampling
  * backward (linear in them); the caller brackets the batch with cgs_view_shared_begin (zeroes norms and scratch, computes the
  * norms once) and cgs_view_shared_end (that last pass, once: dL/dcurve_points, dL/dwidth written or added to).  Every view of
  * the batch must use the SAME norms and scratch buffers; opacity / mask gradients keep coming from cgs_view_backward
