@@ -19,6 +19,9 @@ timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- 
 timeout 240 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc1 -- $B --steps 4 --warmup 1 > $O/pmc1.log 2>&1
 timeout 240 rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $O/pmc2 -- $B --steps 4 --warmup 1 > $O/pmc2.log 2>&1
 timeout 240 rocprofv3 --pmc SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_INSTS_FLAT SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL --kernel-trace --output-format csv -d $O/pmc3 -- $B --steps 4 --warmup 1 > $O/pmc3.log 2>&1
+# round 6: the clock the kernels really ran at (GRBM_GUI_ACTIVE / duration; MI355X_MICROARCH.md, "DVFS give-back") and the
+
+timeout 240 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc4 -- $B --steps 4 --warmup 1 > $O/pmc4.log 2>&1
 timeout 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $B --steps 4 --warmup 1 > $O/fetch.log 2>&1
 timeout 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $B --steps 4 --warmup 1 > $O/write.log 2>&1
 # the operator-API instances (GaussianRasterizer: gated unit backward, general training / colour / all_map / all-gradient backward)

@@ -21,7 +21,7 @@ SHORT = [("k_render_bwd3<false, false, true", "render_bwd_colour_grad"), ("k_ren
          ("k_tile_sort", "tile_sort_big"), ("k_scatter", "scatter"), ("k_preprocess_fwd", "preprocess_fwd"),
          ("k_preprocess_bwd", "preprocess_bwd"), ("k_scan_tiles", "scan_tiles"), ("k_sample_f12", "sample_f12"),
          ("k_sample_f3", "sample_f3"), ("k_sample_bwd<1>", "sample_b1"),
-          ("k_sample_bwd<3>", "sample_b3"), ("k_attrs_fwd", "attrs_fwd"),
+          ("k_sample_bwd<3>", "sample_b3"), ("k_sample_bwd_close", "sample_b3"), ("k_attrs_fwd", "attrs_fwd"),
          ("k_attrs_bwd", "attrs_bwd"), ("k_zero_vec", "zero_fill"), ("k_zero_words", "zero_fill"),
          ("k_view_fwd", "view_fwd"), ("k_view_bwd", "view_bwd")]
 
