@@ -195,6 +195,8 @@ def main():
     ap.add_argument("--no-train-step", action="store_true")
     ap.add_argument("--no-general-route", action="store_true",
                     help="skip the `general_route` block (kernel times of the operator-API instances, GaussianRasterizer)")
+    ap.add_argument("--no-realistic-size", action="store_true",
+                    help="skip the `realistic_size` block of the default cfg3 line (one child run of cfg2, the size the reference trains)")
     ap.add_argument("--all-configs", action="store_true",
                     help="after the run, also run cfg1..cfg5 (one child process each, N = 1, short) and attach a compact "
                          "`all_configs` block: value, ms per view, whole-path roofline fraction, train step, drop-in view")
@@ -927,13 +929,30 @@ help="A/B: tile sort inside the forward compositor (sets CGS_FUSED_TILE_SORT, wh
                              "achieved_GBps": round(alg_view / (ms_per_view * 1e-3) / 1e9, 2),   # whole job, per view
                              "hbm_roofline_frac": round(alg_view / (ms_per_view * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                              "sum_kernel_ms": round(sum(kernel_ms.values()), 5)}
+        # A view whose pixels (nearly) all TERMINATE early -- cfg5: 1 M splats, every pixel saturates -- bins instances it never
+        # composites (everything behind a pixel's cut): the R-proportional bytes then overstate what the compositors touch and
+        # the fraction reads close to 1 for no merit of the kernels.  Such a line carries no whole-path fraction.
+        term_frac = None
+        if prof_direct[1] is not None:
+            npix = H * W
+            off_nc = (4 * npix + 127) // 128 * 128
+            ncw = prof_direct[1]["img"][off_nc:off_nc + 4 * npix].view(torch.int32)
+            term_frac = float((ncw < 0).float().mean())          # bit 31 of the saved n_contrib word: the pixel terminated
+            out["whole_path"]["terminated_pixel_frac"] = round(term_frac, 4)
+            if term_frac > 0.9:
+                out["whole_path"]["hbm_roofline_frac_if_every_instance_were_composited"] = out["whole_path"]["hbm_roofline_frac"]
+                out["whole_path"]["hbm_roofline_frac"] = None
+                out["whole_path"]["hbm_roofline_frac_note"] = (
+                    f"n/a: {term_frac:.0%} of the pixels of the last profiled view terminate early (T < 1e-4); the instances "
+                    "behind their cuts are binned and sorted but never composited, so bytes proportional to R overstate the traffic")
         if stats.get("R_ref"):
             # the same fraction on the instance count the REFERENCE algorithm creates for these views (its 3-sigma tile rects:
             # tile culling drops the instances that stay below alpha 1/255 on all 256 pixels, the reference bins and sorts them)
             alg_ref = algorithmic_bytes(P, stats["R_ref"], H, W)
             out["whole_path"]["reference_instances_per_view"] = round(stats["R_ref"], 1)
             out["whole_path"]["algorithmic_bytes_per_view_reference_R"] = int(alg_ref)
-            out["whole_path"]["hbm_roofline_frac_reference_R"] = round(alg_ref / (ms_per_view * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+            out["whole_path"]["hbm_roofline_frac_reference_R"] = (
+                None if (term_frac is not None and term_frac > 0.9) else round(alg_ref / (ms_per_view * 1e-3) / 1e9 / HBM_PEAK_GBS, 5))
 
     # ---------------------------------------------------------------- train-step ms (the other half of the metric)
     if world == 1 and not args.no_train_step:
@@ -1247,23 +1266,45 @@ help="A/B: tile sort inside the forward compositor (sets CGS_FUSED_TILE_SORT, wh
                 "sample": f"{S_} of the view's {P} splats over the full {W}x{H} image, oracle/torch_ref.dense_render + autograd "
                           f"(dense P x H x W: cost per splat does not depend on its footprint), torch.set_num_threads({threads}), "
                           f"{tp2 - tp0:.1f} s"}
+    def child_line(cfg, extra=()):
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", cfg, "--steps", "8", "--warmup", "2",
+               "--min-seconds", "1.0", "--no-cpu-baseline", "--no-general-route", "--no-realistic-size"] + list(extra)
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return None, (r.stderr or r.stdout)[-300:]
+        return json.loads(line[-1]), None
+
+    if (world == 1 and args.config == "cfg3" and args.mode == "view" and not args.no_realistic_size and not args.all_configs
+            and not args.no_train_step):
+        # The size the reference actually trains (BASELINE cfg2: ~50 k splats at 1600^2): the headline rate, the
+        # training iteration in its three forms and the literal drop-in render() + backward, from one child run on this GPU
+        # after everything above is done with it.
+        j, err = child_line("cfg2", ("--no-kernel-times",))
+        if j is None:
+            out["realistic_size"] = {"config": "cfg2", "error": err}
+        else:
+            out["realistic_size"] = {
+                "config": "cfg2", "splats": j["config"]["splats"], "value": j["value"], "ms_per_view": j["ms_per_view"],
+                "train_step_ms": j.get("train_step_ms"), "train_step_eager_ms": j.get("train_step_eager_ms"),
+                "train_step_eager_direct_ms": j.get("train_step_eager_direct_ms"), "dropin_view_ms": j.get("dropin_view_ms"),
+                "note": "train_step_ms: graph replay; _eager_ms: render() + loss.backward() through Python autograd (the literal "
+                        "drop-in loop); _eager_direct_ms: the same iteration as plain library calls (TrainStep(direct=True)); "
+                        "dropin_view_ms: render() + backward alone"}
     if args.all_configs and world == 1:
         # one child per BASELINE config on this same GPU, after everything above is done with it: the headline fields of each
         # line, compact (the children skip the CPU baseline and the operator-instance block; their timed region is shorter)
-        import subprocess
         allc = {}
         for cfg in ("cfg1", "cfg2", "cfg3", "cfg4", "cfg5"):
-            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", cfg, "--steps", "8", "--warmup", "2",
-                   "--min-seconds", "1.0", "--no-cpu-baseline", "--no-general-route"]
-            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-            r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
-            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-            if r.returncode != 0 or not line:
-                allc[cfg] = {"error": (r.stderr or r.stdout)[-300:]}
+            j, err = child_line(cfg)
+            if j is None:
+                allc[cfg] = {"error": err}
                 continue
-            j = json.loads(line[-1])
             allc[cfg] = {"value": j["value"], "ms_per_view": j["ms_per_view"],
                          "whole_path_hbm_frac": j.get("whole_path", {}).get("hbm_roofline_frac"),
+                         "terminated_pixel_frac": j.get("whole_path", {}).get("terminated_pixel_frac"),
                          "serial_view_graph_ms": j.get("serial_view_graph_ms"), "train_step_ms": j.get("train_step_ms"),
                          "train_step_eager_ms": j.get("train_step_eager_ms"), "train_step_eager_direct_ms": j.get("train_step_eager_direct_ms"), "dropin_view_ms": j.get("dropin_view_ms"),
                          "dropin_view_general_route_ms": j.get("dropin_view_general_route_ms"),
