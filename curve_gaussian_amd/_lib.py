@@ -115,6 +115,11 @@ def load() -> C.CDLL:
 
 _shim = None
 SHIM_PATH = os.path.join(_HERE, "_cgs_torch.so")
+# _cgs_torch.so is linked against $ORIGIN/libcurvegs.so: with CGS_LIB pointing at an experiment build it would run the
+# DEFAULT kernels (and hand out handles of another library instance) while ctypes drives the experiment -- an A/B run must
+# use one library, so an overridden CGS_LIB selects the ctypes bindings.  Resolved once: use_shim() sits on the
+# per-iteration path of the eager routes (two realpath() calls there cost 70 us per training iteration).
+_LIB_IS_DEFAULT = os.path.realpath(LIB_PATH) == os.path.realpath(os.path.join(_HERE, "libcurvegs.so"))
 
 
 def use_shim() -> bool:
@@ -123,10 +128,7 @@ def use_shim() -> bool:
     kernels either way."""
     if os.environ.get("CGS_TORCH_SHIM", "1") == "0":
         return False
-    # _cgs_torch.so is linked against $ORIGIN/libcurvegs.so: with CGS_LIB pointing at an experiment build it would run the
-    # DEFAULT kernels (and hand out handles of another library instance) while ctypes drives the experiment -- an A/B run
-    # must use one library, so an overridden CGS_LIB selects the ctypes bindings (ADVICE r5)
-    return os.path.realpath(LIB_PATH) == os.path.realpath(os.path.join(_HERE, "libcurvegs.so"))
+    return _LIB_IS_DEFAULT
 
 
 def shim():
