@@ -204,11 +204,16 @@ Tensor mark_visible(const Tensor& means3D, const Tensor& viewmatrix, const Tenso
 // Forward half of ops/view_render.py::_ViewRender: detached float32 copies of the parameters, every buffer of the view, the
 // begin half of the checked forward (or the sync-free forward when static_cap > 0) and render()'s epilogue, in one call.
 // -> (color, invdepth, all_map, radii, rend_dir | empty, color_raw | None, saved tensors..., handle, cap)
-py::tuple view_forward(const Tensor& curve_points, const Tensor& width, const Tensor& opacity_logit,
-                       const c10::optional<Tensor>& mask_logit, const c10::optional<Tensor>& is_bezier_u8, const Tensor& coef,
-                       int64_t m, double mask_thr, const Tensor& bg, const Tensor& viewmatrix, const Tensor& projmatrix,
-                       const Tensor& campos, double tanx, double tany, int64_t H, int64_t W, int64_t cap, bool sync_free, bool clamp,
-                       bool want_dir, double eps) {
+struct ViewFwd {
+    Tensor color_out, invd, amap, radii, rend_dir, color_raw;                               // color_raw: undefined unless clamp
+    Tensor cp, w, ol, mk, geom, binb, img, norms, bgc, view, proj, cpos;                   // what the backward needs (mk: undefined = no mask)
+    int handle = -1;
+};
+ViewFwd view_forward_core(const Tensor& curve_points, const Tensor& width, const Tensor& opacity_logit,
+                          const c10::optional<Tensor>& mask_logit, const c10::optional<Tensor>& is_bezier_u8, const Tensor& coef,
+                          int64_t m, double mask_thr, const Tensor& bg, const Tensor& viewmatrix, const Tensor& projmatrix,
+                          const Tensor& campos, double tanx, double tany, int64_t H, int64_t W, int64_t cap, bool sync_free, bool clamp,
+                          bool want_dir, double eps) {
     require_gpu(curve_points, "curve_points");
     require_gpu(bg, "bg_color");   // "Background tensor (bg_color) must be on GPU!" (gaussian_renderer/__init__.py:23)
     require_gpu(viewmatrix, "viewpoint_camera.world_view_transform");
@@ -232,7 +237,6 @@ py::tuple view_forward(const Tensor& curve_points, const Tensor& width, const Te
     const uint8_t* isb = has(is_bezier_u8) ? (const uint8_t*)is_bezier_u8->data_ptr() : nullptr;
     // render()'s epilogue (gaussian_renderer/__init__.py:138-145) is written by the forward compositor itself
     Tensor color_out = color, rend_dir = at::empty({0}, fopt);
-    py::object color_raw = py::none();
     if (clamp) color_out = at::empty({1, H, W}, fopt);
     if (want_dir) rend_dir = at::empty({3, H, W}, fopt);
     const int handle = check(cgs_view_forward_render(sync_free ? 0 : 1, B, (int)m, fp(cp), fp(w), isb, fp(coef), (float)eps,
@@ -243,10 +247,25 @@ py::tuple view_forward(const Tensor& curve_points, const Tensor& width, const Te
                                                      clamp ? color_out.data_ptr<float>() : nullptr,
                                                      want_dir ? rend_dir.data_ptr<float>() : nullptr, st),
                              "cgs_view_forward_render");
-    if (clamp) color_raw = py::cast(color);
-    return py::make_tuple(color_out, invd, amap, radii, rend_dir, color_raw,
-                          py::make_tuple(cp, w, ol, mk.defined() ? py::cast(mk) : py::none(), geom, binb, img, radii, norms, bgc, view, proj, cpos),
-                          sync_free ? -1 : handle);
+    ViewFwd f;
+    f.color_out = color_out; f.invd = invd; f.amap = amap; f.radii = radii; f.rend_dir = rend_dir;
+    if (clamp) f.color_raw = color;
+    f.cp = cp; f.w = w; f.ol = ol; f.mk = mk; f.geom = geom; f.binb = binb; f.img = img; f.norms = norms; f.bgc = bgc;
+    f.view = view; f.proj = proj; f.cpos = cpos;
+    f.handle = sync_free ? -1 : handle;
+    return f;
+}
+py::tuple view_forward(const Tensor& curve_points, const Tensor& width, const Tensor& opacity_logit,
+                       const c10::optional<Tensor>& mask_logit, const c10::optional<Tensor>& is_bezier_u8, const Tensor& coef,
+                       int64_t m, double mask_thr, const Tensor& bg, const Tensor& viewmatrix, const Tensor& projmatrix,
+                       const Tensor& campos, double tanx, double tany, int64_t H, int64_t W, int64_t cap, bool sync_free, bool clamp,
+                       bool want_dir, double eps) {
+    const ViewFwd f = view_forward_core(curve_points, width, opacity_logit, mask_logit, is_bezier_u8, coef, m, mask_thr, bg, viewmatrix,
+                                        projmatrix, campos, tanx, tany, H, W, cap, sync_free, clamp, want_dir, eps);
+    return py::make_tuple(f.color_out, f.invd, f.amap, f.radii, f.rend_dir, f.color_raw.defined() ? py::cast(f.color_raw) : py::none(),
+                          py::make_tuple(f.cp, f.w, f.ol, f.mk.defined() ? py::cast(f.mk) : py::none(), f.geom, f.binb, f.img, f.radii,
+                                         f.norms, f.bgc, f.view, f.proj, f.cpos),
+                          f.handle);
 }
 
 // -> (longest tile list, n_visible); releases the handle
@@ -263,12 +282,13 @@ std::pair<int64_t, int64_t> view_wait(int64_t handle) {
 void view_abandon(int64_t handle) { cgs_view_forward_abandon((int)handle); }
 
 // Backward half: clamp gradient + cgs_view_backward.  -> (g_cp, g_w, g_ol, g_mk | None, g_m2d)
-py::tuple view_backward(const Tensor& cp, const Tensor& w, const Tensor& ol, const c10::optional<Tensor>& mk,
-                        const c10::optional<Tensor>& is_bezier_u8, const Tensor& coef, const Tensor& geom, const Tensor& binb,
-                        const Tensor& img, const Tensor& radii, const Tensor& norms, const Tensor& bgc, const Tensor& view,
-                        const Tensor& proj, const Tensor& cpos, int64_t m, double mask_thr, double tanx, double tany, int64_t H,
-                        int64_t W, double eps, const c10::optional<Tensor>& g_color_in, const c10::optional<Tensor>& color_raw,
-                        const c10::optional<std::vector<Tensor>>& sinks, const c10::optional<Tensor>& rot_extra) {
+struct ViewBwd { Tensor g_cp, g_w, g_ol, g_mk, g_m2d; };   // undefined = None (sinks took it / no mask)
+ViewBwd view_backward_core(const Tensor& cp, const Tensor& w, const Tensor& ol, const c10::optional<Tensor>& mk,
+                           const c10::optional<Tensor>& is_bezier_u8, const Tensor& coef, const Tensor& geom, const Tensor& binb,
+                           const Tensor& img, const Tensor& radii, const Tensor& norms, const Tensor& bgc, const Tensor& view,
+                           const Tensor& proj, const Tensor& cpos, int64_t m, double mask_thr, double tanx, double tany, int64_t H,
+                           int64_t W, double eps, const c10::optional<Tensor>& g_color_in, const c10::optional<Tensor>& color_raw,
+                           const c10::optional<std::vector<Tensor>>& sinks, const c10::optional<Tensor>& rot_extra) {
     c10::hip::HIPGuardMasqueradingAsCUDA guard(cp.device());
     const int B = (int)cp.size(0), P = B * (int)m;
     const auto fopt = cp.options().dtype(at::kFloat);
@@ -314,7 +334,9 @@ py::tuple view_backward(const Tensor& cp, const Tensor& w, const Tensor& ol, con
                                            scratch.data_ptr<float>(), CGS_VIEW_ACCUMULATE, st),
                   "cgs_view_backward_render");
         }
-        return py::make_tuple(py::none(), py::none(), py::none(), py::none(), g_m2d);
+        ViewBwd r;
+        r.g_m2d = g_m2d;
+        return r;
     }
     if (has(rot_extra)) raise_cgs("view_backward: rot_extra is served together with grad sinks only");
     // one allocation for the four curve-level gradients + the screen-space gradient, one for the scratch
@@ -338,7 +360,166 @@ py::tuple view_backward(const Tensor& cp, const Tensor& w, const Tensor& ol, con
                                        has_mk ? g_mk.data_ptr<float>() : nullptr, scratch.data_ptr<float>(), 0, st),
               "cgs_view_backward_render");
     }
-    return py::make_tuple(g_cp, g_w, g_ol, has_mk ? py::cast(g_mk) : py::none(), g_m2d);
+    ViewBwd r;
+    r.g_cp = g_cp; r.g_w = g_w; r.g_ol = g_ol; r.g_mk = g_mk; r.g_m2d = g_m2d;
+    return r;
+}
+py::object opt(const Tensor& t) { return t.defined() ? py::cast(t) : py::none(); }
+py::tuple view_backward(const Tensor& cp, const Tensor& w, const Tensor& ol, const c10::optional<Tensor>& mk,
+                        const c10::optional<Tensor>& is_bezier_u8, const Tensor& coef, const Tensor& geom, const Tensor& binb,
+                        const Tensor& img, const Tensor& radii, const Tensor& norms, const Tensor& bgc, const Tensor& view,
+                        const Tensor& proj, const Tensor& cpos, int64_t m, double mask_thr, double tanx, double tany, int64_t H,
+                        int64_t W, double eps, const c10::optional<Tensor>& g_color_in, const c10::optional<Tensor>& color_raw,
+                        const c10::optional<std::vector<Tensor>>& sinks, const c10::optional<Tensor>& rot_extra) {
+    const ViewBwd r = view_backward_core(cp, w, ol, mk, is_bezier_u8, coef, geom, binb, img, radii, norms, bgc, view, proj, cpos, m,
+                                         mask_thr, tanx, tany, H, W, eps, g_color_in, color_raw, sinks, rot_extra);
+    return py::make_tuple(opt(r.g_cp), opt(r.g_w), opt(r.g_ol), opt(r.g_mk), r.g_m2d);
+}
+
+// ------------------------------------------------------------------------------------------------ C++ autograd nodes
+// The fused view route and the photometric loss as torch::autograd::Function: their backward runs on the autograd engine's
+// device thread WITHOUT the GIL and without the Python custom-Function machinery (ctx object, argument tuple checks, a
+// Python frame per node) -- what `render()` + `loss.backward()` of the literal drop-in loop (train.py:95-148) pays per
+// iteration beside the kernels themselves.  Same kernels, same saved state as ops/view_render.py::_ViewRender, which stays
+// as the ctypes-bindings form (CGS_TORCH_SHIM=0).
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+py::object g_general_backward;   // Python: ops/view_render.py::_general_backward_cpp (re-render through the general route)
+
+struct ViewRenderFn : public torch::autograd::Function<ViewRenderFn> {
+    // thread-local side channel for what is not a tensor output (read by view_render() right behind apply())
+    static thread_local int t_handle;
+    static thread_local Tensor t_img;
+
+    // (absent tensors travel as c10::nullopt: an UNDEFINED Tensor argument makes Function::apply ask it for its device)
+    static variable_list forward(AutogradContext* ctx, const Tensor& curve_points, const Tensor& width, const Tensor& opacity_logit,
+                                 const c10::optional<Tensor>& mask_logit, const Tensor& means2D,
+                                 const c10::optional<Tensor>& is_bezier_u8, const c10::optional<Tensor>& is_bezier, const Tensor& coef, int64_t m, double mask_thr, const Tensor& bg, const Tensor& viewmatrix,
+                                 const Tensor& projmatrix, const Tensor& campos, double tanx, double tany, int64_t H, int64_t W, int64_t cap,
+                                 bool sync_free, bool clamp, bool want_dir, double eps, const std::vector<Tensor>& sinks) {
+        (void)means2D;
+        ViewFwd f = view_forward_core(curve_points, width, opacity_logit, mask_logit, is_bezier_u8, coef, m, mask_thr, bg, viewmatrix, projmatrix,
+                                      campos, tanx, tany, H, W, cap, sync_free, clamp, want_dir, eps);
+        t_handle = f.handle;
+        t_img = f.img;
+        ctx->save_for_backward({f.cp, f.w, f.ol, f.mk, f.geom, f.binb, f.img, f.radii, f.norms, f.bgc, f.view, f.proj, f.cpos, coef,
+                                is_bezier_u8.value_or(Tensor()), f.color_raw, is_bezier.value_or(Tensor())});
+        ctx->saved_data["m"] = m; ctx->saved_data["H"] = H; ctx->saved_data["W"] = W;
+        ctx->saved_data["mask_thr"] = mask_thr; ctx->saved_data["tanx"] = tanx; ctx->saved_data["tany"] = tany; ctx->saved_data["eps"] = eps;
+        ctx->saved_data["clamp"] = clamp;
+        ctx->saved_data["ran"] = false;
+        if (!sinks.empty()) {
+            // the sinks are the `.grad` tensors of FORWARD time; the owners are kept to see whether they still are at backward
+            ctx->saved_data["sinks"] = c10::List<Tensor>(sinks);
+            std::vector<Tensor> owners = {curve_points, width, opacity_logit};
+            if (has(mask_logit)) owners.push_back(*mask_logit);
+            ctx->saved_data["owners"] = c10::List<Tensor>(owners);
+        }
+        ctx->mark_non_differentiable({f.radii});
+        ctx->set_materialize_grads(false);
+        return {f.color_out, f.invd, f.amap, f.radii, f.rend_dir};
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list go) {
+        const variable_list sv = ctx->get_saved_variables();
+        const Tensor &cp = sv[0], &w = sv[1], &ol = sv[2], &mk = sv[3], &geom = sv[4], &binb = sv[5], &img = sv[6], &radii = sv[7],
+                     &norms = sv[8], &bgc = sv[9], &view = sv[10], &proj = sv[11], &cpos = sv[12], &coef = sv[13], &isb = sv[14],
+                     &color_raw = sv[15], &is_bezier = sv[16];
+        const int64_t m = ctx->saved_data["m"].toInt(), H = ctx->saved_data["H"].toInt(), W = ctx->saved_data["W"].toInt();
+        const double mask_thr = ctx->saved_data["mask_thr"].toDouble(), tanx = ctx->saved_data["tanx"].toDouble(),
+                     tany = ctx->saved_data["tany"].toDouble(), eps = ctx->saved_data["eps"].toDouble();
+        variable_list out(24);   // one slot per forward argument; only the first five can carry a gradient
+        const Tensor &g_color = go[0], &g_invd = go[1], &g_amap = go[2], &g_dir = go[4];
+        if (g_invd.defined() || g_amap.defined() || g_dir.defined()) {
+            // a loss on inverse depth / all_map / the direction map: re-render through the differentiable general route (Python)
+            py::gil_scoped_acquire gil;
+            if (!g_general_backward) raise_cgs("view_render: the general backward is not registered");
+            py::tuple r = g_general_backward(cp, w, ol, opt(mk), bgc, view, proj, cpos, is_bezier.defined() ? py::cast(is_bezier) : py::none(),
+                                             m, H, W, mask_thr, tanx, tany, eps, ctx->saved_data["clamp"].toBool(), opt(g_color), opt(g_invd),
+                                             opt(g_amap), opt(g_dir));
+            for (int i = 0; i < 5; i++)
+                if (!r[i].is_none()) out[i] = r[i].cast<Tensor>();
+            return out;
+        }
+        if (ctx->saved_data["ran"].toBool()) {
+            // a second backward over this forward (retain_graph): the sampling backward's two grid-wide sums were cleared by the
+            // forward's norm pass once -- clear them again
+            int first = 0, count = 0;
+            cgs_view_norms_backward_range(&first, &count);
+            norms.narrow(0, first, count).zero_();
+        }
+        c10::optional<std::vector<Tensor>> sinks;
+        if (ctx->saved_data.count("sinks")) {
+            const auto sk = ctx->saved_data["sinks"].toTensorList();
+            const auto ow = ctx->saved_data["owners"].toTensorList();
+            bool same = sk.size() == ow.size();
+            for (size_t i = 0; same && i < sk.size(); i++) {
+                const Tensor o = ow.get(i), s = sk.get(i);
+                same = o.grad().defined() && o.grad().unsafeGetTensorImpl() == s.unsafeGetTensorImpl();
+            }
+            if (same) sinks = std::vector<Tensor>(sk.begin(), sk.end());   // (else: replaced since the forward -> ordinary gradients)
+        }
+        const ViewBwd r = view_backward_core(cp, w, ol, mk.defined() ? c10::optional<Tensor>(mk) : c10::nullopt,
+                                             isb.defined() ? c10::optional<Tensor>(isb) : c10::nullopt, coef, geom, binb, img, radii, norms,
+                                             bgc, view, proj, cpos, m, mask_thr, tanx, tany, H, W, eps,
+                                             g_color.defined() ? c10::optional<Tensor>(g_color) : c10::nullopt,
+                                             color_raw.defined() ? c10::optional<Tensor>(color_raw) : c10::nullopt, sinks, c10::nullopt);
+        ctx->saved_data["ran"] = true;
+        out[0] = r.g_cp; out[1] = r.g_w; out[2] = r.g_ol; out[3] = r.g_mk; out[4] = r.g_m2d;
+        return out;
+    }
+};
+thread_local int ViewRenderFn::t_handle = -1;
+thread_local Tensor ViewRenderFn::t_img;
+
+// -> (color, invdepth, all_map, radii, rend_dir, handle, image buffer)
+py::tuple view_render(const Tensor& curve_points, const Tensor& width, const Tensor& opacity_logit, const c10::optional<Tensor>& mask_logit,
+                      const Tensor& means2D, const c10::optional<Tensor>& is_bezier_u8, const c10::optional<Tensor>& is_bezier,
+                      const Tensor& coef, int64_t m, double mask_thr, const Tensor& bg, const Tensor& viewmatrix, const Tensor& projmatrix,
+                      const Tensor& campos, double tanx, double tany, int64_t H, int64_t W, int64_t cap, bool sync_free, bool clamp,
+                      bool want_dir, double eps, const c10::optional<std::vector<Tensor>>& sinks) {
+    const variable_list o = ViewRenderFn::apply(curve_points, width, opacity_logit, mask_logit, means2D, is_bezier_u8, is_bezier, coef, m, mask_thr, bg,
+                                                viewmatrix, projmatrix, campos, tanx, tany, H, W, cap, sync_free, clamp, want_dir, eps,
+                                                sinks.value_or(std::vector<Tensor>()));
+    const int handle = ViewRenderFn::t_handle;
+    Tensor img = ViewRenderFn::t_img;
+    ViewRenderFn::t_img = Tensor();
+    return py::make_tuple(o[0], o[1], o[2], o[3], o[4], handle, img);
+}
+void set_general_backward(py::object fn) { g_general_backward = std::move(fn); }
+
+// loss = a * edge_aware_loss(x, gt) + b * (1 - ssim(x, gt)), x = clamp(image) if clamp (ops/losses.py::photometric_loss): value and
+// d loss / d image from cgs_photometric_loss in the forward; the backward hands the stored gradient on (times the upstream scalar
+// unless that is the shared unit tensor `unit`).
+struct PhotometricLossFn : public torch::autograd::Function<PhotometricLossFn> {
+    static Tensor forward(AutogradContext* ctx, const Tensor& image, const Tensor& gt, const Tensor& n_pos, const Tensor& ws, double thr,
+                          double a, double b, bool clamp, const c10::optional<Tensor>& unit) {
+        require_gpu(image, "image");
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(image.device());
+        const Tensor img = f32c(image.detach(), "image"), g = f32c(gt.detach(), "gt_image");
+        if (img.dim() != 3 || img.size(0) != 1) raise_cgs("photometric_loss: the fused path renders 1 channel");
+        const int H = (int)img.size(1), W = (int)img.size(2);
+        Tensor grad = at::empty_like(img);
+        Tensor loss = at::empty({}, img.options());
+        check(cgs_photometric_loss(H, W, fp(img), fp(g), (float)thr, (const uint32_t*)n_pos.data_ptr(), (float)a, (float)b, clamp ? 1 : 0,
+                                   ws.data_ptr(), grad.data_ptr<float>(), loss.data_ptr<float>(), stream_of(img)),
+              "cgs_photometric_loss");
+        ctx->save_for_backward({grad, unit.value_or(Tensor())});
+        return loss;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list go) {
+        const variable_list sv = ctx->get_saved_variables();
+        variable_list out(9);
+        const Tensor& g = go[0];
+        const bool is_unit = sv[1].defined() && g.defined() && g.numel() == 1 && g.data_ptr() == sv[1].data_ptr();
+        out[0] = is_unit ? sv[0] : sv[0] * g;
+        return out;
+    }
+};
+Tensor photometric_loss(const Tensor& image, const Tensor& gt, const Tensor& n_pos, const Tensor& ws, double thr, double a, double b,
+                        bool clamp, const c10::optional<Tensor>& unit) {
+    return PhotometricLossFn::apply(image, gt, n_pos, ws, thr, a, b, clamp, unit);
 }
 
 }  // namespace
@@ -359,6 +540,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
     mod.def("view_forward", &view_forward);
     mod.def("view_wait", &view_wait);
     mod.def("view_abandon", &view_abandon);
+    mod.def("view_render", &view_render);
+    mod.def("set_general_backward", &set_general_backward);
+    mod.def("photometric_loss", &photometric_loss);
     mod.def("view_backward", &view_backward, py::arg("cp"), py::arg("w"), py::arg("ol"), py::arg("mk"), py::arg("is_bezier_u8"),
             py::arg("coef"), py::arg("geom"), py::arg("binb"), py::arg("img"), py::arg("radii"), py::arg("norms"), py::arg("bgc"),
             py::arg("view"), py::arg("proj"), py::arg("cpos"), py::arg("m"), py::arg("mask_thr"), py::arg("tanx"), py::arg("tany"),

@@ -136,4 +136,23 @@ def photometric_loss(image, gt_image, lambda_mse=10.0, lambda_dssim=0.1, thresho
     """image, gt_image: [1,H,W].  Same value/gradient as composing (clamp,) edge_aware_loss and fused_ssim (tested).
     clamp=True takes the UNclamped rasterizer output and applies render()'s clamp(0,1) inside the kernels.
     n_pos: optional device int32 scalar from ``edge_pixel_count`` (graph-captured steps feed it through a static buffer)."""
+    if L.use_shim() and image.is_cuda and image.dim() == 3 and image.shape[0] == 1:
+        # the C++ autograd node of the compiled shim (csrc/torch_shim.cpp::PhotometricLossFn): same kernels, no Python frame in
+        # the backward
+        lib = L.load()
+        dev = image.device
+        gt = gt_image.detach().float().contiguous()
+        H, W = int(image.shape[1]), int(image.shape[2])
+        stream = L.raw_stream(dev)
+        if n_pos is None:
+            n_pos = _EdgeCountCache.get(gt, threshold, stream)
+        key = (str(dev), H, W, stream)
+        ws = _PhotometricLoss._workspaces.get(key)
+        if ws is None:
+            while len(_PhotometricLoss._workspaces) >= 6:
+                _PhotometricLoss._workspaces.pop(next(iter(_PhotometricLoss._workspaces)))
+            ws = _PhotometricLoss._workspaces[key] = torch.zeros(int(lib.cgs_photometric_workspace_bytes(H, W)), dtype=torch.uint8,
+                                                                  device=dev)
+        return L.shim().photometric_loss(image, gt, n_pos, ws, float(threshold), lambda_mse * (1.0 - lambda_dssim),
+                                         lambda_mse * lambda_dssim, bool(clamp), unit_grad(dev))
     return _PhotometricLoss.apply(image, gt_image, lambda_mse, lambda_dssim, threshold, clamp, n_pos)

@@ -302,10 +302,62 @@ def view_render(curve_points, width, opacity_logit, mask_logit, means2D, is_bezi
     mask_logit]) -- normally the parameters' `.grad` -- that the backward kernels ADD their gradients to; the node then hands
     autograd no gradient for those inputs (no AccumulateGrad kernels).  A loss that reaches depth / all_map / the direction
     map takes the general backward, which returns its gradients the ordinary way."""
-    if grad_sinks is not None and not L.use_shim():
-        grad_sinks = None
+    if L.use_shim():   # the C++ autograd node of the compiled shim (csrc/torch_shim.cpp::ViewRenderFn)
+        return _view_render_cpp(curve_points, width, opacity_logit, mask_logit, means2D, is_bezier, m, mask_thr, bg, cam, tanx, tany,
+                                static_cap, status_sink, clamp, want_dir, pending_out, eps, grad_sinks)
+    grad_sinks = None
     return _ViewRender.apply(curve_points, width, opacity_logit, mask_logit, means2D, is_bezier, m, mask_thr, bg, cam, tanx,
                              tany, static_cap, status_sink, clamp, want_dir, pending_out, eps, grad_sinks)
+
+
+_cpp_ready = []
+
+
+def _general_backward_cpp(cp, w, ol, mk, bgc, view, proj, campos, is_bezier, m, H, W, mask_thr, tanx, tany, eps, clamped, g_color, g_invd,
+                          g_amap, g_dir):
+    """Called by the C++ node's backward (with the GIL) when a gradient reaches inverse depth / all_map / the direction map."""
+    import types
+    empty = torch.empty(0, device=cp.device)
+    ctx = types.SimpleNamespace(
+        saved_tensors=(cp, w, ol, mk if mk is not None else empty, None, None, None, None, None, bgc, view, proj, campos),
+        dims=(cp.shape[0], int(m), int(H), int(W), float(mask_thr), float(tanx), float(tany), float(eps)), is_bezier=is_bezier,
+        has_mask=mk is not None, clamped=bool(clamped))
+    return _general_backward(ctx, g_color, g_invd, g_amap, g_dir)
+
+
+def _view_render_cpp(curve_points, width, opacity_logit, mask_logit, means2D, is_bezier, m, mask_thr, bg, cam, tanx, tany, static_cap,
+                     status_sink, clamp, want_dir, pending_out, eps, grad_sinks):
+    """view_render() on the compiled shim's autograd node: one pybind call builds the node and runs the forward; its backward
+    runs on the autograd engine's device thread without the GIL (the general backward of depth / normal losses calls back)."""
+    L.require_gpu_tensor(curve_points, "curve_points")
+    shim = L.shim()
+    if not _cpp_ready:
+        shim.set_general_backward(_general_backward_cpp)
+        _cpp_ready.append(True)
+    lib = L.load()
+    dev = curve_points.device
+    H, W = int(cam.image_height), int(cam.image_width)
+    P = curve_points.shape[0] * m
+    isb = _bezier_mask(is_bezier, dev)
+    coef = sample_coefficients(m, dev)
+    cap = int(static_cap) if static_cap else _capacity(lib, dev, P, W, H)
+    color, invd, amap, radii, rend_dir, handle, img = shim.view_render(
+        curve_points, width, opacity_logit, mask_logit, means2D, isb, is_bezier, coef, m, mask_thr, bg, cam.world_view_transform,
+        cam.full_proj_transform, cam.camera_center, tanx, tany, H, W, cap, bool(static_cap), bool(clamp), bool(want_dir), eps, grad_sinks)
+    if static_cap:
+        if status_sink is not None:
+            off, nw = int(lib.cgs_image_status_offset(W, H)), int(lib.cgs_status_words())
+            status_sink.append(img[off:off + 4 * nw].view(torch.int32))
+    else:
+        pend = Pending(handle, (dev.index, P, W, H), cap, img)
+        if pending_out is not None:
+            pending_out.append(pend)
+        else:
+            ok, _ = finish(pend)
+            if not ok:
+                raise L.CurveGSError("view_render: a tile list outgrew its bucket; call again (the capacity for this "
+                                     "shape has been raised) or pass pending_out and retry on finish() == False")
+    return color, invd, amap, radii, rend_dir
 
 
 def finish(pend):
