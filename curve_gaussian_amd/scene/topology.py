@@ -10,7 +10,8 @@ Reference: /root/reference/scene/gaussian_curve_model.py
   prune_curves :283-304   densification_postfix :306-326   densify_and_split_curve :330-349
   densify_and_prune :351-365   de_casteljau_trim :368-371   curve_split_curvature :373-390
   de_casteljau_split :392-425   only_prune :428-435   mask_trim_split :437-463
-``merge_curves`` (:466ff, RANSAC line fitting on the host) is not reproduced.
+``fit_curve_to_line`` :597-621 / ``merge_curves`` :459-595 (host-side numpy there and here; skimage's RANSAC and scipy's curve_fit
+restated, see below) -- what ever sets ``is_bezier = False`` during training (train.py:209-211).
 
 The functions take the model as first argument and are installed as methods of
 ``curve_gaussian_amd.scene.GaussianCurveModel`` under the reference's names.  Parity: the reference's scene package
@@ -305,7 +306,236 @@ def mask_trim_split(g, mask_threshold):
     g.prepare_scaling_rot()
 
 
-METHODS = dict(prune_curves=prune_curves, densification_postfix=densification_postfix,
+# ------------------------------------------------------------------------------------------------ line fitting / merging
+# train.py:209-211 (every merge interval): fit_curve_to_line turns Bezier curves that are straight into line segments --
+# what makes the line branch of prepare_scaling_rot live -- and merge_curves fuses end-to-end neighbours.  Host-side numpy in
+# the reference (scene/gaussian_curve_model.py:459-632 over edge_extraction/fitting.py, merging.py), host-side numpy here.
+# Two third-party pieces of the reference are absent from this image and restated: skimage's ransac(LineModelND) (the reference
+# calls it unseeded: its result is random; here a SEEDED sampler with the same model, residual and trial count) and
+# scipy.optimize.curve_fit on a model that is linear in its 12 parameters (= its linear least-squares solution).
+def get_curve_gaussians(g, t):
+    """:70-79 -- curve points at parameters t ([n,1,1]) -> [n,B,3]; straight segments on their chord."""
+    cp = g._curve_points
+    bez = (1 - t) ** 3 * cp[:, 0, :] + 3 * (1 - t) ** 2 * t * cp[:, 1, :] + 3 * (1 - t) * t ** 2 * cp[:, 2, :] + t ** 3 * cp[:, 3, :]
+    if bool(g.is_bezier.all()):
+        return bez
+    line = (1 - t) * cp[:, 0, :] + t * cp[:, 3, :]
+    return torch.where(g.is_bezier.unsqueeze(0).unsqueeze(2), bez, line)
+
+
+def fit_straight_line(points):
+    """edge_extraction/fitting.py:74-97 -- principal axis of the points and the extent of their projections on it."""
+    import numpy as np
+    mean_point = np.mean(points, axis=0)
+    centered = points - mean_point
+    cov = np.dot(centered.T, centered) / len(points)
+    eigenvalues, eigenvectors = np.linalg.eigh(cov)
+    direction = eigenvectors[:, np.argmax(eigenvalues)]
+    direction = direction / np.linalg.norm(direction)
+    projections = np.dot(points - mean_point, direction)
+    t_min, t_max = np.min(projections), np.max(projections)
+    return mean_point + t_min * direction, mean_point + t_max * direction, direction, mean_point, t_min, t_max
+
+
+def is_curve_straight(g, sample_points, threshold=0.002, threshold_max=0.004):
+    """:624-631 -- mean and maximum distance of the samples to their fitted segment below the two thresholds."""
+    import numpy as np
+    pts = sample_points.detach().cpu().numpy() if torch.is_tensor(sample_points) else np.asarray(sample_points)
+    start, end, direction, mean_point, t_min, t_max = fit_straight_line(pts)
+    t = np.dot(pts - mean_point, direction)
+    closest = mean_point + np.clip(t, t_min, t_max).reshape(-1, 1) * direction
+    d = np.linalg.norm(pts - closest, axis=1)
+    return bool((np.mean(d) < threshold) & (d.max() < threshold_max)), start, end
+
+
+def fit_curve_to_line(g, threshold=0.002, threshold_max=0.004, sample_num=100):
+    """:597-621 -- Bezier curves whose 100 samples lie on a segment become straight segments (is_bezier = False).  Like the
+    reference the control points themselves are NOT moved (its `new_curve_points[selected_mask][:, 0] = ...` assigns into a
+    copy made by the boolean index): the segment is the chord P0-P3 from then on, and the curve-point group's Adam moments
+    restart from zero (replace_tensor_to_optimizer)."""
+    dev = g._curve_points.device
+    t = torch.linspace(0, 1, sample_num, device=dev)[:, None, None]
+    with torch.no_grad():
+        samples = get_curve_gaussians(g, t).permute(1, 0, 2).contiguous().cpu()     # 'm b c -> b m c'
+        is_bez = g.is_bezier.cpu()
+    selected = torch.zeros(samples.shape[0], dtype=torch.bool)
+    for i in range(samples.shape[0]):
+        if not bool(is_bez[i]):
+            continue
+        ok, _start, _end = is_curve_straight(g, samples[i], threshold, threshold_max)
+        selected[i] = ok
+    if bool(selected.any()):
+        new_is_bezier = g.is_bezier.clone()
+        new_is_bezier[selected.to(dev)] = False
+        g.is_bezier = new_is_bezier
+        _, allp = replace_tensor_to_optimizer(g, g._curve_points.clone().detach(), "curve_points")
+        _install(g, allp)
+        g.prepare_scaling_rot()      # (the reference leaves that to the next statement, merge_curves / train.py:242-243)
+    _check_ranks(g)
+    return int(selected.sum())
+
+
+def _ransac_line(pts, residual_threshold, max_trials, rng):
+    """skimage.measure.ransac(pts, LineModelND, min_samples=2, residual_threshold, max_trials): the inlier mask of the best
+    two-point line (most inliers, then smallest residual sum), restated; `rng` seeded by the caller."""
+    import numpy as np
+    n = len(pts)
+    best, best_count, best_res = None, 0, np.inf
+    for _ in range(max_trials):
+        i, j = rng.choice(n, 2, replace=False)
+        d = pts[j] - pts[i]
+        nd = np.linalg.norm(d)
+        if nd == 0:
+            continue
+        d = d / nd
+        r = pts - pts[i]
+        res = np.linalg.norm(r - np.outer(r @ d, d), axis=1)
+        inl = res < residual_threshold
+        cnt, rs = int(inl.sum()), float((res ** 2).sum())
+        if cnt > best_count or (cnt == best_count and rs < best_res):
+            best, best_count, best_res = inl, cnt, rs
+        if best_count == n:
+            break
+    if best is None or best_count < 2:
+        raise ValueError("ransac: no line found")
+    return best
+
+
+def _line_fitting(endpoints):
+    """edge_extraction/fitting.py:27-50 -- SVD line through the points -> [start(3), end(3)]."""
+    import numpy as np
+    center = np.mean(endpoints, axis=0)
+    c = endpoints - center
+    _u, _s, vh = np.linalg.svd(c, full_matrices=False)
+    main = vh[0] / np.linalg.norm(vh[0])
+    proj = c @ main
+    out = np.zeros(6)
+    out[:3] = center + main * proj.min()
+    out[3:] = center + main * proj.max()
+    return out
+
+
+_BEZ_W = None
+
+
+def _bezier_fit(xyz, error_threshold=0.02):
+    """edge_extraction/fitting.py:52-72 -- cubic Bezier through n ordered points at t = linspace(0, 1, n); the model is linear in
+    its control points, so curve_fit's minimum is the least-squares solution.  -> 12 control-point coordinates, or None when the
+    RMSE exceeds error_threshold."""
+    import numpy as np
+    n = len(xyz)
+    t = np.linspace(0, 1, n)
+    T = np.stack([t ** 3, t ** 2, t, np.ones(n)], axis=1)
+    Wm = np.array([[-1, 3, -3, 1], [3, -6, 3, 0], [-3, 3, 0, 0], [1, 0, 0, 0]], float)
+    A = T @ Wm                                   # [n,4]: Bernstein weights of the four control points
+    P, *_ = np.linalg.lstsq(A, xyz.astype(float), rcond=None)
+    rmse = np.sqrt(np.mean(np.sum((xyz - A @ P) ** 2, axis=1)))
+    return None if rmse > error_threshold else P.reshape(-1)
+
+
+def merge_curves(g, distance_threshold=0.02, similarity_threshold=0.97, sample_num=100, ransac_thresh=0.005, seed=0):
+    """:459-595 -- (1) Bezier curves whose end points lie within 2 * distance_threshold and whose end tangents are parallel
+    (|cos| > similarity_threshold) are paired greedily (most parallel partner first), their 200 samples ordered along the RANSAC
+    line of the pair and refitted by ONE cubic Bezier if its RMSE stays below distance_threshold; (2) straight segments that are
+    close and parallel are merged per connected component into the segment spanning their samples.  Merged curves are pruned, the
+    new ones appended with the mean opacity / width of their sources.  -> number of curves removed."""
+    import numpy as np
+    dev = g._curve_points.device
+    rng = np.random.default_rng(seed)
+    with torch.no_grad():
+        t = torch.linspace(0, 1, sample_num, device=dev)[:, None, None]
+        samples = get_curve_gaussians(g, t).permute(1, 0, 2).contiguous()            # [B,n,3]
+        cp = g._curve_points.detach()
+        B = cp.shape[0]
+        is_bez = g.is_bezier.cpu().numpy().astype(bool)
+        all_points = torch.cat([cp[:, 0], cp[:, -1]], dim=0)
+        all_tangs = torch.cat([cp[:, 1] - cp[:, 0], cp[:, 2] - cp[:, -1]], dim=0)
+        all_tangs = all_tangs / (torch.norm(all_tangs, dim=-1, keepdim=True) + 1e-6)
+        similarity = torch.abs(all_tangs @ all_tangs.T)
+        dist = torch.cdist(all_points, all_points, p=2)
+        mm = (dist < 2 * distance_threshold) & (similarity > similarity_threshold)
+        adjacency = (mm[:B, :B] | mm[:B, B:] | mm[B:, :B] | mm[B:, B:]).cpu().numpy()
+        confidence = torch.max(torch.max(similarity[:B, :B], similarity[:B, B:]),
+                               torch.max(similarity[B:, :B], similarity[B:, B:])).cpu().numpy()
+        samples_h = samples.cpu().numpy()
+        merge_mask = np.zeros(B, bool)
+        new = dict(cp=[], op=[], w=[], bez=[])
+        merged, pairs = set(), []
+        for i in range(B):
+            if i in merged or not is_bez[i]:
+                continue
+            nb = [j for j in np.nonzero(adjacency[i])[0].tolist() if j not in merged and j != i and is_bez[j]]
+            if not nb:
+                continue
+            best_j = max(nb, key=lambda j: confidence[i, j])
+            merged.update((i, best_j))
+            pairs.append([i, best_j])
+        for comp in pairs:
+            pts = np.concatenate([samples_h[i] for i in comp], axis=0)
+            try:
+                inl = _ransac_line(pts, ransac_thresh, 1000, rng)
+                line_eps = _line_fitting(pts[inl])
+            except Exception:   # noqa: BLE001 -- like the reference: a pair without a line is left alone
+                continue
+            main = line_eps[3:] - line_eps[:3]
+            main = main / np.linalg.norm(main)
+            mean_pt = (line_eps[3:] + line_eps[:3]) / 2
+            pts = pts[np.argsort((pts - mean_pt) @ main)]
+            out = _bezier_fit(pts, error_threshold=distance_threshold)
+            if out is not None:
+                merge_mask[comp] = True
+                new["cp"].append(torch.from_numpy(out.reshape(4, 3)).float())
+                new["op"].append(g._opacity.detach()[comp].mean(dim=0, keepdim=True))
+                new["w"].append(g._width.detach()[comp].mean(dim=0, keepdim=True))
+                new["bez"].append(True)
+        line_idx = np.nonzero(~is_bez)[0]
+        if len(line_idx) > 0:
+            from scipy.sparse.csgraph import connected_components
+            seg = cp.cpu().numpy()[line_idx][:, [0, -1], :].reshape(len(line_idx), 6)
+            n = len(seg)
+            dmat = np.zeros((n, n))
+
+            def seg_point(s6, q):   # edge_extraction/merging.py:63-82
+                p1, p2 = s6[:3], s6[3:]
+                d = p2 - p1
+                u = np.clip(np.dot(q - p1, d) / np.dot(d, d), 0, 1)
+                return np.linalg.norm(p1 + u * d - q)
+            for a in range(n):      # :84-106 (upper triangle, mirrored)
+                for b in range(a + 1, n):
+                    dmat[a, b] = min(seg_point(seg[a], seg[b][:3]), seg_point(seg[a], seg[b][3:]))
+            dmat = dmat + dmat.T
+            dv = seg[:, 3:] - seg[:, :3]
+            dvn = dv / np.maximum(np.linalg.norm(dv, axis=1, keepdims=True), 1e-30)
+            sim = np.abs(dvn @ dvn.T)     # sklearn cosine_similarity
+            ncomp, labels = connected_components((dmat <= distance_threshold) & (sim >= similarity_threshold))
+            for c in range(ncomp):
+                members = np.nonzero(labels == c)[0]
+                if len(members) == 1:
+                    continue
+                comp = line_idx[members]
+                merge_mask[comp] = True
+                start, end, *_ = fit_straight_line(samples_h[comp].reshape(-1, 3))
+                out = np.zeros((4, 3), np.float32)
+                out[0], out[-1] = start, end
+                new["cp"].append(torch.from_numpy(out).float())
+                new["op"].append(g._opacity.detach()[comp.tolist()].mean(dim=0, keepdim=True))
+                new["w"].append(g._width.detach()[comp.tolist()].mean(dim=0, keepdim=True))
+                new["bez"].append(False)
+    removed = int(merge_mask.sum())
+    if removed:
+        k = len(new["cp"])
+        fdc, frest, msk = g._features_dc.detach()[0:1], g._features_rest.detach()[0:1], torch.ones_like(g._mask.detach()[0:1])
+        prune_curves(g, torch.from_numpy(merge_mask).to(dev))
+        densification_postfix(g, torch.stack(new["cp"]).to(dev), fdc.repeat(k, 1, 1, 1), frest.repeat(k, 1, 1, 1),
+                              torch.cat(new["op"]).to(dev), torch.cat(new["w"]).to(dev), msk.repeat(k, 1, 1),
+                              torch.tensor(new["bez"], dtype=torch.bool, device=dev))
+        g.prepare_scaling_rot()
+    _check_ranks(g)
+    return removed
+
+
+METHODS = dict(fit_curve_to_line=fit_curve_to_line, is_curve_straight=is_curve_straight, merge_curves=merge_curves,
+               get_curve_gaussians=get_curve_gaussians, prune_curves=prune_curves, densification_postfix=densification_postfix,
                densify_and_split_curve=densify_and_split_curve, densify_and_prune=densify_and_prune,
                curve_split_curvature=curve_split_curvature, only_prune=only_prune, reset_opacity=reset_opacity,
                fix_opacity=fix_opacity, mask_trim_split=mask_trim_split, de_casteljau_split=de_casteljau_split,

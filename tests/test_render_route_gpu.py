@@ -200,6 +200,26 @@ def test_grad_sinks_replaced_between_forward_and_backward_fall_back_to_autograd(
         assert_close(n, getattr(gm, n).grad.cpu(), getattr(ref, n).grad.cpu(), rel=2e-4)
 
 
+def test_fused_route_and_loss_are_cpp_autograd_nodes_under_the_shim():
+    """with the compiled shim the fused view route and the photometric loss are torch::autograd::Function nodes of
+    _cgs_torch.so (their backward runs on the engine's device thread without the GIL); CGS_TORCH_SHIM=0 keeps the Python nodes."""
+    from curve_gaussian_amd import _lib as L
+    from curve_gaussian_amd.gaussian_renderer import PipelineParams, render
+    from curve_gaussian_amd.ops.losses import photometric_loss
+    if not L.use_shim():
+        pytest.skip("ctypes bindings selected")
+    c, mask, cam = _small()
+    cam = cam.to(DEV)
+    gm = _model(c, mask)
+    pkg = render(cam, gm, PipelineParams(), torch.zeros(3, device=DEV), clamp=False)
+    assert "ViewRenderFn" in pkg["render"].grad_fn.name(), pkg["render"].grad_fn.name()
+    gt = (torch.rand(1, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(1)) > 0.9).float().to(DEV)
+    loss = photometric_loss(pkg["render"], gt, 10.0, 0.1, clamp=True)
+    assert "PhotometricLossFn" in loss.grad_fn.name(), loss.grad_fn.name()
+    loss.backward()
+    assert float(gm._curve_points.grad.abs().max()) > 0 and pkg["viewspace_points"].grad is not None
+
+
 def test_fused_route_backward_twice_over_one_forward():
     """retain_graph + two backwards through one fused render(): the second one gives the same gradients again (the grid-wide
     sums of the sampling backward are cleared by the forward once and by the node before any further backward)."""

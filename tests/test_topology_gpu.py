@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import S
+from util import S, assert_close
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -209,3 +209,99 @@ def test_checkpoint_resume_continues_the_trajectory(fused_a, fused_b, tmp_path):
         # same back end: only the order of the compositor's float atomics differs between the runs; different back ends: the
         # two Adam implementations round differently as well (test_prune_and_split_keep_both_optimizers...)
         np.testing.assert_allclose(_params(g1)[n], v, rtol=2e-5 if same_backend else 2e-4, atol=2e-7 if same_backend else 2e-6, err_msg=n)
+
+
+def _line_merge_model():
+    """30 random curved Beziers + 6 straight ones (control points evenly spaced on a chord, wobbling by 2e-4) + one smooth curve
+    cut in two by de Casteljau at 0.5 (its halves are end-to-end neighbours with parallel end tangents)."""
+    from curve_gaussian_amd.scene import GaussianCurveModel
+    c = S.make_curves(30, 11)
+    g = torch.Generator().manual_seed(11)
+    # (the synthetic curves are short and nearly straight: bend them well beyond the 4e-3 line threshold)
+    bend = torch.nn.functional.normalize(torch.randn(30, 1, 3, generator=g), dim=-1) * 0.03
+    c["curve_points"][:, 1:2] += bend
+    c["curve_points"][:, 2:3] += bend
+    a = torch.rand(6, 3, generator=g) * 0.6 + 0.2
+    d = torch.nn.functional.normalize(torch.randn(6, 3, generator=g), dim=-1) * 0.15
+    straight = torch.stack([a + d * k / 3.0 for k in range(4)], 1) + 2e-4 * torch.randn(6, 4, 3, generator=g)
+    whole = torch.tensor([[[0.2, 0.2, 0.5], [0.3, 0.32, 0.5], [0.45, 0.36, 0.5], [0.6, 0.3, 0.5]]])
+    l = lambda p, q: 0.5 * (p + q)
+    p0, p1, p2, p3 = whole[0]
+    a0, a1, a2 = l(p0, p1), l(p1, p2), l(p2, p3)
+    b0, b1 = l(a0, a1), l(a1, a2)
+    mid = l(b0, b1)
+    halves = torch.stack([torch.stack([p0, a0, b0, mid]), torch.stack([mid, b1, a2, p3])])
+    cp = torch.cat([c["curve_points"], straight, halves])
+    B = cp.shape[0]
+    width = torch.cat([c["width"], c["width"][:8]])
+    opac = torch.cat([c["opacity"], c["opacity"][:8]])
+    gm = GaussianCurveModel(0, 12, device=DEV).create_from_curves(cp, width, opac, torch.ones(B, 12, 1), torch.ones(B, dtype=torch.bool))
+    return gm, whole
+
+
+def test_fit_curve_to_line_and_merge_curves_like_the_reference_loop():
+    """train.py:209-211: fit_curve_to_line flips straight Beziers to segments (control points untouched -- the reference's masked
+    assignment writes into a copy --, Adam moments of the curve points restart), merge_curves fuses the two halves of a cut curve
+    back into one Bezier and parallel touching segments into one; the model keeps training through both render routes."""
+    from curve_gaussian_amd.gaussian_renderer import PipelineParams, render
+    from curve_gaussian_amd.train_step import TrainStep
+    gm, whole = _line_merge_model()
+    cam = S.make_camera((0.5, -1.7, 0.9), (0.5, 0.5, 0.5), (0, 0, 1), 64, 96).to(DEV)
+    gt = render(cam, gm, PipelineParams(), torch.zeros(3, device=DEV))["render"].detach()
+    ts = TrainStep(gm, [cam], [gt], seed=1)
+    for _ in range(3):
+        ts.step()
+    assert float(gm.optimizer.state_of("curve_points")[0].abs().max()) > 0
+    cp_before = gm._curve_points.detach().clone()
+    B0 = cp_before.shape[0]
+    n = gm.fit_curve_to_line(0.002, 0.004)
+    # the six built straight are found (a random bent curve may pass too when its bend happens to lie along its chord)
+    assert 6 <= n <= 8 and int((~gm.is_bezier).sum()) == n and bool((~gm.is_bezier[30:36]).all()) and bool(gm.is_bezier[36:38].all())
+    assert torch.equal(gm._curve_points.detach(), cp_before)                       # quirk kept: the points are not moved
+    assert float(gm.optimizer.state_of("curve_points")[0].abs().max()) == 0.0      # replace_tensor_to_optimizer
+    assert gm._curve_points.grad is not None and gm._curve_points.grad.data_ptr() == ts.flat.view("curve_points").data_ptr()
+    # the line branch renders the chord: same image through the fused and the general route
+    a = render(cam, gm, PipelineParams(), torch.zeros(3, device=DEV))["render"]
+    b = render(cam, gm, PipelineParams(), torch.zeros(3, device=DEV), fused=False)["render"]
+    assert_close("fused vs general with segments", a.detach().cpu().numpy(), b.detach().cpu().numpy(), min_outliers=4)
+    removed = gm.merge_curves(0.02, 0.97)
+    assert removed >= 2 and gm._curve_points.shape[0] < B0
+    assert gm.is_bezier.shape[0] == gm._curve_points.shape[0] == gm._opacity.shape[0] == gm._mask.shape[0]
+    # the two halves came back as ONE Bezier that follows the original curve
+    t = torch.linspace(0, 1, 50, device=DEV)[:, None, None]
+    pts = gm.get_curve_gaussians(t).permute(1, 0, 2)                               # [B,50,3]
+    w = whole.to(DEV)[0]
+    tt = t[:, 0]
+    ref = (1 - tt) ** 3 * w[0] + 3 * (1 - tt) ** 2 * tt * w[1] + 3 * (1 - tt) * tt ** 2 * w[2] + tt ** 3 * w[3]    # [50,3]
+    d = torch.cdist(pts.reshape(-1, 3), ref).min(dim=1).values.reshape(pts.shape[0], 50).max(dim=1).values
+    span = (pts[:, 0] - pts[:, -1]).norm(dim=-1)
+    whole_span = float((w[0] - w[3]).norm())
+    hit = (d < 5e-3) & (span > 0.9 * whole_span)
+    assert int(hit.sum()) == 1, (d.min(), span[d.argmin()], whole_span)
+    for _ in range(3):        # still trains (topology listener rebound the flat buffers)
+        loss, _ = ts.step()
+    assert np.isfinite(float(loss))
+    td = TrainStep(gm, [cam], [gt], seed=1, direct=True)
+    assert np.isfinite(float(td.step()[0]))
+
+
+def test_merge_curves_fuses_touching_parallel_segments():
+    from curve_gaussian_amd.scene import GaussianCurveModel
+    c = S.make_curves(12, 13)
+    seg = torch.zeros(3, 4, 3)
+    seg[0, 0], seg[0, 3] = torch.tensor([0.1, 0.5, 0.5]), torch.tensor([0.3, 0.5, 0.5])
+    seg[1, 0], seg[1, 3] = torch.tensor([0.305, 0.5, 0.5]), torch.tensor([0.5, 0.502, 0.5])
+    seg[2, 0], seg[2, 3] = torch.tensor([0.8, 0.1, 0.2]), torch.tensor([0.8, 0.3, 0.2])       # far away: stays
+    for k in range(3):
+        seg[k, 1] = seg[k, 0] + (seg[k, 3] - seg[k, 0]) / 3
+        seg[k, 2] = seg[k, 0] + (seg[k, 3] - seg[k, 0]) * 2 / 3
+    cp = torch.cat([c["curve_points"], seg])
+    isb = torch.cat([torch.ones(12, dtype=torch.bool), torch.zeros(3, dtype=torch.bool)])
+    gm = GaussianCurveModel(0, 12, device=DEV).create_from_curves(cp, torch.cat([c["width"], c["width"][:3]]),
+                                                                  torch.cat([c["opacity"], c["opacity"][:3]]), torch.ones(15, 12, 1), isb)
+    removed = gm.merge_curves(0.02, 0.97)
+    assert removed >= 2
+    lines = gm._curve_points.detach()[~gm.is_bezier]
+    assert lines.shape[0] == 2
+    lens = (lines[:, 0] - lines[:, 3]).norm(dim=-1)
+    assert float(lens.max()) > 0.39          # the merged segment spans both sources (0.1 .. 0.5)
