@@ -752,6 +752,46 @@ def test_view_path_matches_the_frozen_oracle_chain(name):
         assert rel < 5e-4, f"view_{name}: dL/d{pname} relative L2 error {rel:.2e}"
 
 
+@pytest.mark.parametrize("B,H,W,opaque,wide,ties", [(900, 128, 160, False, 0.0, False), (1000, 96, 128, True, 0.8, False),
+                                                     (500, 64, 80, True, 1.0, False), (600, 96, 96, False, 0.3, True)])
+def test_bucket_capacity_and_sort_placement_do_not_change_the_view(B, H, W, opaque, wide, ties):
+    """The same scene with bucket capacity 1 024 (tile sort INSIDE the unit-colour forward) and with 2 048 / 4 096 (separate
+    sort launches, non-sorting forward -- the cfg5 route): images, saved per-pixel state and cuts are bit-identical, the
+    gradients agree to float-atomics noise.  Cases: short lists, lists of several batches with early termination (opaque, fat
+    splats), equal depths (coincident curves).  (Written for round 6's lazy batch-by-batch ordering of long buckets, which
+    passed it bit for bit and lost on time: profiles/r06_experiments.md #6.)"""
+    curves = S.make_curves(B, 31 + B)
+    curves["width"] = curves["width"] + wide
+    if opaque:
+        curves = _opaque(curves)
+    if ties:   # every curve three times: equal depths in every tile list
+        for k in ("curve_points", "width", "opacity", "is_bezier"):
+            curves[k] = torch.cat([curves[k][: B // 3]] * 3)
+    cam = S.make_camera((0.5, -1.7, 0.9), (0.5, 0.5, 0.5), (0, 0, 1), H, W)
+    dimg = torch.randn(1, H, W, generator=torch.Generator().manual_seed(B)).to(DEV)
+    outs = {}
+    for cap in (1024, 2048, 4096):
+        vc = _ViewCalls(curves["curve_points"], curves["width"], curves["opacity"], curves["is_bezier"], cam, cap)
+        vc.forward()
+        n = curves["curve_points"].shape[0]
+        g = [vc.f32(n, 4, 3), vc.f32(n, 1), vc.f32(n, 1)]
+        g_m2d = vc.backward(dimg, *g, 0)
+        off = (4 * H * W + 127) // 128 * 128
+        ncw = vc.img[off:off + 4 * H * W].view(torch.int32).clone()
+        outs[cap] = (vc.color.clone(), vc.invd.clone(), vc.omap.clone(), vc.final_T(), ncw, [t.clone() for t in g], g_m2d)
+    longest = int((outs[1024][4] & 0x7fffffff).max())
+    ref = outs[1024]
+    for cap in (2048, 4096):
+        o = outs[cap]
+        for a, b, name in zip(o[:5], ref[:5], ("color", "invdepth", "all_map", "final_T", "n_contrib")):
+            assert torch.equal(a, b), f"cap {cap}: {name} differs from the sorting forward"
+        for a, b, name in zip(o[5], ref[5], ("curve_points", "width", "opacity")):
+            rel = float((a - b).norm() / b.norm().clamp_min(1e-30))
+            assert rel < 1e-3, f"cap {cap}: dL/d{name} relative L2 {rel:.2e}"
+    print(f"deepest cut / list position {longest}")
+    assert longest > 0
+
+
 @pytest.mark.parametrize("W,H,B,seed,bg,opaque,wide", [(70, 50, 60, 1, 0.0, False, 0.0), (129, 97, 300, 2, 0.35, False, 0.0),
                                                          (160, 128, 900, 3, 0.0, True, 0.0), (48, 16, 40, 4, 0.0, False, 1.5),
                                                          (333, 211, 2500, 5, 0.2, True, 0.8), (16, 16, 5, 6, 0.0, False, 0.0),
