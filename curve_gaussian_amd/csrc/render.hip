@@ -75,7 +75,8 @@ constexpr int GROUP = 16;
 // What-if builds (profiles/probes/kernel_times.py, profiles/r06_experiments.md): the forward with ONE cost removed -- wrong
 // images on purpose, only the times mean something.  Bits: 1 no pair walk (operands + MFMAs stay), 2 no groups at all (sort,
 // staging and lists stay), 4 walk without the per-pair LDS read of the splat's channels, 8 walk without v_exp, 16 walk without the
-// termination test, 32 fused rank + stage path without the ranking loop, 64 no per-pixel output stores.  0 in every product build.
+// termination test, 32 fused rank + stage path without the ranking loop, 64 no per-pixel output stores, 128 staging without the
+// quadrant reach test (every mask 15), 256 staging without the record gather, 512 no list building.  0 in every product build.
 #ifndef CGS_WHATIF
 #define CGS_WHATIF 0
 #endif
@@ -180,7 +181,7 @@ __global__ void __launch_bounds__(256, UNIT ? CGS_FWD3_WAVES : CGS_FWD3_WAVES_GE
             const SplatRec* r = rec + id;
             float4 ra = make_float4(0.f, 0.f, 1.f, 0.f), rb = make_float4(1.f, 0.f, 0.f, 0.f), rc = ra;
             float tau2 = -1.f;
-            if (has) {
+            if (has && !(CGS_WHATIF & 256)) {
                 ra = r->a;
                 rb = r->b;
                 if (GEO) rc = r->c;
@@ -201,7 +202,7 @@ __global__ void __launch_bounds__(256, UNIT ? CGS_FWD3_WAVES : CGS_FWD3_WAVES_GE
                     s_geo[slot] = sa;
                     s_at[slot] = make_float4(sb.z, sb.w, sb.x, __builtin_amdgcn_logf(sb.y));
                     if (GEO) s_c[GEO ? slot : 0] = UNIT ? make_float4(rc.x, rc.y, rc.z, sb.w) : rc;
-                    const uint32_t qm = quadrant_mask(ra, rb, tau2, X0, Y0);
+                    const uint32_t qm = (CGS_WHATIF & 128) ? 15u : quadrant_mask(ra, rb, tau2, X0, Y0);
                     lost = atomicExch(&s_si[rk[0]], 0x100u | qm);
                     bs.point_list[base + rk[0]] = TAG ? (id | (qm << LIST_TAG_SHIFT)) : id;
                 }
@@ -275,7 +276,7 @@ __global__ void __launch_bounds__(256, UNIT ? CGS_FWD3_WAVES : CGS_FWD3_WAVES_GE
         }
         __syncthreads();
         }
-        if (wave_done) continue;
+        if (wave_done || (CGS_WHATIF & 512)) continue;
         // ---- this wave's list: the staged entries its quadrant accepted, in list order, padded to a multiple of 16
         int n = 0;
 #pragma unroll
