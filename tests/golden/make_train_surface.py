@@ -12,9 +12,8 @@ for no, line in enumerate(open(REF), 1):
     for m in re.finditer(r"\bgaussians\.([A-Za-z_][A-Za-z_0-9]*)", line):
         names.setdefault(m.group(1), []).append(no)
 # SURVEY.md section 2 marks these OUT OF SCOPE (CPU/numpy post-processing and visualisation of the trained curves)
-out_of_scope = {"merge_curves": "RANSAC line fitting + endpoint merging, numpy/scipy on the host (SURVEY 2a row 6)",
-                "fit_curve_to_line": "host-side line fitting (SURVEY 2a row 6)",
-                "draw_curve": "matplotlib visualisation (SURVEY 2a row 14)",
+# (merge_curves / fit_curve_to_line, SURVEY 2a row 6, were on this list until round 6: scene/topology.py has them now)
+out_of_scope = {"draw_curve": "matplotlib visualisation (SURVEY 2a row 14)",
                 "draw_ellipsoids": "matplotlib visualisation (SURVEY 2a row 14)"}
 out = {"source": "train.py of zhirui-gao/Curve-Gaussian (reference snapshot 2025-09-05)",
        "names": {k: names[k] for k in sorted(names)}, "out_of_scope": out_of_scope}
