@@ -385,7 +385,9 @@ py::tuple view_backward(const Tensor& cp, const Tensor& w, const Tensor& ol, con
 using torch::autograd::AutogradContext;
 using torch::autograd::variable_list;
 
-py::object g_general_backward;   // Python: ops/view_render.py::_general_backward_cpp (re-render through the general route)
+// Python: ops/view_render.py::_general_backward_cpp (re-render through the general route).  A leaked pointer on purpose: a
+// static py::object would be destroyed after the interpreter has been finalised.
+py::object* g_general_backward = nullptr;
 
 struct ViewRenderFn : public torch::autograd::Function<ViewRenderFn> {
     // thread-local side channel for what is not a tensor output (read by view_render() right behind apply())
@@ -435,7 +437,7 @@ struct ViewRenderFn : public torch::autograd::Function<ViewRenderFn> {
             // a loss on inverse depth / all_map / the direction map: re-render through the differentiable general route (Python)
             py::gil_scoped_acquire gil;
             if (!g_general_backward) raise_cgs("view_render: the general backward is not registered");
-            py::tuple r = g_general_backward(cp, w, ol, opt(mk), bgc, view, proj, cpos, is_bezier.defined() ? py::cast(is_bezier) : py::none(),
+            py::tuple r = (*g_general_backward)(cp, w, ol, opt(mk), bgc, view, proj, cpos, is_bezier.defined() ? py::cast(is_bezier) : py::none(),
                                              m, H, W, mask_thr, tanx, tany, eps, ctx->saved_data["clamp"].toBool(), opt(g_color), opt(g_invd),
                                              opt(g_amap), opt(g_dir));
             for (int i = 0; i < 5; i++)
@@ -487,7 +489,10 @@ py::tuple view_render(const Tensor& curve_points, const Tensor& width, const Ten
     ViewRenderFn::t_img = Tensor();
     return py::make_tuple(o[0], o[1], o[2], o[3], o[4], handle, img);
 }
-void set_general_backward(py::object fn) { g_general_backward = std::move(fn); }
+void set_general_backward(py::object fn) {
+    if (g_general_backward) *g_general_backward = std::move(fn);
+    else g_general_backward = new py::object(std::move(fn));
+}
 
 // loss = a * edge_aware_loss(x, gt) + b * (1 - ssim(x, gt)), x = clamp(image) if clamp (ops/losses.py::photometric_loss): value and
 // d loss / d image from cgs_photometric_loss in the forward; the backward hands the stored gradient on (times the upstream scalar
