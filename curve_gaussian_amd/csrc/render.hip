@@ -97,6 +97,11 @@ constexpr int GROUP = 16;
 // (176 us); with three views in flight the matching footprints let forward and backward workgroups of neighbouring views
 // share CUs evenly: 567 -> 597 Msplats/s.  (A branch-free walk -- eight pairs' exp2 / rcp / colour reads in flight before
 // the sequential recurrence -- was 8 us faster at 5 waves, but needs 32 more live registers: 589 at 6 waves with spills.)
+// What-if builds of the general backward (profiles/r06_experiments.md section 8; 0 in product builds): 1 = no flush (the
+// splat-parallel moment passes), 2 = no recurrences in the walk (exp2 + tests + the store stay), 4 = no combining pass
+#ifndef CGS_BWD3_WHATIF
+#define CGS_BWD3_WHATIF 0
+#endif
 #ifndef CGS_BWD3_WAVES
 #define CGS_BWD3_WAVES 6
 #endif
@@ -674,6 +679,11 @@ __global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG)
                         const float m = sat01(fmaf(e, k.big, k.cA)) * sat01((float)wv[u] - jmin_f);
                         const float alpha_u = e * m;
                         const float alpha = fminf(0.99f, alpha_u);
+                        if (CGS_BWD3_WHATIF & 2) {
+                            sg[u * SSTRIDE + pix_off] = alpha;
+                            if (EXTRA) sw[u * SSTRIDE + pix_off] = alpha_u;
+                            continue;
+                        }
                         // The reference keeps (last_alpha, last_colour) and folds them into the "colour behind" accumulator at
                         // the start of the next step (backward.cu:605,620,631); folding right after use is the same
                         // recurrence -- acc' = acc + alpha (c - acc) -- with one fma per channel.
@@ -703,7 +713,7 @@ __global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG)
                         if (EXTRA) sw[u * SSTRIDE + pix_off] = v_w;
                     }
                     // ---- flush the eight slots
-                    {
+                    if (!(CGS_BWD3_WHATIF & 1)) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -801,7 +811,7 @@ __global__ void __launch_bounds__(256, GEO ? CGS_BWD3_WAVES_GEO : (INVD || COLG)
         }
         // ---- the batch's per-splat sums leave the workgroup: lane (entry, field) -> consecutive floats of the splat's
         // 64-byte accumulator record = one L2 request per entry
-        {
+        if (!(CGS_BWD3_WHATIF & 4)) {
             __syncthreads();
             const int nb = min(BB, total - i * BB);
             uint64_t tm[4][NC];
