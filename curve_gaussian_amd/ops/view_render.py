@@ -65,7 +65,12 @@ class _ViewRender(torch.autograd.Function):
     loss of train.py:98-107 reads `render` alone.  A gradient arriving at inverse depth, all_map or the direction map (a depth
     / normal loss: the reference's rasterizer backward takes grad_out_depth and grad_out_all_map,
     diff_cur_rasterization/__init__.py:117-151) is served too: the backward then re-renders the view through the general
-    operator route under autograd and pulls all upstream gradients through it (_general_backward)."""
+    operator route under autograd and pulls all upstream gradients through it (_general_backward).  Tolerance of that route:
+    the re-render bins with exact-size lists instead of the forward's fixed-capacity buckets and evaluates alpha on the general
+    compositor; its image equals the one the forward returned within the parity criterion of tests/util.py (1e-4 of the
+    tensor's maximum: test_default_render_takes_the_fused_route_and_equals_the_general_one), so a mixed colour + depth loss gets
+    gradients that are exact for the re-rendered image and within 2e-4 relative of the all-general computation
+    (test_fused_route_serves_depth_and_normal_losses)."""
 
     @staticmethod
     def forward(ctx, curve_points, width, opacity_logit, mask_logit, means2D, is_bezier, m, mask_thr, bg, cam, tanx, tany,
