@@ -1169,6 +1169,40 @@ def test_bench_default_command_runs_every_section():
     assert gr["roofline"]["bound"] == "hbm" and 0 < gr["roofline"]["frac"] < 1
 
 
+@pytest.mark.parametrize("flags,launch", [
+    (["--mode", "raster"], None),
+    (["--no-graph"], "eager launches (fused direct body"),
+    (["--autograd-view"], "hipGraph replay per view (autograd body"),
+    (["--no-graph", "--autograd-view"], "eager launches (autograd body"),
+    (["--no-pingpong"], "hipGraph replay per view (fused direct body"),
+    (["--streams", "1", "--views-per-step", "1"], "hipGraph replay per view (fused direct body"),
+], ids=["raster", "eager_direct", "graph_autograd", "eager_autograd", "single_gradient_set", "reference_schedule"])
+def test_bench_other_schedules(flags, launch):
+    """Every schedule bench.py's ViewPipeline offers besides the default one, short, on the smallest config: each runs to its
+    JSON line, says which launch form it used, and -- wherever views overlap or graphs replay -- reproduces the serial eager
+    step gradient (bench.check_step_gradient raises otherwise)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--min-seconds", "0.2", "--config", "cfg1",
+           "--no-cpu-baseline", "--no-train-step"] + flags
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["value"] > 0 and out["config"]["mode"] == ("raster" if "raster" in flags else "view")
+    if launch is not None:
+        assert out["config"]["launch"].startswith(launch), out["config"]["launch"]
+        assert out["kernel_ms_per_view"]["render_fwd"] > 0
+    if "step_gradient_rel_l2_vs_serial_eager" in out:
+        assert out["step_gradient_rel_l2_vs_serial_eager"] < 1e-3
+    if "--no-pingpong" in flags:
+        assert out["step_boundary"] == "join per step"
+
+
 def test_connection_loss_matches_the_reference_block():
     """cgs_endpoint_connection_loss (O(B) memory, one sweep) against train.py:133-146 written out with torch.cdist:
     value, gradient w.r.t. the control points (only first and last points receive one), the no-pair case, and end points
