@@ -920,7 +920,10 @@ def test_unit_colour_instances_agree_with_the_general_ones_on_random_scenes():
         keep = ~moved.view(B, 12).any(dim=1)          # curves none of whose splats carries a flipped pair
         for name, a, b, b2 in zip(("curve_points", "width", "opacity"), u["g"], gen["g"], out["general_again"]["g"]):
             noise = l2(b2, b)
-            assert noise < 1e-3, f"{where}: dL/d{name}: the general instances differ from themselves by {noise:.2e}"
+            # (premise, not parity: a camera inside a cloud of e^2.5-times-wider curves amplifies the raster backward's 3e-6
+            # atomics-order noise in dL/dmeans2D two-hundredfold on its way through the sampling backward -- 1e-4 .. 1.1e-3 for
+            # dL/dcurve_points and dL/dwidth over six runs of CGS_FUZZ_SEED=6100 case 74, with round 5's kernels as well)
+            assert noise < 3e-3, f"{where}: dL/d{name}: the general instances differ from themselves by {noise:.2e}"
             assert l2(a[keep], b[keep]) < 1e-3 + 4.0 * noise and bool(torch.isfinite(a).all()), \
                 f"{where}: dL/d{name} {l2(a[keep], b[keep]):.2e} (run-to-run noise of the general instances {noise:.2e})"
         done += 1

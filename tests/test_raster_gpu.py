@@ -899,18 +899,30 @@ def test_bucket_path_equals_exact_path_on_random_scenes():
             gref = bwd(ref, d, rs, g)
             # (the same backward over the same state once more: what the order of the float atomics alone moves -- up to
             # 2e-4 of the maximum in 1 of 640 campaign scenes, CGS_FUZZ_SEED=414)
-            noise = [float((a - b).abs().max()) if a.numel() else 0.0 for a, b in zip(bwd(ref, d, rs, g), gref)]
+            # The noise is itself a random draw: the largest of three repeats (one repeat under-estimated it in 4 of 6 000 scenes
+            # of the round-6 campaign, CGS_FUZZ_SEED 6101 / 6102 / 6110 / 6112 -- none of them reproducible on a second run).
+            noise = [0.0] * len(gref)
+            for _ in range(3):
+                noise = [max(nz, float((a - b).abs().max()) if a.numel() else 0.0) for nz, a, b in zip(noise, bwd(ref, d, rs, g), gref)]
             for k in range(3):
                 o = fwd(d, rs, H, W, False)
                 assert o[0] == R, (case, k)
-                for a, b in ((o[1], ref[1]), (o[2], ref[2]), (o[6], ref[6]), (o[7], ref[7])):
-                    assert torch.equal(a, b), (case, k)
+                for name, a, b in (("color", o[1], ref[1]), ("radii", o[2], ref[2]), ("invdepth", o[6], ref[6]), ("all_map", o[7], ref[7])):
+                    if not torch.equal(a, b):
+                        diff = (a.double() - b.double()).abs().reshape(-1)
+                        where = torch.nonzero(diff > 0).flatten()
+                        raise AssertionError(f"case {case} call {k} (P={P} {W}x{H}): {name} differs from the debug forward's at "
+                                             f"{where.numel()} of {diff.numel()} elements, max {float(diff.max()):.3e}, first at "
+                                             f"{where[:4].tolist()}: {a.reshape(-1)[where[:2]].tolist()} vs {b.reshape(-1)[where[:2]].tolist()}")
                 orr, ol, _, _ = _decode_state(o[3], o[4], o[5], P, H, W, R)
                 assert ((orr[:, 1] - orr[:, 0]) == lens).all(), (case, k)
                 for t in range(len(lens)):
                     assert (ol[orr[t, 0]:orr[t, 1]] == rl[rr[t, 0]:rr[t, 1]]).all(), (case, k, t)
-                for a, b, nz in zip(bwd(o, d, rs, g), gref, noise):
+                for gi, (a, b, nz) in enumerate(zip(bwd(o, d, rs, g), gref, noise)):
                     if a.numel():
-                        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 4.0 * nz + 1e-9, (case, k)
+                        got = float((a - b).abs().max())
+                        assert got <= 2e-4 * float(b.abs().max()) + 4.0 * nz + 1e-9, \
+                            (f"case {case} call {k} (P={P} {W}x{H}): gradient {gi} differs from the debug forward's by {got:.3e} "
+                             f"(max |ref| {float(b.abs().max()):.3e}, run-to-run noise of the reference {nz:.3e})")
     finally:
         lib.cgs_reset_binning_hints()
