@@ -918,11 +918,23 @@ def test_bucket_path_equals_exact_path_on_random_scenes():
                 assert ((orr[:, 1] - orr[:, 0]) == lens).all(), (case, k)
                 for t in range(len(lens)):
                     assert (ol[orr[t, 0]:orr[t, 1]] == rl[rr[t, 0]:rr[t, 1]]).all(), (case, k, t)
-                for gi, (a, b, nz) in enumerate(zip(bwd(o, d, rs, g), gref, noise)):
-                    if a.numel():
-                        got = float((a - b).abs().max())
-                        assert got <= 2e-4 * float(b.abs().max()) + 4.0 * nz + 1e-9, \
-                            (f"case {case} call {k} (P={P} {W}x{H}): gradient {gi} differs from the debug forward's by {got:.3e} "
-                             f"(max |ref| {float(b.abs().max()):.3e}, run-to-run noise of the reference {nz:.3e})")
+                # A difference in the ORDER of the float atomics is not persistent: the reference's own run-to-run difference has a heavy
+                # tail (CGS_FUZZ_SEED=6104 case 71, 12 000 splats on 16 x 64: typically 1e-7 of the maximum, 1e-4 once in a few
+                # hundred repeats -- for the debug forward's state against itself exactly as for the bucket state against it), so a
+                # gradient that misses the bound is recomputed: a structural difference shows in every repeat, a rare ordering in one.
+                got_all = [[float((a - b).abs().max()) if a.numel() else 0.0 for a, b in zip(bwd(o, d, rs, g), gref)]]
+                bound = [2e-4 * float(b.abs().max()) + 4.0 * nz + 1e-9 if b.numel() else 0.0 for b, nz in zip(gref, noise)]
+                for _ in range(2):
+                    if all(min(col) <= bd for col, bd in zip(zip(*got_all), bound)):
+                        break
+                    got_all.append([float((a - b).abs().max()) if a.numel() else 0.0 for a, b in zip(bwd(o, d, rs, g), gref)])
+                if not all(min(col) <= bd for col, bd in zip(zip(*got_all), bound)):
+                    # ... unless the rare ordering sits in the reference run itself: judge against a fresh one
+                    gref = bwd(ref, d, rs, g)
+                    got_all = [[float((a - b).abs().max()) if a.numel() else 0.0 for a, b in zip(bwd(o, d, rs, g), gref)] for _ in range(2)]
+                for gi, (col, bd, b, nz) in enumerate(zip(zip(*got_all), bound, gref, noise)):
+                    assert min(col) <= bd, \
+                        (f"case {case} call {k} (P={P} {W}x{H}): gradient {gi} differs from the debug forward's by {[f'{x:.3e}' for x in col]} "
+                         f"in {len(col)} runs (max |ref| {float(b.abs().max()):.3e}, run-to-run noise of the reference {nz:.3e})")
     finally:
         lib.cgs_reset_binning_hints()
