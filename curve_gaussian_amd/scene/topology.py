@@ -415,7 +415,32 @@ def _line_fitting(endpoints):
     return out
 
 
-_BEZ_W = None
+def _pairwise_segment_distances(seg):
+    """edge_extraction/merging.py:63-108 -- [n,6] segments -> symmetric [n,n]: for a < b the smaller of the distances of b's two end
+    points to segment a (point-to-segment, the foot clipped to the segment)."""
+    import numpy as np
+    n = len(seg)
+    dmat = np.zeros((n, n))
+
+    def seg_point(s6, q):   # :63-82
+        p1, p2 = s6[:3], s6[3:]
+        d = p2 - p1
+        u = np.clip(np.dot(q - p1, d) / np.dot(d, d), 0, 1)
+        return np.linalg.norm(p1 + u * d - q)
+    for a in range(n):      # :84-106 (upper triangle, mirrored)
+        for b in range(a + 1, n):
+            dmat[a, b] = min(seg_point(seg[a], seg[b][:3]), seg_point(seg[a], seg[b][3:]))
+    return dmat + dmat.T
+
+
+def _pairwise_cosine_similarity(seg):
+    """edge_extraction/merging.py:58-61 (sklearn's cosine_similarity of the direction vectors, signed)."""
+    import numpy as np
+    dv = seg[:, 3:] - seg[:, :3]
+    dvn = dv / np.maximum(np.linalg.norm(dv, axis=1, keepdims=True), 1e-30)
+    return dvn @ dvn.T
+
+
 
 
 def _bezier_fit(xyz, error_threshold=0.02):
@@ -492,21 +517,8 @@ def merge_curves(g, distance_threshold=0.02, similarity_threshold=0.97, sample_n
         if len(line_idx) > 0:
             from scipy.sparse.csgraph import connected_components
             seg = cp.cpu().numpy()[line_idx][:, [0, -1], :].reshape(len(line_idx), 6)
-            n = len(seg)
-            dmat = np.zeros((n, n))
-
-            def seg_point(s6, q):   # edge_extraction/merging.py:63-82
-                p1, p2 = s6[:3], s6[3:]
-                d = p2 - p1
-                u = np.clip(np.dot(q - p1, d) / np.dot(d, d), 0, 1)
-                return np.linalg.norm(p1 + u * d - q)
-            for a in range(n):      # :84-106 (upper triangle, mirrored)
-                for b in range(a + 1, n):
-                    dmat[a, b] = min(seg_point(seg[a], seg[b][:3]), seg_point(seg[a], seg[b][3:]))
-            dmat = dmat + dmat.T
-            dv = seg[:, 3:] - seg[:, :3]
-            dvn = dv / np.maximum(np.linalg.norm(dv, axis=1, keepdims=True), 1e-30)
-            sim = np.abs(dvn @ dvn.T)     # sklearn cosine_similarity
+            dmat = _pairwise_segment_distances(seg)
+            sim = np.abs(_pairwise_cosine_similarity(seg))     # (:557)
             ncomp, labels = connected_components((dmat <= distance_threshold) & (sim >= similarity_threshold))
             for c in range(ncomp):
                 members = np.nonzero(labels == c)[0]

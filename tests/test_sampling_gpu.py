@@ -49,6 +49,28 @@ def test_sample_curves_forward_backward(B, seed, lines):
     assert_close("dL_dwidth", w.grad.cpu().numpy(), w64.grad.numpy(), rel=1e-4, outlier_frac=0, abs_floor=1e-6)
 
 
+@pytest.mark.parametrize("case", ["mixed", "bezier", "lines"])
+def test_sample_curves_matches_the_reference_generated_fixture(case):
+    """k_sample_f12 / k_sample_f3 / k_sample_bwd against tests/golden/prepare_scaling_rot.npz -- outputs and autograd gradients of the
+    REFERENCE's own GaussianCurveModel.prepare_scaling_rot (gaussian_curve_model.py:180-198; tests/golden/make_model_golden.py imports
+    it), not of the restatement: mixed Bezier / straight curves, all Bezier, all straight.  Tolerances of the test above."""
+    import os
+    from curve_gaussian_amd.ops.curve_sampling import sample_curves
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "prepare_scaling_rot.npz"))
+    t = lambda k: torch.from_numpy(z[f"{case}_{k}"])
+    cp = t("curve_points").to(DEV).requires_grad_(True)
+    w = t("width").to(DEV).requires_grad_(True)
+    xyz, rot, scl = sample_curves(cp, w, t("is_bezier").to(DEV), 12)
+    ((xyz * t("cot_xyz").to(DEV)).sum() + (rot * t("cot_rotation").to(DEV)).sum() + (scl * t("cot_scaling").to(DEV)).sum()).backward()
+    torch.cuda.synchronize()
+    assert_close("xyz", xyz.detach().cpu().numpy(), z[f"{case}_xyz"], rel=1e-6, outlier_frac=0)
+    assert_close("scaling", scl.detach().cpu().numpy(), z[f"{case}_scaling"], rel=1e-4, outlier_frac=0)
+    assert_close("rotation", rot.detach().cpu().numpy(), z[f"{case}_rotation"], rel=1e-4, outlier_frac=2e-3)
+    # (the file's gradients also carry the opacity functional: it does not reach curve_points / width)
+    assert_close("dL_dcurve_points", cp.grad.cpu().numpy(), z[f"{case}_grad_curve_points"], rel=1e-4, outlier_frac=2e-3, abs_floor=1e-6)
+    assert_close("dL_dwidth", w.grad.cpu().numpy(), z[f"{case}_grad_width"], rel=1e-4, outlier_frac=0, abs_floor=1e-6)
+
+
 def test_sample_curves_none_grads_and_reentry():
     from curve_gaussian_amd.ops.curve_sampling import sample_curves
     c = _curves(300, 9, False)

@@ -180,3 +180,59 @@ def test_all_bezier_model_takes_the_short_path():
     t = 0.2 + 0.6 * torch.rand(int(sel.sum()), 1, generator=g)
     gm.densify_and_split_curve(sel.to(DEV), t.to(DEV)); ref.densify_and_split_curve(sel, t)
     _check(gm, ref, "split, all Bezier")
+
+
+@pytest.mark.parametrize("flat", [False, True])
+def test_topology_edits_match_the_reference_generated_fixture(flat):
+    """scene/topology.py against tests/golden/topology.npz -- the states the REFERENCE ITSELF went through on the CPU
+    (tests/golden/make_topology_golden.py imports scene/gaussian_curve_model.py and calls prune_curves, reset_opacity, only_prune and
+    mask_trim_split unmodified over a real torch.optim.Adam, Adam steps in between): after every recorded step the six parameter
+    tensors, both Adam moments of every group, is_bezier, the statistics buffers and the derived splat tensors, for both optimizer
+    back ends of the product.  (The restatement oracle/topology_ref.py is held to the same file by tests/test_model_golden_cpu.py.)"""
+    import os
+    from curve_gaussian_amd.ops.optim import FlatAdam
+    from curve_gaussian_amd.scene import GaussianCurveModel
+    from curve_gaussian_amd.view_parallel import FlatGrads
+    from util import replay_topology_fixture
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "topology.npz"))
+    t = lambda k: torch.from_numpy(z[k])
+    gm = GaussianCurveModel(0, 12, device=DEV).create_from_curves(t("in_curve_points"), t("in_width"), t("in_opacity"), t("in_mask"),
+                                                                   t("in_is_bezier"))
+    with torch.no_grad():
+        gm._features_dc.copy_(t("in_f_dc").to(DEV))
+    gm.training_setup()
+    if flat:
+        named = {"curve_points": gm._curve_points, "width": gm._width, "opacity": gm._opacity, "mask": gm._mask,
+                 "f_dc": gm._features_dc, "f_rest": gm._features_rest}
+        fg = FlatGrads(named)
+        gm.optimizer = FlatAdam(named, {grp["name"]: grp["lr"] for grp in gm.optimizer.param_groups}, fg, eps=1e-15)
+        gm.prepare_scaling_rot()
+    n = lambda x: x.detach().cpu().numpy()
+    seen = []
+
+    def check(tag):
+        seen.append(tag)
+        for name in GROUPS:
+            got, want = getattr(gm, ATTR[name]), z[f"{tag}.{name}"]
+            assert tuple(got.shape) == want.shape, f"{tag}: shape of {name}"
+            np.testing.assert_allclose(n(got), want, rtol=2e-5, atol=2e-6, err_msg=f"{tag}: {name}")
+            mom = _moments(gm, name)
+            assert mom is not None, f"{tag}: {name} lost its Adam state"
+            if want.size:
+                np.testing.assert_allclose(n(mom[0]), z[f"{tag}.exp_avg.{name}"], rtol=2e-5, atol=1e-9, err_msg=f"{tag}: exp_avg {name}")
+                np.testing.assert_allclose(n(mom[1]), z[f"{tag}.exp_avg_sq.{name}"], rtol=2e-5, atol=1e-12, err_msg=f"{tag}: exp_avg_sq {name}")
+        assert np.array_equal(n(gm.is_bezier), z[f"{tag}.is_bezier"]), tag
+        for name in ("xyz_gradient_accum", "denom", "max_radii2D"):
+            np.testing.assert_allclose(n(getattr(gm, name)), z[f"{tag}.{name}"], rtol=1e-6, atol=0, err_msg=f"{tag}: {name}")
+        np.testing.assert_allclose(n(gm._xyz), z[f"{tag}.xyz"], rtol=2e-5, atol=2e-6, err_msg=f"{tag}: xyz")
+        np.testing.assert_allclose(n(gm._scaling), z[f"{tag}.scaling"], rtol=1e-4, atol=2e-6, err_msg=f"{tag}: scaling")
+    replay_topology_fixture(gm, z, DEV, check)
+    assert len(seen) == 7 and gm._curve_points.shape[0] == z["adam_after_trim.curve_points"].shape[0] == 41
+    # de Casteljau at per-curve parameters, mixed Bezier / straight curves (gaussian_curve_model.py:388-421, :366-369)
+    from curve_gaussian_amd.scene import topology as T
+    gm.is_bezier = t("dc_is_bezier").to(DEV)
+    left, right = T.de_casteljau_split(gm, t("dc_curves").to(DEV), t("dc_t").to(DEV), t("dc_is_bezier").to(DEV))
+    np.testing.assert_allclose(n(left), z["dc_left"], rtol=0, atol=2e-7)
+    np.testing.assert_allclose(n(right), z["dc_right"], rtol=0, atol=2e-7)
+    trimmed = T.de_casteljau_trim(gm, t("dc_curves").to(DEV), t("dc_from_t").to(DEV), t("dc_end_t").to(DEV), t("dc_is_bezier").to(DEV))
+    np.testing.assert_allclose(n(trimmed), z["dc_trimmed"], rtol=0, atol=4e-7)

@@ -156,3 +156,52 @@ def carve_offsets(base_ptr_mod, counts_and_sizes):
         offs.append(cur - base_ptr_mod)
         cur += count * size
     return offs
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# tests/golden/topology.npz (make_topology_golden.py: the REFERENCE's own topology edits run on the CPU) replayed on a model that
+# offers the reference's method names -- oracle/topology_ref.RefCurveModel on the CPU, the product's GaussianCurveModel on the GPU
+TOPOLOGY_GROUPS = (("f_dc", "_features_dc"), ("f_rest", "_features_rest"), ("opacity", "_opacity"), ("width", "_width"),
+                   ("curve_points", "_curve_points"), ("mask", "_mask"))
+TOPOLOGY_TAGS = ("setup", "prune_curves", "reset_opacity", "adam_after_reset", "only_prune", "mask_trim_split", "adam_after_trim")
+
+
+def replay_topology_fixture(model, z, dev, check):
+    """Runs the fixture's sequence of Adam steps and edits on `model`; check(tag) is called after every recorded state."""
+    import torch
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+    step = [0]
+
+    def adam_step():
+        k = step[0]
+        step[0] += 1
+        for name, attr in TOPOLOGY_GROUPS:
+            p = getattr(model, attr)
+            g = t(f"grad{k}_{name}")
+            assert tuple(g.shape) == tuple(p.shape), (k, name, tuple(g.shape), tuple(p.shape))
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+        model.optimizer.step()
+        model.prepare_scaling_rot()
+    model.xyz_gradient_accum = t("in_xyz_gradient_accum").clone()
+    model.denom = t("in_denom").clone()
+    model.tmp_radii = t("in_tmp_radii").clone()
+    for _ in range(3):
+        adam_step()
+    check("setup")
+    model.prune_curves(t("prune_mask"))
+    check("prune_curves")
+    model.reset_opacity()
+    check("reset_opacity")
+    adam_step()
+    check("adam_after_reset")
+    with torch.no_grad():
+        model._opacity.add_(t("opacity_bump"))
+    model.only_prune(0.12, 0.3)
+    check("only_prune")
+    model.mask_trim_split(0.4)
+    check("mask_trim_split")
+    adam_step()
+    check("adam_after_trim")
