@@ -129,6 +129,15 @@ class RefCurveModel:
         opacities_new = torch.logit(torch.min(op, torch.ones_like(op) * 0.1)).detach()
         self._opacity = self.replace_tensor_to_optimizer(opacities_new, "opacity")["opacity"]
 
+    def fix_opacity(self):                                                                          # GCM:270-279
+        op = self.get_curve_opacity
+        opacities_new = torch.logit(torch.max(op, 0.6 * torch.ones_like(op))).detach()
+        self._opacity = self.replace_tensor_to_optimizer(opacities_new, "opacity")["opacity"]
+        self._opacity.requires_grad = False
+        for group in self.optimizer.param_groups:
+            if group["name"] == "opacity":
+                group["lr"] = 0.
+
     def prune_curves(self, mask):                                                                   # GCM:283-304
         valid_curves_mask = ~mask
         self._take(self._prune_optimizer(valid_curves_mask))

@@ -7,7 +7,7 @@ poisoned placeholders that raise if any called function touches them).
 
 Called, all from scene/gaussian_curve_model.py (the methods without a hard-coded device='cuda'; densification_postfix :306-327
 and densify_and_split_curve :329-347 allocate on 'cuda' and cannot run here):
-    _prune_optimizer :246-262, reset_opacity :264-268, prune_curves :282-304, de_casteljau_trim :366-369,
+    _prune_optimizer :246-262, reset_opacity :264-268, fix_opacity :270-279, prune_curves :282-304, de_casteljau_trim :366-369,
     de_casteljau_split :388-421, only_prune :424-431, mask_trim_split :433-457, is_curve_straight :623-631,
     prepare_scaling_rot :180-198 (inside the edits), and scene/gaussian_model.py replace_tensor_to_optimizer :460-473
 over a real torch.optim.Adam built from the group list of training_setup :203-213 (training_setup itself allocates its two
@@ -131,6 +131,10 @@ def main():
     snap("mask_trim_split")
     adam_step()
     snap("adam_after_trim")
+    g.fix_opacity()                                         # :270-279 (train.py:199)
+    snap("fix_opacity")
+    out["fix_opacity.requires_grad"] = np.bool_(g._opacity.requires_grad)
+    out["fix_opacity.lr_opacity"] = np.float64([grp["lr"] for grp in g.optimizer.param_groups if grp["name"] == "opacity"][0])
 
     # ---- the pure functions
     Bc = g._curve_points.shape[0]

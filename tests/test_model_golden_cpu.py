@@ -119,7 +119,7 @@ def test_oracle_topology_edits_match_the_reference_run():
         np.testing.assert_allclose(snap["scaling"].numpy(), z[f"{tag}.scaling"], rtol=3e-6, atol=1e-9, err_msg=f"{tag}: scaling")
         np.testing.assert_allclose(snap["rotation"].numpy(), z[f"{tag}.rotation"], rtol=0, atol=2e-6, err_msg=f"{tag}: rotation")
     replay_topology_fixture(ref, z, "cpu", check)
-    assert len(seen) == 7 and z["only_prune.curve_points"].shape[0] < z["adam_after_reset.curve_points"].shape[0]
+    assert len(seen) == 8 and z["only_prune.curve_points"].shape[0] < z["adam_after_reset.curve_points"].shape[0]
     # ---- the pure functions
     ref.is_bezier = t("dc_is_bezier")
     left, right = ref.de_casteljau_split(t("dc_curves"), t("dc_t"), t("dc_is_bezier"))

@@ -227,7 +227,7 @@ def test_topology_edits_match_the_reference_generated_fixture(flat):
         np.testing.assert_allclose(n(gm._xyz), z[f"{tag}.xyz"], rtol=2e-5, atol=2e-6, err_msg=f"{tag}: xyz")
         np.testing.assert_allclose(n(gm._scaling), z[f"{tag}.scaling"], rtol=1e-4, atol=2e-6, err_msg=f"{tag}: scaling")
     replay_topology_fixture(gm, z, DEV, check)
-    assert len(seen) == 7 and gm._curve_points.shape[0] == z["adam_after_trim.curve_points"].shape[0] == 41
+    assert len(seen) == 8 and gm._curve_points.shape[0] == z["adam_after_trim.curve_points"].shape[0] == 41
     # de Casteljau at per-curve parameters, mixed Bezier / straight curves (gaussian_curve_model.py:388-421, :366-369)
     from curve_gaussian_amd.scene import topology as T
     gm.is_bezier = t("dc_is_bezier").to(DEV)

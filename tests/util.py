@@ -163,7 +163,8 @@ def carve_offsets(base_ptr_mod, counts_and_sizes):
 # offers the reference's method names -- oracle/topology_ref.RefCurveModel on the CPU, the product's GaussianCurveModel on the GPU
 TOPOLOGY_GROUPS = (("f_dc", "_features_dc"), ("f_rest", "_features_rest"), ("opacity", "_opacity"), ("width", "_width"),
                    ("curve_points", "_curve_points"), ("mask", "_mask"))
-TOPOLOGY_TAGS = ("setup", "prune_curves", "reset_opacity", "adam_after_reset", "only_prune", "mask_trim_split", "adam_after_trim")
+TOPOLOGY_TAGS = ("setup", "prune_curves", "reset_opacity", "adam_after_reset", "only_prune", "mask_trim_split", "adam_after_trim",
+                 "fix_opacity")
 
 
 def replay_topology_fixture(model, z, dev, check):
@@ -205,3 +206,9 @@ def replay_topology_fixture(model, z, dev, check):
     check("mask_trim_split")
     adam_step()
     check("adam_after_trim")
+    model.fix_opacity()
+    check("fix_opacity")
+    assert model._opacity.requires_grad == bool(z["fix_opacity.requires_grad"]) == False
+    lr = model.optimizer.lr_of("opacity") if hasattr(model.optimizer, "lr_of") else \
+        [grp["lr"] for grp in model.optimizer.param_groups if grp["name"] == "opacity"][0]
+    assert float(lr) == float(z["fix_opacity.lr_opacity"]) == 0.0
